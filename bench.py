@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the fused view-synthesis loss path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = forward + backward of the multi-scale photometric loss (sfm_loss_fwd + sfm_loss_bwd
+through the C ABI) over one synthetic batch that is already resident in HBM, plus -- for
+N > 1 -- the RCCL all-reduce of the five reported scalars.  The workload at any N is
+BASELINE.json configs[2]/[3]: B = 32 samples PER GPU, 128x416, 4 scales, 2 sources,
+L1 + SSIM(0.15) + second-order smoothness(0.1) (experiments/sfm_learner_v1_ssim.yml), weak scaling.
+
+Metric: warped output Mpixels/s, pixels := B * n_src * sum_s h_s*w_s per step.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+PKG = "sfm-learner-chainer_amd"
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+BYTES_FWD, BYTES_BWD = 28, 32   # algorithmic bytes per warped pixel, SURVEY.md §8(d)
+
+WORKLOADS = {
+    # name: (B per GPU, H, W, n_src, n_scales, loss config, description)
+    "cfg3": (32, 128, 416, 2, 4, dict(smooth_reg=0.1, ssim_rate=0.15),
+             "BASELINE cfg3: B=32/GPU, 128x416, 4 scales, 2 src, L1+SSIM(0.15)+2nd-order smoothness(0.1)"),
+    "cfg2": (8, 128, 416, 2, 4, dict(smooth_reg=0.1),
+             "BASELINE cfg2: B=8, 128x416, 4 scales, 2 src, L1 + smoothness"),
+    "cfg3_edge": (32, 128, 416, 2, 4, dict(smooth_reg=0.1, ssim_rate=0.15, smooth_mode="edge_aware"),
+                  "cfg3 with the edge-aware smoothness (base_model.py:144-155)"),
+    "cfg5": (8, 256, 832, 4, 4, dict(smooth_reg=0.1, ssim_rate=0.15),
+             "BASELINE cfg5: B=8, 256x832, 5-frame (4 src), 4 scales"),
+    "cfg5_2src": (8, 256, 832, 2, 4, dict(smooth_reg=0.1, ssim_rate=0.15),
+                  "BASELINE cfg5 as parenthesised: B=8, 256x832, 2 src, 4 scales"),
+}
+
+
+class HipEvents:
+    """Raw hipEvent_t pairs (torch.cuda.Event does not expose a handle before its first record)."""
+
+    def __init__(self):
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        self.hip.hipEventDestroy.argtypes = [C.c_void_p]
+
+    def create(self):
+        ev = C.c_void_p()
+        assert self.hip.hipEventCreate(C.byref(ev)) == 0
+        return ev
+
+    def elapsed_ms(self, a, b):
+        ms = C.c_float()
+        assert self.hip.hipEventElapsedTime(C.byref(ms), a, b) == 0
+        return ms.value
+
+    def destroy(self, ev):
+        self.hip.hipEventDestroy(ev)
+
+
+def cpu_baseline(budget_s=15.0):
+    """The oracle (NumPy restatement of the reference's CPU path) timed on this box's host
+    cores on BASELINE cfg1: B=1, 128x416, 1 scale, 2 sources, L1 only, forward + backward."""
+    import numpy as np
+    from oracle import sfm_oracle as O
+    synth = importlib.import_module(PKG + ".synth")
+    d = synth.make_inputs(B=1, H=128, W=416, n_src=2, n_scales=1, seed=1)
+
+    def step():
+        return O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], backward=True)
+
+    step()
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while len(times) < 20 and (time.perf_counter() < t_end or len(times) < 3):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    px = 1 * 2 * 128 * 416
+    return {"value": round(px / med / 1e6, 4), "unit": "Mpix/s", "cores": 1, "kind": "port",
+            "sample": "cfg1 (B=1, 128x416, 1 scale, 2 src, L1 only) fwd+bwd, median of %d runs, %.3f s/step; "
+                      "single-threaded NumPy oracle, host has %d cores (%d usable)" % (
+                          len(times), med, os.cpu_count(), len(os.sched_getaffinity(0)))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="separate", choices=["separate", "fused"],
+                    help="separate: sfm_loss_fwd then sfm_loss_bwd (the reference's forward / loss.backward()); "
+                         "fused: one sfm_loss_fwd_bwd launch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    ops = importlib.import_module(PKG + ".ops")
+    synth = importlib.import_module(PKG + ".synth")
+    B, H, W, n_src, n_scales, cfg, desc = WORKLOADS[args.workload]
+    d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=n_scales, seed=1 + rank)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    fl = ops.FusedLoss(**cfg).bind([t(a) for a in d["tgt_pyr"]], [t(a) for a in d["src_pyr"]], t(d["intrinsics"]),
+                                   [t(a) for a in d["disps"]], [t(a) for a in d["poses"]], norm_B=B * world)
+    warped_px = B * n_src * sum((H >> s) * (W >> s) for s in range(n_scales))
+
+    ev = HipEvents()
+    lib = ops.lib
+
+    def step(evs=None):
+        if args.mode == "fused":
+            if evs:
+                lib.sfm_loss_profile_events(evs[0], evs[1])
+            fl.forward_backward()
+        else:
+            if evs:
+                lib.sfm_loss_profile_events(evs[0], evs[1])
+            fl.forward()
+            if evs:
+                lib.sfm_loss_profile_events(evs[2], evs[3])
+            fl.backward(1.0)
+        if world > 1:
+            dist.all_reduce(fl.loss5)       # the five reported scalars, summed over shards (RCCL)
+
+    for _ in range(args.warmup):
+        step()
+    events = [[ev.create() for _ in range(4)] for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # per-launch duration of the main kernels, from the HIP events recorded inside the timed region
+    k_fwd = float(np.mean([ev.elapsed_ms(e[0], e[1]) for e in events]))
+    k_bwd = float(np.mean([ev.elapsed_ms(e[2], e[3]) for e in events])) if args.mode == "separate" else None
+    loss = fl.loss5.cpu().numpy().tolist()
+    for e4 in events:
+        for e in e4:
+            ev.destroy(e)
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        value = warped_px * world / (elapsed / args.steps) / 1e6
+        if args.mode == "fused":
+            kname, kbytes, kms = "loss_kernel<grad+loss> (sfm_loss_fwd_bwd)", BYTES_FWD + BYTES_BWD, k_fwd
+        else:
+            kname, kbytes, kms = "loss_kernel<grad> (sfm_loss_bwd)", BYTES_BWD, k_bwd
+        achieved = kbytes * warped_px / (kms * 1e-3) / 1e9
+        out = {
+            "metric": "warp+photo-loss fwd+bwd Mpixels/s @128x416x4scales; % HBM roofline",
+            "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "per_gpu_batch": B, "global_batch": B * world, "H": H, "W": W, "n_src": n_src,
+                       "n_scales": n_scales, "mode": args.mode, "warped_px_per_gpu_step": warped_px,
+                       "parallelism": "batch-sharded x%d, RCCL all-reduce of 5 scalars" % world},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": kname, "kernel_ms": round(kms, 5), "bytes_per_warped_px": kbytes},
+            "kernel_ms": {"fwd_main": round(k_fwd, 5) if args.mode == "separate" else None,
+                          "bwd_main": round(k_bwd, 5) if k_bwd is not None else None,
+                          "fused_main": round(k_fwd, 5) if args.mode == "fused" else None},
+            "step_roofline_frac": round((BYTES_FWD + BYTES_BWD) * warped_px / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "loss5": [round(v, 6) for v in loss],
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,158 @@
+/*
+ * sfmwarp.h -- C ABI of libsfmwarp.so: the MI355X (gfx950) implementation of SfM-Learner's
+ * photometric view-synthesis loss path.
+ *
+ * Every entry point replaces a piece of pfnet/sfm-learner-chainer (citations are
+ * file:line into that repository).  Conventions:
+ *
+ *   - all tensors are float32, C-contiguous, NCHW, resident in device (HBM) memory and owned
+ *     by the caller; the library never allocates, frees or keeps a pointer after return;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every call is
+ *     asynchronous with respect to the host, re-entrant, and keeps no global mutable state
+ *     (the reference's module globals `filler` / `meshgrid`, models/transform.py:62,135, are
+ *     deliberately not reproduced);
+ *   - return value: 0 on success; SFM_ERR_* (<0) for a rejected argument; a positive value is
+ *     a hipError_t from the launch.  sfm_last_error() returns a thread-local message.
+ *     No exception or abort crosses the ABI.
+ */
+#ifndef SFMWARP_H_
+#define SFMWARP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFM_ABI_VERSION 1
+
+#define SFM_OK 0
+#define SFM_ERR_NULL (-1)      /* a required pointer is NULL                       */
+#define SFM_ERR_SHAPE (-2)     /* a dimension is out of the supported range        */
+#define SFM_ERR_CONFIG (-3)    /* inconsistent loss configuration                  */
+#define SFM_ERR_WORKSPACE (-4) /* workspace missing or too small                   */
+
+#define SFM_MAX_SCALES 8
+#define SFM_MAX_SRC 8
+
+int sfm_abi_version(void);
+const char *sfm_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Pose -> projection.  proj_tgt_to_src(), models/transform.py:64-91 (euler2mat :11-40,
+ * pose_vec2mat :43-59), kept on the device (the reference hops to the CPU, :76-80,89-90).
+ *   pose6 (N,6) rx,ry,rz,tx,ty,tz ; K (N,3,3)  ->  proj (N,4,4) = [[K,0],[0,1]] . [[R,t],[0,1]]
+ * Backward: g_proj (N,4,4) -> d_pose6 (N,6) (overwritten).
+ * ---------------------------------------------------------------------------------------- */
+int sfm_pose_proj_fwd(const float *pose6, const float *K, float *proj, int N, void *stream);
+int sfm_pose_proj_bwd(const float *pose6, const float *K, const float *g_proj, float *d_pose6, int N,
+                      void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * projective_inverse_warp(imgs, depthes, poses, K), models/transform.py:156-193
+ * (pixel2cam :94-109, cam2pixel :111-133 incl. the x2 rule :128-131, and the
+ * F.spatial_transformer_sampler call :189).
+ *   src (N,C,H,W) ; depth (N,H*W) -- ONE row of the reference's (N,3,H*W) broadcast
+ *   (models/base_model.py:82-84) ; pose6 (N,6) ; K (N,3,3)  ->  warped (N,C,H,W).
+ * Backward for an upstream gradient g_warped (N,C,H,W):
+ *   d_depth (N,H*W)   overwritten; already summed over the 3 broadcast rows
+ *   d_pose6 (N,6)     overwritten
+ *   d_src   (N,C,H,W) or NULL; ACCUMULATED into (zero it first) with float atomics
+ *   ws: sfm_warp_bwd_workspace_bytes(N,H,W) bytes of scratch.
+ * H, W >= 3 (below that the reference's x2 rule no longer implies zero fill).
+ * ---------------------------------------------------------------------------------------- */
+int sfm_warp_fwd(const float *src, const float *depth, const float *pose6, const float *K, float *warped,
+                 int N, int C, int H, int W, void *stream);
+size_t sfm_warp_bwd_workspace_bytes(int N, int H, int W);
+int sfm_warp_bwd(const float *src, const float *depth, const float *pose6, const float *K,
+                 const float *g_warped, float *d_depth, float *d_pose6, float *d_src, void *ws,
+                 size_t ws_bytes, int N, int C, int H, int W, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * F.spatial_transformer_sampler(x, grid) as called at models/transform.py:189 (Chainer
+ * built-in): normalized grid (N,2,oH,oW) with [:,0]=x, [:,1]=y in [-1,1]; bilinear; the image
+ * is zero-padded by one pixel and coordinates are clipped to the padded image.
+ *   fwd: x (N,C,H,W), grid -> y (N,C,oH,oW)
+ *   bwd: gy -> ggrid (N,2,oH,oW) overwritten ; gx (N,C,H,W) or NULL, ACCUMULATED (atomics)
+ * ---------------------------------------------------------------------------------------- */
+int sfm_sampler_fwd(const float *x, const float *grid, float *y, int N, int C, int H, int W, int oH, int oW,
+                    void *stream);
+int sfm_sampler_bwd(const float *x, const float *grid, const float *gy, float *ggrid, float *gx, int N,
+                    int C, int H, int W, int oH, int oW, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SpatialTransformerSamplerInterp, models/spational_transformer_sampler_interp.py:9-159:
+ * grid in PIXEL coordinates; weights formed after clipping the taps (:46-55), so the result is
+ * exactly 0 outside [0,W-1) x [0,H-1); backward returns ggrid (:129-147) and gx == 0 (:148).
+ *   fwd: _forward :32-78 ; bwd: _backward :86-149 (gx, if not NULL, is zero-filled).
+ * ---------------------------------------------------------------------------------------- */
+int sfm_sampler_interp_fwd(const float *x, const float *grid, float *y, int N, int C, int H, int W, int oH,
+                           int oW, void *stream);
+int sfm_sampler_interp_bwd(const float *x, const float *grid, const float *gy, float *ggrid, float *gx,
+                           int N, int C, int H, int W, int oH, int oW, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The fused multi-scale loss: the loop of SFMLearner.__call__, models/base_model.py:69-124,
+ * from the image pyramid onwards -- depth = 1/disp (:60), projective_inverse_warp (:90-94),
+ * L1 + zero mask (:95-100,:111), SSIM (:112-115, compute_ssim :126-142), smoothness
+ * (:75-77 compute_smooth_loss :169-185, or the edge-aware compute_disp_smooth :144-155 that
+ * the reference leaves commented out at :78-80), explainability (:103-109, :157-167) and the
+ * assembly of the five reported scalars (:117-123).
+ * ---------------------------------------------------------------------------------------- */
+#define SFM_SMOOTH_NONE 0
+#define SFM_SMOOTH_SECOND_ORDER 1 /* base_model.py:169-185 (the live one) */
+#define SFM_SMOOTH_EDGE_AWARE 2   /* base_model.py:144-155                */
+
+typedef struct SfmLossDesc {
+  int32_t B;        /* samples held by this call (a batch shard)                              */
+  int32_t norm_B;   /* batch size used in every mean: the GLOBAL batch when sharded, else B   */
+  int32_t n_src;    /* seq_len - 1 (base_model.py:34)                                         */
+  int32_t n_scales; /* len(pred_disps) (:66)                                                  */
+  int32_t H[SFM_MAX_SCALES];
+  int32_t W[SFM_MAX_SCALES];
+  float smooth_reg;    /* config['smooth_reg'] (:37); 0 disables (:75)                        */
+  float exp_reg;       /* config['exp_reg'] (:38); 0 disables (:86,:103)                      */
+  float ssim_rate;     /* config.get('ssim_rate', 0) (:39)                                    */
+  int32_t smooth_mode; /* SFM_SMOOTH_*                                                        */
+  /* inputs */
+  const float *tgt[SFM_MAX_SCALES];         /* (B,3,h,w)        curr_tgt_img  (:71)           */
+  const float *src[SFM_MAX_SCALES];         /* (B,3*n_src,h,w)  curr_src_imgs (:72)           */
+  const float *disp[SFM_MAX_SCALES];        /* (B,1,h,w)        pred_disps    (:59)           */
+  const float *mask_logits[SFM_MAX_SCALES]; /* (B,n_src,h,w)    pred_maskes (:62) or NULL     */
+  const float *intrinsics;                  /* (B,n_scales,3,3) (:85)                         */
+  const float *pose[SFM_MAX_SRC];           /* (B,6)            pred_poses[i] (:62)           */
+  /* gradient outputs (backward only) */
+  float *d_disp[SFM_MAX_SCALES]; /* (B,1,h,w)     overwritten                                 */
+  float *d_pose[SFM_MAX_SRC];    /* (B,6)         overwritten                                 */
+  float *d_mask[SFM_MAX_SCALES]; /* (B,n_src,h,w) overwritten; required iff exp_reg != 0      */
+  float *d_src[SFM_MAX_SCALES];  /* (B,3*n_src,h,w) or NULL; ACCUMULATED (atomics)            */
+} SfmLossDesc;
+
+/* scratch needed by the three calls below for this descriptor (0 on a bad descriptor) */
+size_t sfm_loss_workspace_bytes(const SfmLossDesc *desc);
+
+/* loss5 (device, 5 floats): total, pixel, smooth, exp, ssim -- the chainer.report keys
+ * (:119-123) in that order.  With norm_B > B the values are this shard's additive share. */
+int sfm_loss_fwd(const SfmLossDesc *desc, float *loss5, void *ws, size_t ws_bytes, void *stream);
+/* gradients of total_loss scaled by the upstream gradient gy (loss.backward() => gy = 1) */
+int sfm_loss_bwd(const SfmLossDesc *desc, float gy, void *ws, size_t ws_bytes, void *stream);
+/* forward and backward in one launch: loss5 and the gradients for gy = 1 */
+int sfm_loss_fwd_bwd(const SfmLossDesc *desc, float *loss5, void *ws, size_t ws_bytes, void *stream);
+
+/* Measurement hook (the reference times the same loop with CUDA events, models/utils.py:16-30,
+ * models/base_model.py:67): the NEXT sfm_loss_* call of the calling thread records the two
+ * hipEvent_t handles on its stream immediately before and after its main kernel, then forgets
+ * them.  NULL disables. */
+int sfm_loss_profile_events(void *ev_start, void *ev_stop);
+
+/* ------------------------------------------------------------------------------------------
+ * F.resize_images(x, (oH,oW)) as used for the pyramid, models/base_model.py:70-72:
+ * bilinear, align-corners.  x (N,C,H,W) -> y (N,C,oH,oW).
+ * ---------------------------------------------------------------------------------------- */
+int sfm_resize_fwd(const float *x, float *y, int N, int C, int H, int W, int oH, int oW, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFMWARP_H_ */

@@ -1,0 +1,241 @@
+// Shared device helpers for libsfmwarp (gfx950 / CDNA4 only: 64-lane wavefronts, DPP wave shifts).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/sfmwarp.h"
+
+namespace sfm {
+
+// ------------------------------------------------------------------------------------------
+// error plumbing (host)
+// ------------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+int check_launch(const char* what);
+
+// ------------------------------------------------------------------------------------------
+// Geometry of one (sample, scale, source): everything the per-pixel projection needs,
+// 32 floats so that a wave fetches it with scalar loads.
+//   P    rows 0..2 of Pm = K4 . T                       (models/transform.py:86-88)
+//   Kinv batch_inv(K)                                   (models/transform.py:105)
+//   M    P[:, :3] . Kinv, so that q = D * (M . (x,y,1)) + P[:,3]  -- algebraically
+//        Pm . (D * Kinv . pix, 1) of transform.py:105-108,122
+// ------------------------------------------------------------------------------------------
+struct Geom {
+  float P[12];
+  float Kinv[9];
+  float M[9];
+  float pad[2];
+};
+static_assert(sizeof(Geom) == 128, "Geom is 32 floats");
+
+struct Rot {  // euler2mat intermediates, kept for the pose backward
+  float c[3], s[3];
+  float X[9], Y[9], Z[9], XY[9], R[9];
+};
+
+__device__ __forceinline__ void mat3_mul(const float* a, const float* b, float* o) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) o[i * 3 + j] = a[i * 3 + 0] * b[0 * 3 + j] + a[i * 3 + 1] * b[1 * 3 + j] + a[i * 3 + 2] * b[2 * 3 + j];
+}
+
+__device__ __forceinline__ void mat3_mul_tn(const float* a, const float* b, float* o) {  // a^T . b
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) o[i * 3 + j] = a[0 * 3 + i] * b[0 * 3 + j] + a[1 * 3 + i] * b[1 * 3 + j] + a[2 * 3 + i] * b[2 * 3 + j];
+}
+
+__device__ __forceinline__ void mat3_mul_nt(const float* a, const float* b, float* o) {  // a . b^T
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) o[i * 3 + j] = a[i * 3 + 0] * b[j * 3 + 0] + a[i * 3 + 1] * b[j * 3 + 1] + a[i * 3 + 2] * b[j * 3 + 2];
+}
+
+// euler2mat, models/transform.py:11-40:  R = (X . Y) . Z, angles clipped to [-pi, pi]
+__device__ __forceinline__ void euler2mat(const float* r, Rot& o) {
+  const float pi = 3.14159265358979323846f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float a = fminf(fmaxf(r[k], -pi), pi);
+    o.c[k] = cosf(a);
+    o.s[k] = sinf(a);
+  }
+  const float Z[9] = {o.c[2], -o.s[2], 0.f, o.s[2], o.c[2], 0.f, 0.f, 0.f, 1.f};
+  const float Y[9] = {o.c[1], 0.f, o.s[1], 0.f, 1.f, 0.f, -o.s[1], 0.f, o.c[1]};
+  const float X[9] = {1.f, 0.f, 0.f, 0.f, o.c[0], -o.s[0], 0.f, o.s[0], o.c[0]};
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    o.X[k] = X[k];
+    o.Y[k] = Y[k];
+    o.Z[k] = Z[k];
+  }
+  mat3_mul(o.X, o.Y, o.XY);
+  mat3_mul(o.XY, o.Z, o.R);
+}
+
+// batch_inv for one 3x3 (models/transform.py:105): adjugate / determinant
+__device__ __forceinline__ void inv3(const float* K, float* o) {
+#pragma clang fp contract(off)
+  const float a = K[0], b = K[1], c = K[2], d = K[3], e = K[4], f = K[5], g = K[6], h = K[7], i = K[8];
+  const float A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+  const float det = a * A + b * B + c * C;
+  o[0] = A / det;
+  o[1] = -(b * i - c * h) / det;
+  o[2] = (b * f - c * e) / det;
+  o[3] = B / det;
+  o[4] = (a * i - c * g) / det;
+  o[5] = -(a * f - c * d) / det;
+  o[6] = C / det;
+  o[7] = -(a * h - b * g) / det;
+  o[8] = (a * e - b * d) / det;
+}
+
+// proj_tgt_to_src (models/transform.py:64-91) for one sample; rows 0..2 of K4 . [R|t]
+__device__ __forceinline__ void make_geom(const float* pose6, const float* K, Geom& g) {
+#pragma clang fp contract(off)
+  Rot rot;
+  euler2mat(pose6, rot);
+  const float t[3] = {pose6[3], pose6[4], pose6[5]};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      g.P[i * 4 + j] = K[i * 3 + 0] * rot.R[0 * 3 + j] + K[i * 3 + 1] * rot.R[1 * 3 + j] + K[i * 3 + 2] * rot.R[2 * 3 + j];
+    g.P[i * 4 + 3] = K[i * 3 + 0] * t[0] + K[i * 3 + 1] * t[1] + K[i * 3 + 2] * t[2];
+  }
+  inv3(K, g.Kinv);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      g.M[i * 3 + j] = g.P[i * 4 + 0] * g.Kinv[0 * 3 + j] + g.P[i * 4 + 1] * g.Kinv[1 * 3 + j] + g.P[i * 4 + 2] * g.Kinv[2 * 3 + j];
+  g.pad[0] = g.pad[1] = 0.f;
+}
+
+// Backward of proj_tgt_to_src for one sample.
+//   gT3 = (K^T . gPm[0:3, :]) accumulated by the caller over scales: 3x4, row-major
+__device__ __forceinline__ void pose_backward(const float* pose6, const float* gT3, float* d_pose6) {
+  const float pi = 3.14159265358979323846f;
+  Rot rot;
+  euler2mat(pose6, rot);
+  float gR[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) gR[i * 3 + j] = gT3[i * 4 + j];
+  float gXY[9], gZ[9], gX[9], gY[9];
+  mat3_mul_nt(gR, rot.Z, gXY);    // gXY = gR . Z^T
+  mat3_mul_tn(rot.XY, gR, gZ);    // gZ  = XY^T . gR
+  mat3_mul_nt(gXY, rot.Y, gX);    // gX  = gXY . Y^T
+  mat3_mul_tn(rot.X, gXY, gY);    // gY  = X^T . gXY
+  const float gcos[3] = {gX[4] + gX[8], gY[0] + gY[8], gZ[0] + gZ[4]};
+  const float gsin[3] = {gX[7] - gX[5], gY[2] - gY[6], gZ[3] - gZ[1]};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float g = -rot.s[k] * gcos[k] + rot.c[k] * gsin[k];
+    d_pose6[k] = (pose6[k] > -pi && pose6[k] < pi) ? g : 0.f;   // F.clip backward (transform.py:23)
+    d_pose6[3 + k] = gT3[k * 4 + 3];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// wave-level helpers (wave = 64 lanes)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// lane l receives the value of lane l-1; lane 0 receives 0   (DPP wave_shr:1)
+__device__ __forceinline__ float from_left(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, false));
+}
+// lane l receives the value of lane l+1; lane 63 receives 0  (DPP wave_shl:1)
+__device__ __forceinline__ float from_right(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float hsum3(float x) { return from_left(x) + x + from_right(x); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+
+__device__ __forceinline__ float signf(float t) { return (t > 0.f) ? 1.f : ((t < 0.f) ? -1.f : 0.f); }
+
+// two horizontally adjacent taps with one 8-byte load; only 4-byte alignment is guaranteed
+struct __attribute__((packed, aligned(4))) Tap2 {
+  float a, b;
+};
+__device__ __forceinline__ Tap2 load_tap2(const float* p) { return *reinterpret_cast<const Tap2*>(p); }
+
+// ------------------------------------------------------------------------------------------
+// The per-pixel projection + sampling coordinates shared by every kernel.
+//
+// Restates models/transform.py:105-108 (pixel2cam), :122-131 (cam2pixel incl. the x2 rule) and
+// the coordinate handling of F.spatial_transformer_sampler (:189).  Under the x2 rule a
+// coordinate that is not strictly inside (-1,1) is pushed at least half an image outside the
+// zero-padded picture (needs H,W >= 3), where the sampler returns exactly 0 and a zero
+// gradient; so the whole rule collapses to the `inview` predicate computed here.
+// ------------------------------------------------------------------------------------------
+struct Proj {
+  float U, V;    // q0/z, q1/z               (transform.py:124-125 numerators)
+  float rz;      // 1/z, z = q2 + 1e-10      (transform.py:123)
+  bool inview;   // -1 < xn < 1 and -1 < yn < 1   (transform.py:129)
+  int u0, v0;    // top-left tap, clamped to [0,W-2] x [0,H-2]
+  float fu, fv;  // bilinear fractions w.r.t. (u0, v0)
+};
+
+struct ScaleConst {  // per-scale constants derived from (H, W)
+  float inv_half_w, inv_half_h;  // 1 / ((W-1)/2), 1 / ((H-1)/2)
+  float wm1, hm1;                // W-1, H-1
+};
+
+__device__ __forceinline__ ScaleConst make_scale_const(int H, int W) {
+  ScaleConst s;
+  s.wm1 = (float)(W - 1);
+  s.hm1 = (float)(H - 1);
+  s.inv_half_w = 1.0f / ((float)(W - 1) * 0.5f);
+  s.inv_half_h = 1.0f / ((float)(H - 1) * 0.5f);
+  return s;
+}
+
+// aray = M . (x, y, 1) ;  q = D * aray + P[:,3]
+__device__ __forceinline__ Proj project(const float aray0, const float aray1, const float aray2, const float p03,
+                                        const float p13, const float p23, const float D, const ScaleConst& sc,
+                                        const int H, const int W) {
+#pragma clang fp contract(off)
+  Proj o;
+  const float q0 = fmaf(D, aray0, p03);
+  const float q1 = fmaf(D, aray1, p13);
+  const float q2 = fmaf(D, aray2, p23);
+  const float z = q2 + 1e-10f;
+  o.rz = rcp(z);
+  o.U = q0 * o.rz;
+  o.V = q1 * o.rz;
+  const float xn = fmaf(o.U, sc.inv_half_w, -1.0f);
+  const float yn = fmaf(o.V, sc.inv_half_h, -1.0f);
+  o.inview = (xn > -1.0f) && (xn < 1.0f) && (yn > -1.0f) && (yn < 1.0f);
+  // sampler: u_pad = (xn + 1) * (W - 1) / 2 + 1 on the zero-padded image
+  const float up = (xn + 1.0f) * sc.wm1 * 0.5f + 1.0f;
+  const float vp = (yn + 1.0f) * sc.hm1 * 0.5f + 1.0f;
+  // in view => up in [1, W], vp in [1, H]; clamp also makes the address safe when not in view / NaN
+  int u0 = (int)floorf(up) - 1;
+  int v0 = (int)floorf(vp) - 1;
+  u0 = o.inview ? min(max(u0, 0), W - 2) : 0;
+  v0 = o.inview ? min(max(v0, 0), H - 2) : 0;
+  o.u0 = u0;
+  o.v0 = v0;
+  o.fu = (up - 1.0f) - (float)u0;
+  o.fv = (vp - 1.0f) - (float)v0;
+  return o;
+}
+
+}  // namespace sfm

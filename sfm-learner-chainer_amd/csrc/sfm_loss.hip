@@ -1,0 +1,802 @@
+// Fused multi-scale view-synthesis loss (forward, backward, forward+backward) for gfx950.
+//
+// Restates the loop of SFMLearner.__call__, models/base_model.py:69-124 (citations into
+// pfnet/sfm-learner-chainer), per (sample b, scale s, source i, pixel):
+//   depth = 1/disp (:60) -> projective_inverse_warp (:90-94, models/transform.py:156-193)
+//   -> |I^ - I| with the all-channels-zero mask (:95-100,:111) -> SSIM (:112-115,:126-142)
+//   -> smoothness of the disparity (:75-77,:169-185 or :144-155) -> explainability (:103-109)
+// and the hand-derived backward to disp, pose, mask logits and (optionally) the source image.
+//
+// Execution model ("wave strip"): one 64-lane wavefront owns a strip of one image at one scale:
+// 64 consecutive columns (the outer HL/HR lanes are halo) and `chunk_rows` rows (+ halo rows).
+// It walks down its rows keeping the last rows in registers, so that
+//   * horizontal neighbours come from DPP wave shifts (no LDS, no barrier),
+//   * vertical neighbours come from a register ring,
+//   * the 3x3 SSIM pools and their transposes are separable sums over those two,
+//   * depth gradients of all sources are summed in a wave-private LDS tile and d_disp is
+//     written exactly once, coalesced; the 12 sums of dL/dPm are reduced in-wavefront.
+// All scales, sources and samples of a step are covered by ONE launch; a second tiny launch
+// reduces the per-wave partials in a fixed order (bitwise reproducible) and finishes d_pose.
+#include <stdlib.h>
+#include <string.h>
+
+#include "sfm_common.h"
+
+namespace sfm {
+
+constexpr int MAX_CHUNK_ROWS = 16;
+
+struct ScaleArgs {
+  const float* tgt;
+  const float* src;
+  const float* disp;
+  const float* mlog;
+  float* d_disp;
+  float* d_mask;
+  float* d_src;
+  int h, w, strips, chunks, tiles, item_begin;
+  float inv_cnt;               // 1 / (norm_B * 3 * h * w)                 base_model.py:111,115
+  float c_dx2, c_dy2, c_dxy;   // smooth_reg / 2^s / element count         base_model.py:76,184-185
+  float c_ex, c_ey;            // the same for the edge-aware form         base_model.py:154-155
+  float c_exp;                 // exp_reg / (norm_B * h * w)               base_model.py:105,167
+};
+
+struct LossArgs {
+  ScaleArgs sc[SFM_MAX_SCALES];
+  const float* pose[SFM_MAX_SRC];
+  float* d_pose[SFM_MAX_SRC];
+  const float* intrinsics;
+  Geom* geom;        // [B][n_scales][n_src]
+  float* part_loss;  // [items][4]   pixel, ssim, smooth, exp
+  float* part_gpm;   // [items][n_src][12]
+  int B, n_src, n_scales, items, chunk_rows;
+  float gy;          // upstream gradient on total_loss
+  float alpha;       // ssim_rate
+};
+
+template <bool SSIM, bool GRAD, int SMODE>
+struct Halo {
+  static constexpr int HS = SSIM ? (GRAD ? 2 : 1) : 0;              // reach of the photometric pass
+  static constexpr int HM = SMODE == 1 ? 2 : (SMODE == 2 ? 1 : 0);  // reach of the smoothness stencil
+  static constexpr int HR = HS > HM ? HS : HM;                      // right halo lanes
+  static constexpr int HL = GRAD ? HR : HS;                         // left halo lanes (forward smoothness terms look right/down only)
+  static constexpr int SW = 64 - HL - HR;                           // output columns per strip
+};
+
+static int strip_width(bool ssim, bool grad, int smode) {
+  const int hs = ssim ? (grad ? 2 : 1) : 0;
+  const int hm = smode == 1 ? 2 : (smode == 2 ? 1 : 0);
+  const int hr = hs > hm ? hs : hm;
+  const int hl = grad ? hr : hs;
+  return 64 - hl - hr;
+}
+
+// ------------------------------------------------------------------------------------------
+// geometry table
+// ------------------------------------------------------------------------------------------
+__global__ void geom_kernel(const LossArgs A) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = A.B * A.n_scales * A.n_src;
+  if (t >= total) return;
+  const int i = t % A.n_src;
+  const int bs = t / A.n_src;  // b * n_scales + s
+  const int b = bs / A.n_scales;
+  Geom g;
+  make_geom(A.pose[i] + b * 6, A.intrinsics + (size_t)bs * 9, g);
+  A.geom[t] = g;
+}
+
+// ------------------------------------------------------------------------------------------
+// smoothness passes (one per wave, before the sources)
+// ------------------------------------------------------------------------------------------
+// second-order, models/base_model.py:169-185
+template <bool GRAD, bool LOSS>
+__device__ __forceinline__ void smooth2_pass(const LossArgs& A, const ScaleArgs& S, const float* __restrict__ dplane, int lane,
+                                             int x, bool xin, bool outl, int y0, int y1, float* gacc, float& acc_sm) {
+  const int h = S.h, w = S.w;
+  float dm2 = 0.f, dm1 = 0.f, d0 = 0.f, dp1 = 0.f, dp2 = 0.f;
+  const bool vx2 = xin && (x <= w - 3);
+  const bool vx1 = xin && (x <= w - 2);
+  for (int r = y0 - 2; r < y1 + 2; ++r) {
+    dm2 = dm1; dm1 = d0; d0 = dp1; dp1 = dp2;
+    dp2 = 0.f;
+    if (r >= 0 && r < h && xin) dp2 = dplane[r * w + x];
+    const int q = r - 2;
+    if (q < y0) continue;
+    const float dxr0 = from_right(d0) - d0;        // dx(q,x)
+    const float dx2 = from_right(dxr0) - dxr0;     // dx2(q,x)
+    const float dy0 = dp1 - d0, dy1 = dp2 - dp1;   // dy(q,x), dy(q+1,x)
+    const float dy2 = dy1 - dy0;                   // dy2(q,x)
+    const float dxrp = from_right(dp1) - dp1;      // dx(q+1,x)
+    const float dxdy0 = dxrp - dxr0;               // dxdy(q,x) = dx(q+1,x) - dx(q,x)
+    const float dydx0 = from_right(dy0) - dy0;     // dydx(q,x) = dy(q,x+1) - dy(q,x)
+    const bool vq2 = q <= h - 3, vq1 = q <= h - 2;
+    if (LOSS) {
+      float t = 0.f;
+      if (vx2) t += S.c_dx2 * fabsf(dx2);
+      if (vq2) t += S.c_dy2 * fabsf(dy2);
+      if (vx1 && vq1) t += S.c_dxy * (fabsf(dxdy0) + fabsf(dydx0));
+      if (outl) acc_sm += t;
+    }
+    if (GRAD) {
+      const float s2x = vx2 ? signf(dx2) : 0.f;
+      const float s2x1 = from_left(s2x);
+      const float gx2 = from_left(s2x1) - 2.f * s2x1 + s2x;
+      const float dym2 = dm1 - dm2, dym1 = d0 - dm1;   // dy(q-2,x), dy(q-1,x)
+      const float s2ym2 = (q - 2 >= 0) ? signf(dym1 - dym2) : 0.f;
+      const float s2ym1 = (q - 1 >= 0 && vq1) ? signf(dy0 - dym1) : 0.f;
+      const float s2y0 = vq2 ? signf(dy2) : 0.f;
+      const float gy2 = s2ym2 - 2.f * s2ym1 + s2y0;
+      const float dxrm = from_right(dm1) - dm1;        // dx(q-1,x)
+      const float dxdym1 = dxr0 - dxrm;                // dxdy(q-1,x)
+      const float dydxm1 = from_right(dym1) - dym1;    // dydx(q-1,x)
+      const float t1 = (vx1 && q - 1 >= 0) ? signf(dxdym1) + signf(dydxm1) : 0.f;
+      const float t0 = (vx1 && vq1) ? signf(dxdy0) + signf(dydx0) : 0.f;
+      const float gxy = from_left(t1) - t1 - from_left(t0) + t0;
+      gacc[(q - y0) * 64 + lane] = A.gy * (S.c_dx2 * gx2 + S.c_dy2 * gy2 + S.c_dxy * gxy);
+    }
+  }
+}
+
+// edge-aware first-order, models/base_model.py:144-155 (commented out at :78-80 in the reference)
+template <bool GRAD, bool LOSS>
+__device__ __forceinline__ void smooth_edge_pass(const LossArgs& A, const ScaleArgs& S, const float* __restrict__ dplane,
+                                                 const float* __restrict__ tplane, int lane, int x, bool xin, bool outl, int y0,
+                                                 int y1, float* gacc, float& acc_sm) {
+  const int h = S.h, w = S.w;
+  const size_t P = (size_t)h * w;
+  float dm1 = 0.f, d0 = 0.f, dp1 = 0.f;
+  float im1[3] = {0.f, 0.f, 0.f}, i0[3] = {0.f, 0.f, 0.f}, ip1[3] = {0.f, 0.f, 0.f};
+  const bool vx1 = xin && (x <= w - 2);
+  const float third = 1.0f / 3.0f;
+  for (int r = y0 - 1; r < y1 + 1; ++r) {
+    dm1 = d0; d0 = dp1; dp1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { im1[c] = i0[c]; i0[c] = ip1[c]; ip1[c] = 0.f; }
+    if (r >= 0 && r < h && xin) {
+      dp1 = dplane[r * w + x];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) ip1[c] = tplane[c * P + r * w + x];
+    }
+    const int q = r - 1;
+    if (q < y0) continue;
+    // x term anchored at (q,x)
+    float mx = 0.f, my0 = 0.f, mym1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      mx += from_right(i0[c]) - i0[c];
+      my0 += ip1[c] - i0[c];
+      mym1 += i0[c] - im1[c];
+    }
+    const float wx = vx1 ? __expf(-fabsf(mx * third)) : 0.f;
+    const float wy0 = (xin && q <= h - 2) ? __expf(-fabsf(my0 * third)) : 0.f;
+    const float wym1 = (xin && q - 1 >= 0) ? __expf(-fabsf(mym1 * third)) : 0.f;
+    const float ddx = from_right(d0) - d0;   // d_dx(q,x)
+    const float ddy0 = dp1 - d0;             // d_dy(q,x)
+    const float ddym1 = d0 - dm1;            // d_dy(q-1,x)
+    if (LOSS) {
+      if (outl) acc_sm += S.c_ex * fabsf(ddx) * wx + S.c_ey * fabsf(ddy0) * wy0;
+    }
+    if (GRAD) {
+      const float tx = signf(ddx) * wx;
+      const float gx = from_left(tx) - tx;
+      const float gyv = signf(ddym1) * wym1 - signf(ddy0) * wy0;
+      gacc[(q - y0) * 64 + lane] = A.gy * (S.c_ex * gx + S.c_ey * gyv);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// photometric pass for one source
+// ------------------------------------------------------------------------------------------
+struct RowA {        // what stage A leaves behind for a row (per lane = per pixel)
+  float ih[3];       // warped source I^
+  float it[3];       // target I
+  float du[3], dv[3];// dI^/du, dI^/dv
+  float U, V, rz, D; // projection (for the geometry backward)
+  float inv;         // 1 if the pixel is in view, else 0
+  float sg;          // sigmoid(explainability logit)   (EXPL only)
+};
+
+__device__ __forceinline__ void zero_row(RowA& r) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) r.ih[c] = r.it[c] = r.du[c] = r.dv[c] = 0.f;
+  r.U = r.V = r.rz = r.D = r.inv = r.sg = 0.f;
+}
+
+struct SrcConst {    // per (wave, source): uniform geometry in SGPRs + per-lane hoisted x terms
+  float M1[3], P3[3], K1[3];   // uniform: M[k][1], P[k][3], Kinv[j][1]
+  float mx[3], kx[3];          // per lane: M[k][0]*x + M[k][2],  Kinv[j][0]*x + Kinv[j][2]
+};
+
+template <bool SSIM, bool GRAD, bool LOSS, bool EXPL>
+__device__ __forceinline__ void source_pass(const LossArgs& A, const ScaleArgs& S, const ScaleConst& sc, const int b, const int i,
+                                            const int s, const int lane, const int x, const bool xin, const bool outl,
+                                            const int y0, const int y1, float* gacc, const bool first, float& acc_pix,
+                                            float& acc_ssim, float& acc_exp, const int item) {
+  constexpr int HS = SSIM ? (GRAD ? 2 : 1) : 0;
+  const int h = S.h, w = S.w;
+  const size_t P = (size_t)h * w;
+  const float xf = (float)x;
+
+  // --- geometry of (b, s, i): uniform -> SGPRs
+  const Geom* __restrict__ gp = A.geom + ((size_t)(b * A.n_scales + s) * A.n_src + i);
+  SrcConst G;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float m0 = uniform(gp->M[k * 3 + 0]), m2 = uniform(gp->M[k * 3 + 2]);
+    G.M1[k] = uniform(gp->M[k * 3 + 1]);
+    G.P3[k] = uniform(gp->P[k * 4 + 3]);
+    G.mx[k] = fmaf(m0, xf, m2);
+    if (GRAD) {
+      const float k0 = uniform(gp->Kinv[k * 3 + 0]), k2 = uniform(gp->Kinv[k * 3 + 2]);
+      G.K1[k] = uniform(gp->Kinv[k * 3 + 1]);
+      G.kx[k] = fmaf(k0, xf, k2);
+    }
+  }
+  const float* __restrict__ tplane = S.tgt + (size_t)b * 3 * P;
+  const float* __restrict__ splane = S.src + ((size_t)b * A.n_src + i) * 3 * P;
+  const float* __restrict__ dplane = S.disp + (size_t)b * P;
+  const float* __restrict__ mplane = EXPL ? S.mlog + ((size_t)b * A.n_src + i) * P : nullptr;
+  float* __restrict__ dmplane = (EXPL && GRAD) ? S.d_mask + ((size_t)b * A.n_src + i) * P : nullptr;
+  float* __restrict__ dsplane = (GRAD && S.d_src) ? S.d_src + ((size_t)b * A.n_src + i) * 3 * P : nullptr;
+
+  const float one_m_alpha = 1.0f - A.alpha;
+  const float k_pix = A.gy * one_m_alpha * S.inv_cnt;   // dL/d(sum |e|)      base_model.py:111,117
+  const float k_ssim = A.gy * A.alpha * S.inv_cnt;      // dL/d(sum ssim_err) base_model.py:115,117
+  const float c1 = 0.0001f, c2 = 0.0009f;               // base_model.py:127-128
+  const float ninth = 1.0f / 9.0f;
+
+  float gpm[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) gpm[k] = 0.f;
+
+  // rings
+  RowA p1, p2;  // rows r-1, r-2
+  zero_row(p1);
+  zero_row(p2);
+  float hx1[3] = {0, 0, 0}, hx2[3] = {0, 0, 0}, hxx1[3] = {0, 0, 0}, hxx2[3] = {0, 0, 0}, hxy1[3] = {0, 0, 0}, hxy2[3] = {0, 0, 0};
+  float hy1[3] = {0, 0, 0}, hy2[3] = {0, 0, 0}, hyy1[3] = {0, 0, 0}, hyy2[3] = {0, 0, 0};
+  float ga1[3] = {0, 0, 0}, ga2[3] = {0, 0, 0}, gb1[3] = {0, 0, 0}, gb2[3] = {0, 0, 0}, ge1[3] = {0, 0, 0}, ge2[3] = {0, 0, 0};
+
+  for (int r = y0 - HS; r < y1 + HS; ++r) {
+    // ------------------------------ stage A: warp row r ------------------------------
+    RowA cur;
+    zero_row(cur);
+    const bool rin = (r >= 0) && (r < h);
+    if (rin && xin) {
+      const int off = r * w + x;
+      const float yf = (float)r;
+      const float disp = dplane[off];
+      cur.D = rcp(disp);                                             // base_model.py:60
+#pragma unroll
+      for (int c = 0; c < 3; ++c) cur.it[c] = tplane[c * P + off];
+      if (EXPL) {
+        const float lg = mplane[off];
+        cur.sg = rcp(1.0f + __expf(-lg));                            // F.sigmoid, base_model.py:107
+        if (LOSS && outl && r >= y0 && r < y1) {
+          // softplus(-x) = max(-x,0) + log(1 + exp(-|x|))            base_model.py:165-167
+          acc_exp += fmaxf(-lg, 0.f) + __logf(1.0f + __expf(-fabsf(lg)));
+        }
+      }
+      const float a0 = fmaf(G.M1[0], yf, G.mx[0]), a1 = fmaf(G.M1[1], yf, G.mx[1]), a2 = fmaf(G.M1[2], yf, G.mx[2]);
+      const Proj p = project(a0, a1, a2, G.P3[0], G.P3[1], G.P3[2], cur.D, sc, h, w);
+      cur.U = p.U; cur.V = p.V; cur.rz = p.rz;
+      if (p.inview) {
+        cur.inv = 1.f;
+        const float* sp = splane + p.v0 * w + p.u0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const Tap2 t = load_tap2(sp + c * P);
+          const Tap2 bt = load_tap2(sp + c * P + w);
+          const float dxt = t.b - t.a, dxb = bt.b - bt.a;
+          const float top = fmaf(p.fu, dxt, t.a);
+          const float bot = fmaf(p.fu, dxb, bt.a);
+          const float dvv = bot - top;
+          cur.ih[c] = fmaf(p.fv, dvv, top);
+          cur.dv[c] = dvv;
+          cur.du[c] = fmaf(p.fv, dxb - dxt, dxt);
+        }
+      }
+    }
+
+    if (SSIM) {
+      // horizontal 3-sums of row r
+      float hx0[3], hxx0[3], hxy0[3], hy0[3], hyy0[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        hx0[c] = hsum3(cur.ih[c]);
+        hxx0[c] = hsum3(cur.ih[c] * cur.ih[c]);
+        hxy0[c] = hsum3(cur.ih[c] * cur.it[c]);
+        hy0[c] = hsum3(cur.it[c]);
+        hyy0[c] = hsum3(cur.it[c] * cur.it[c]);
+      }
+      // ------------------------------ stage B: SSIM at row r-1 ------------------------------
+      const int rb = r - 1;
+      const bool rb_in = (rb >= 0) && (rb < h);
+      const float m1 = (p1.ih[0] == 0.f && p1.ih[1] == 0.f && p1.ih[2] == 0.f) ? 1.f : 0.f;   // base_model.py:96
+      float ga0[3], gb0[3], ge0[3];
+      float ssum = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float mux = (hx2[c] + hx1[c] + hx0[c]) * ninth;        // :130
+        const float muy = (hy2[c] + hy1[c] + hy0[c]) * ninth;        // :131
+        const float exx = (hxx2[c] + hxx1[c] + hxx0[c]) * ninth;
+        const float eyy = (hyy2[c] + hyy1[c] + hyy0[c]) * ninth;
+        const float exy = (hxy2[c] + hxy1[c] + hxy0[c]) * ninth;
+        const float sx = exx - mux * mux;                            // :133
+        const float sy = eyy - muy * muy;                            // :134
+        const float sxy = exy - mux * muy;                           // :135
+        const float n1 = 2.f * mux * muy + c1, n2 = 2.f * sxy + c2;  // :137
+        const float d1 = mux * mux + muy * muy + c1, d2 = sx + sy + c2;   // :138
+        const float rd = rcp(d1 * d2);
+        const float Sv = n1 * n2 * rd;                               // :140
+        const float e = (1.f - Sv) * 0.5f;                           // :142
+        ssum += fminf(fmaxf(e, 0.f), 1.f);
+        if (GRAD) {
+          float kap = (e > 0.f && e < 1.f) ? -0.5f * k_ssim * (1.f - m1) : 0.f;
+          if (!(rb_in && xin)) kap = 0.f;
+          const float rd2 = rcp(d2);
+          const float dS_dmux = (2.f * muy * (n2 - n1) - Sv * 2.f * mux * (d2 - d1)) * rd;
+          ga0[c] = hsum3(kap * dS_dmux);
+          gb0[c] = hsum3(kap * (-Sv * rd2));
+          ge0[c] = hsum3(kap * (2.f * n1 * rd));
+        }
+      }
+      if (LOSS) {
+        if (outl && rb >= y0 && rb < y1) {
+          acc_ssim += ssum * (1.f - m1);                             // :114-115
+          float e1 = 0.f;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) e1 += fabsf(p1.ih[c] - p1.it[c]);   // :95
+          acc_pix += e1 * (1.f - m1);                                // :98-100,:111
+        }
+      }
+      if (GRAD) {
+        // ------------------------------ stage C: gradients at row r-2 ------------------------------
+        const int rc = r - 2;
+        if (rc >= y0 && rc < y1) {
+          const float m2 = (p2.ih[0] == 0.f && p2.ih[1] == 0.f && p2.ih[2] == 0.f) ? 1.f : 0.f;
+          float gU = 0.f, gV = 0.f;
+          float gI[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float Aq = (ga2[c] + ga1[c] + ga0[c]) * ninth;
+            const float Bq = (gb2[c] + gb1[c] + gb0[c]) * ninth;
+            const float Eq = (ge2[c] + ge1[c] + ge0[c]) * ninth;
+            float g = Aq + 2.f * p2.ih[c] * Bq + p2.it[c] * Eq;
+            g += k_pix * (1.f - m2) * signf(p2.ih[c] - p2.it[c]);
+            gI[c] = g;
+            gU = fmaf(g, p2.du[c], gU);
+            gV = fmaf(g, p2.dv[c], gV);
+          }
+          gU *= p2.inv;
+          gV *= p2.inv;
+          const float yf = (float)rc;
+          const float gq0 = gU * p2.rz, gq1 = gV * p2.rz;
+          const float gq2 = -(gU * p2.U + gV * p2.V) * p2.rz;
+          const float a0 = fmaf(G.M1[0], yf, G.mx[0]), a1 = fmaf(G.M1[1], yf, G.mx[1]), a2 = fmaf(G.M1[2], yf, G.mx[2]);
+          const float gD = gq0 * a0 + gq1 * a1 + gq2 * a2;
+          const float gdisp = outl ? -gD * p2.D * p2.D : 0.f;       // d(1/d) = -1/d^2
+          float* ga = gacc + (rc - y0) * 64 + lane;
+          *ga = first ? gdisp : (*ga + gdisp);
+          if (outl) {
+            const float cc0 = p2.D * fmaf(G.K1[0], yf, G.kx[0]);
+            const float cc1 = p2.D * fmaf(G.K1[1], yf, G.kx[1]);
+            const float cc2 = p2.D * fmaf(G.K1[2], yf, G.kx[2]);
+            gpm[0] = fmaf(gq0, cc0, gpm[0]); gpm[1] = fmaf(gq0, cc1, gpm[1]); gpm[2] = fmaf(gq0, cc2, gpm[2]); gpm[3] += gq0;
+            gpm[4] = fmaf(gq1, cc0, gpm[4]); gpm[5] = fmaf(gq1, cc1, gpm[5]); gpm[6] = fmaf(gq1, cc2, gpm[6]); gpm[7] += gq1;
+            gpm[8] = fmaf(gq2, cc0, gpm[8]); gpm[9] = fmaf(gq2, cc1, gpm[9]); gpm[10] = fmaf(gq2, cc2, gpm[10]); gpm[11] += gq2;
+            if (dsplane && p2.inv != 0.f) {
+              const Proj p = project(a0, a1, a2, G.P3[0], G.P3[1], G.P3[2], p2.D, sc, h, w);
+              float* ds = dsplane + p.v0 * w + p.u0;
+              const float w00 = (1.f - p.fu) * (1.f - p.fv), w01 = p.fu * (1.f - p.fv), w10 = (1.f - p.fu) * p.fv, w11 = p.fu * p.fv;
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                atomicAdd(ds + c * P, gI[c] * w00);
+                atomicAdd(ds + c * P + 1, gI[c] * w01);
+                atomicAdd(ds + c * P + w, gI[c] * w10);
+                atomicAdd(ds + c * P + w + 1, gI[c] * w11);
+              }
+            }
+          }
+        }
+      }
+      // rotate rings
+      p2 = p1;
+      p1 = cur;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        hx2[c] = hx1[c]; hx1[c] = hx0[c];
+        hxx2[c] = hxx1[c]; hxx1[c] = hxx0[c];
+        hxy2[c] = hxy1[c]; hxy1[c] = hxy0[c];
+        hy2[c] = hy1[c]; hy1[c] = hy0[c];
+        hyy2[c] = hyy1[c]; hyy1[c] = hyy0[c];
+        if (GRAD) {
+          ga2[c] = ga1[c]; ga1[c] = ga0[c];
+          gb2[c] = gb1[c]; gb1[c] = gb0[c];
+          ge2[c] = ge1[c]; ge1[c] = ge0[c];
+        }
+      }
+    } else {
+      // ------------------------------ no SSIM: everything is per pixel ------------------------------
+      const float m = (cur.ih[0] == 0.f && cur.ih[1] == 0.f && cur.ih[2] == 0.f) ? 1.f : 0.f;
+      float e1 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) e1 += fabsf(cur.ih[c] - cur.it[c]);
+      e1 *= (1.f - m);
+      const float wgt = EXPL ? cur.sg : 1.f;                         // base_model.py:107-109
+      if (LOSS && outl) acc_pix += e1 * wgt;
+      if (GRAD) {
+        float gU = 0.f, gV = 0.f;
+        float gI[3];
+        const float kk = k_pix * (1.f - m) * wgt;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float g = kk * signf(cur.ih[c] - cur.it[c]);
+          gI[c] = g;
+          gU = fmaf(g, cur.du[c], gU);
+          gV = fmaf(g, cur.dv[c], gV);
+        }
+        gU *= cur.inv;
+        gV *= cur.inv;
+        const float yf = (float)r;
+        const float gq0 = gU * cur.rz, gq1 = gV * cur.rz;
+        const float gq2 = -(gU * cur.U + gV * cur.V) * cur.rz;
+        const float a0 = fmaf(G.M1[0], yf, G.mx[0]), a1 = fmaf(G.M1[1], yf, G.mx[1]), a2 = fmaf(G.M1[2], yf, G.mx[2]);
+        const float gD = gq0 * a0 + gq1 * a1 + gq2 * a2;
+        const float gdisp = outl ? -gD * cur.D * cur.D : 0.f;
+        float* ga = gacc + (r - y0) * 64 + lane;
+        *ga = first ? gdisp : (*ga + gdisp);
+        if (outl) {
+          if (EXPL) {
+            // d/dlogit of  (1-a) * mean(err * sigmoid)  +  exp_reg * mean(softplus(-logit))
+            dmplane[r * w + x] = k_pix * e1 * cur.sg * (1.f - cur.sg) + A.gy * S.c_exp * (cur.sg - 1.f);
+          }
+          const float cc0 = cur.D * fmaf(G.K1[0], yf, G.kx[0]);
+          const float cc1 = cur.D * fmaf(G.K1[1], yf, G.kx[1]);
+          const float cc2 = cur.D * fmaf(G.K1[2], yf, G.kx[2]);
+          gpm[0] = fmaf(gq0, cc0, gpm[0]); gpm[1] = fmaf(gq0, cc1, gpm[1]); gpm[2] = fmaf(gq0, cc2, gpm[2]); gpm[3] += gq0;
+          gpm[4] = fmaf(gq1, cc0, gpm[4]); gpm[5] = fmaf(gq1, cc1, gpm[5]); gpm[6] = fmaf(gq1, cc2, gpm[6]); gpm[7] += gq1;
+          gpm[8] = fmaf(gq2, cc0, gpm[8]); gpm[9] = fmaf(gq2, cc1, gpm[9]); gpm[10] = fmaf(gq2, cc2, gpm[10]); gpm[11] += gq2;
+          if (dsplane && cur.inv != 0.f) {
+            const Proj p = project(a0, a1, a2, G.P3[0], G.P3[1], G.P3[2], cur.D, sc, h, w);
+            float* ds = dsplane + p.v0 * w + p.u0;
+            const float w00 = (1.f - p.fu) * (1.f - p.fv), w01 = p.fu * (1.f - p.fv), w10 = (1.f - p.fu) * p.fv, w11 = p.fu * p.fv;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              atomicAdd(ds + c * P, gI[c] * w00);
+              atomicAdd(ds + c * P + 1, gI[c] * w01);
+              atomicAdd(ds + c * P + w, gI[c] * w10);
+              atomicAdd(ds + c * P + w + 1, gI[c] * w11);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if (GRAD) {
+    float* out = A.part_gpm + ((size_t)item * A.n_src + i) * 12;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      const float v = wave_sum(gpm[k]);
+      if (lane == 0) out[k] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// the main kernel: one wavefront per (scale, sample, strip, chunk)
+// ------------------------------------------------------------------------------------------
+template <bool SSIM, bool GRAD, bool LOSS, bool EXPL, int SMODE>
+__global__ void __launch_bounds__(64) loss_kernel(const LossArgs A) {
+  using HH = Halo<SSIM, GRAD, SMODE>;
+  __shared__ float gacc[GRAD ? MAX_CHUNK_ROWS * 64 : 64];
+
+  const int item = blockIdx.x;
+  int s = 0;
+#pragma unroll
+  for (int k = 1; k < SFM_MAX_SCALES; ++k)
+    if (k < A.n_scales && item >= A.sc[k].item_begin) s = k;
+  const ScaleArgs& S = A.sc[s];
+  const int idx = item - S.item_begin;
+  const int b = idx / S.tiles;
+  const int t = idx - b * S.tiles;
+  const int chunk = t / S.strips;
+  const int strip = t - chunk * S.strips;
+  const int h = S.h, w = S.w;
+  const int lane = threadIdx.x;
+  const int x = strip * HH::SW - HH::HL + lane;
+  const bool xin = (x >= 0) && (x < w);
+  const bool outl = (lane >= HH::HL) && (lane < 64 - HH::HR) && (x < w);
+  const int y0 = chunk * A.chunk_rows;
+  const int y1 = min(y0 + A.chunk_rows, h);
+  const ScaleConst sc = make_scale_const(h, w);
+  const size_t P = (size_t)h * w;
+
+  float acc_pix = 0.f, acc_ssim = 0.f, acc_sm = 0.f, acc_exp = 0.f;
+  bool first = true;
+  if (SMODE == 1) {
+    smooth2_pass<GRAD, LOSS>(A, S, S.disp + (size_t)b * P, lane, x, xin, outl, y0, y1, gacc, acc_sm);
+    first = false;
+  } else if (SMODE == 2) {
+    smooth_edge_pass<GRAD, LOSS>(A, S, S.disp + (size_t)b * P, S.tgt + (size_t)b * 3 * P, lane, x, xin, outl, y0, y1, gacc, acc_sm);
+    first = false;
+  }
+  for (int i = 0; i < A.n_src; ++i) {
+    source_pass<SSIM, GRAD, LOSS, EXPL>(A, S, sc, b, i, s, lane, x, xin, outl, y0, y1, gacc, first, acc_pix, acc_ssim, acc_exp, item);
+    first = false;
+  }
+  if (GRAD) {
+    if (outl) {
+      float* o = S.d_disp + (size_t)b * P;
+      for (int q = y0; q < y1; ++q) o[q * w + x] = gacc[(q - y0) * 64 + lane];
+    }
+  }
+  if (LOSS) {
+    const float v0 = wave_sum(acc_pix) * S.inv_cnt;
+    const float v1 = wave_sum(acc_ssim) * S.inv_cnt;
+    const float v2 = wave_sum(acc_sm);
+    const float v3 = wave_sum(acc_exp) * S.c_exp;
+    if (lane == 0) {
+      float* o = A.part_loss + (size_t)item * 4;
+      o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// finalize: fixed-order reduction of the per-wave partials
+//   blocks [0, B*n_src): d_pose of (b, i)         (only when do_pose)
+//   last block        : the five reported scalars (only when loss5 != nullptr)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ void __launch_bounds__(64) finalize_kernel(const LossArgs A, float* __restrict__ loss5, const int n_pose_blocks) {
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x < n_pose_blocks) {
+    const int b = blockIdx.x / A.n_src, i = blockIdx.x - b * A.n_src;
+    float gT3[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) gT3[k] = 0.f;
+    for (int s = 0; s < A.n_scales; ++s) {
+      const ScaleArgs& S = A.sc[s];
+      const int beg = S.item_begin + b * S.tiles;
+      double acc[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) acc[k] = 0.0;
+      for (int t = lane; t < S.tiles; t += 64) {
+        const float* p = A.part_gpm + ((size_t)(beg + t) * A.n_src + i) * 12;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) acc[k] += (double)p[k];
+      }
+      float gPm[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) gPm[k] = (float)wave_sum_d(acc[k]);
+      const float* K = A.intrinsics + ((size_t)b * A.n_scales + s) * 9;
+      // gT3 += K^T . gPm   (K4^T . gPm of the rows that reach R and t)
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) gT3[r * 4 + c] += K[0 * 3 + r] * gPm[0 * 4 + c] + K[1 * 3 + r] * gPm[1 * 4 + c] + K[2 * 3 + r] * gPm[2 * 4 + c];
+    }
+    if (lane == 0) {
+      float d[6];
+      pose_backward(A.pose[i] + b * 6, gT3, d);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) A.d_pose[i][b * 6 + k] = d[k];
+    }
+    return;
+  }
+  if (loss5 == nullptr) return;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int t = lane; t < A.items; t += 64) {
+    const float* p = A.part_loss + (size_t)t * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] += (double)p[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc[k] = wave_sum_d(acc[k]);
+  if (lane == 0) {
+    const double pixel = acc[0], ssim = acc[1], smooth = acc[2], expl = acc[3];
+    const double a = (double)A.alpha;
+    loss5[0] = (float)((1.0 - a) * pixel + a * ssim + smooth + expl);   // base_model.py:117-118
+    loss5[1] = (float)pixel;
+    loss5[2] = (float)smooth;
+    loss5[3] = (float)expl;
+    loss5[4] = (float)ssim;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct Plan {
+  LossArgs args;
+  size_t off_geom, off_loss, off_gpm, total;
+  bool ssim, expl;
+  int smode;
+};
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// optional profiling hook (sfm_loss_profile_events): events recorded right before / after the
+// main kernel of the NEXT fused-loss call of this thread
+static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+
+static int chunk_rows_setting() {
+  const char* e = getenv("SFM_CHUNK_ROWS");
+  int v = e ? atoi(e) : 0;
+  if (v < 1 || v > MAX_CHUNK_ROWS) v = MAX_CHUNK_ROWS;
+  return v;
+}
+
+// validates the descriptor and lays out items + workspace for the given mode
+static int make_plan(const SfmLossDesc* d, bool grad, bool need_outputs, float gy, Plan& p) {
+  if (!d) return fail(SFM_ERR_NULL, "sfm_loss: NULL descriptor");
+  if (d->B < 0 || d->B > (1 << 20)) return fail(SFM_ERR_SHAPE, "sfm_loss: B=%d", d->B);
+  if (d->norm_B < d->B || d->norm_B < 1) return fail(SFM_ERR_CONFIG, "sfm_loss: norm_B=%d must be >= max(B,1) (B=%d)", d->norm_B, d->B);
+  if (d->n_src < 1 || d->n_src > SFM_MAX_SRC) return fail(SFM_ERR_SHAPE, "sfm_loss: n_src=%d not in [1,%d]", d->n_src, SFM_MAX_SRC);
+  if (d->n_scales < 1 || d->n_scales > SFM_MAX_SCALES)
+    return fail(SFM_ERR_SHAPE, "sfm_loss: n_scales=%d not in [1,%d]", d->n_scales, SFM_MAX_SCALES);
+  if (!(d->ssim_rate >= 0.f && d->ssim_rate <= 1.f)) return fail(SFM_ERR_CONFIG, "sfm_loss: ssim_rate=%g not in [0,1]", d->ssim_rate);
+  if (!(d->smooth_reg >= 0.f) || !(d->exp_reg >= 0.f)) return fail(SFM_ERR_CONFIG, "sfm_loss: negative regulariser weight");
+  if (d->smooth_mode < SFM_SMOOTH_NONE || d->smooth_mode > SFM_SMOOTH_EDGE_AWARE)
+    return fail(SFM_ERR_CONFIG, "sfm_loss: smooth_mode=%d", d->smooth_mode);
+  if (!d->intrinsics) return fail(SFM_ERR_NULL, "sfm_loss: intrinsics is NULL");
+  p.expl = d->exp_reg > 0.f;                       // base_model.py:86,103
+  p.ssim = !p.expl && d->ssim_rate > 0.f;          // base_model.py:110-112
+  p.smode = d->smooth_reg > 0.f ? d->smooth_mode : SFM_SMOOTH_NONE;   // base_model.py:75
+  LossArgs& A = p.args;
+  memset(&A, 0, sizeof(A));
+  A.B = d->B;
+  A.n_src = d->n_src;
+  A.n_scales = d->n_scales;
+  A.chunk_rows = chunk_rows_setting();
+  A.gy = gy;
+  A.alpha = d->ssim_rate;
+  A.intrinsics = d->intrinsics;
+  for (int i = 0; i < d->n_src; ++i) {
+    if (!d->pose[i]) return fail(SFM_ERR_NULL, "sfm_loss: pose[%d] is NULL", i);
+    A.pose[i] = d->pose[i];
+    if (grad && need_outputs) {
+      if (!d->d_pose[i]) return fail(SFM_ERR_NULL, "sfm_loss: d_pose[%d] is NULL", i);
+      A.d_pose[i] = d->d_pose[i];
+    }
+  }
+  const int sw = strip_width(p.ssim, grad, p.smode);
+  int items = 0;
+  for (int s = 0; s < d->n_scales; ++s) {
+    const int h = d->H[s], w = d->W[s];
+    if (h < 3 || w < 3) return fail(SFM_ERR_SHAPE, "sfm_loss: scale %d is %dx%d, need H,W >= 3", s, h, w);
+    if ((long long)d->B * 3 * d->n_src * h * w >= (1ll << 31)) return fail(SFM_ERR_SHAPE, "sfm_loss: scale %d too large", s);
+    if (!d->tgt[s] || !d->src[s] || !d->disp[s]) return fail(SFM_ERR_NULL, "sfm_loss: tgt/src/disp[%d] is NULL", s);
+    if (p.expl && !d->mask_logits[s]) return fail(SFM_ERR_NULL, "sfm_loss: exp_reg > 0 but mask_logits[%d] is NULL", s);
+    ScaleArgs& S = A.sc[s];
+    S.tgt = d->tgt[s];
+    S.src = d->src[s];
+    S.disp = d->disp[s];
+    S.mlog = p.expl ? d->mask_logits[s] : nullptr;
+    if (grad && need_outputs) {
+      if (!d->d_disp[s]) return fail(SFM_ERR_NULL, "sfm_loss: d_disp[%d] is NULL", s);
+      if (p.expl && !d->d_mask[s]) return fail(SFM_ERR_NULL, "sfm_loss: exp_reg > 0 but d_mask[%d] is NULL", s);
+      S.d_disp = d->d_disp[s];
+      S.d_mask = p.expl ? d->d_mask[s] : nullptr;
+      S.d_src = d->d_src[s];
+    }
+    S.h = h;
+    S.w = w;
+    S.strips = (w + sw - 1) / sw;
+    S.chunks = (h + A.chunk_rows - 1) / A.chunk_rows;
+    S.tiles = S.strips * S.chunks;
+    S.item_begin = items;
+    items += d->B * S.tiles;
+    const double nb = (double)d->norm_B;
+    S.inv_cnt = (float)(1.0 / (nb * 3.0 * h * w));
+    const double wgt = (double)d->smooth_reg / (double)(1 << s);               // base_model.py:76
+    S.c_dx2 = (float)(wgt / (nb * h * (w - 2)));
+    S.c_dy2 = (float)(wgt / (nb * (h - 2) * w));
+    S.c_dxy = (float)(wgt / (nb * (h - 1) * (w - 1)));
+    S.c_ex = (float)(wgt / (nb * h * (w - 1)));
+    S.c_ey = (float)(wgt / (nb * (h - 1) * w));
+    S.c_exp = (float)((double)d->exp_reg / (nb * h * w));
+  }
+  A.items = items;
+  p.off_geom = 0;
+  p.off_loss = align_up(p.off_geom + (size_t)d->B * d->n_scales * d->n_src * sizeof(Geom), 256);
+  p.off_gpm = align_up(p.off_loss + (size_t)items * 4 * sizeof(float), 256);
+  p.total = align_up(p.off_gpm + (size_t)items * d->n_src * 12 * sizeof(float), 256);
+  return SFM_OK;
+}
+
+static void bind_workspace(Plan& p, void* ws) {
+  char* base = (char*)ws;
+  p.args.geom = (Geom*)(base + p.off_geom);
+  p.args.part_loss = (float*)(base + p.off_loss);
+  p.args.part_gpm = (float*)(base + p.off_gpm);
+}
+
+template <bool GRAD, bool LOSS>
+static void launch_main(const Plan& p, hipStream_t st) {
+  const dim3 grid(p.args.items), block(64);
+#define SFM_LAUNCH(SS, EX, SM) hipLaunchKernelGGL((loss_kernel<SS, GRAD, LOSS, EX, SM>), grid, block, 0, st, p.args)
+  if (p.expl) {
+    if (p.smode == 0) SFM_LAUNCH(false, true, 0);
+    else if (p.smode == 1) SFM_LAUNCH(false, true, 1);
+    else SFM_LAUNCH(false, true, 2);
+  } else if (p.ssim) {
+    if (p.smode == 0) SFM_LAUNCH(true, false, 0);
+    else if (p.smode == 1) SFM_LAUNCH(true, false, 1);
+    else SFM_LAUNCH(true, false, 2);
+  } else {
+    if (p.smode == 0) SFM_LAUNCH(false, false, 0);
+    else if (p.smode == 1) SFM_LAUNCH(false, false, 1);
+    else SFM_LAUNCH(false, false, 2);
+  }
+#undef SFM_LAUNCH
+}
+
+static int run(const SfmLossDesc* d, bool grad, bool loss, float gy, float* loss5, void* ws, size_t ws_bytes, void* stream,
+               const char* who) {
+  Plan p;
+  if (int e = make_plan(d, grad, true, gy, p)) return e;
+  if (loss && !loss5) return fail(SFM_ERR_NULL, "%s: loss5 is NULL", who);
+  if (!ws || ws_bytes < p.total) return fail(SFM_ERR_WORKSPACE, "%s: workspace of %zu bytes needed, got %zu", who, p.total, ws_bytes);
+  if (((uintptr_t)ws & 255) != 0) return fail(SFM_ERR_WORKSPACE, "%s: workspace must be 256-byte aligned", who);
+  bind_workspace(p, ws);
+  hipStream_t st = (hipStream_t)stream;
+  if (d->B == 0) {
+    if (loss) {
+      hipError_t e = hipMemsetAsync(loss5, 0, 5 * sizeof(float), st);
+      if (e != hipSuccess) return fail((int)e, "%s: memset: %s", who, hipGetErrorString(e));
+    }
+    return SFM_OK;
+  }
+  const int ng = d->B * d->n_scales * d->n_src;
+  hipLaunchKernelGGL(geom_kernel, dim3((ng + 63) / 64), dim3(64), 0, st, p.args);
+  if (g_ev_start) (void)hipEventRecord(g_ev_start, st);
+  if (grad && loss) launch_main<true, true>(p, st);
+  else if (grad) launch_main<true, false>(p, st);
+  else launch_main<false, true>(p, st);
+  if (g_ev_stop) (void)hipEventRecord(g_ev_stop, st);
+  g_ev_start = g_ev_stop = nullptr;
+  const int n_pose_blocks = grad ? d->B * d->n_src : 0;
+  hipLaunchKernelGGL(finalize_kernel, dim3(n_pose_blocks + 1), dim3(64), 0, st, p.args, loss ? loss5 : (float*)nullptr, n_pose_blocks);
+  return check_launch(who);
+}
+
+}  // namespace sfm
+
+extern "C" {
+
+size_t sfm_loss_workspace_bytes(const SfmLossDesc* desc) {
+  sfm::Plan p;
+  // the gradient layout has the narrowest strips, hence the most items: size for it
+  if (sfm::make_plan(desc, true, false, 1.f, p) != SFM_OK) return 0;
+  return p.total;
+}
+
+int sfm_loss_profile_events(void* ev_start, void* ev_stop) {
+  sfm::g_ev_start = (hipEvent_t)ev_start;
+  sfm::g_ev_stop = (hipEvent_t)ev_stop;
+  return SFM_OK;
+}
+
+int sfm_loss_fwd(const SfmLossDesc* desc, float* loss5, void* ws, size_t ws_bytes, void* stream) {
+  return sfm::run(desc, false, true, 1.f, loss5, ws, ws_bytes, stream, "sfm_loss_fwd");
+}
+
+int sfm_loss_bwd(const SfmLossDesc* desc, float gy, void* ws, size_t ws_bytes, void* stream) {
+  return sfm::run(desc, true, false, gy, nullptr, ws, ws_bytes, stream, "sfm_loss_bwd");
+}
+
+int sfm_loss_fwd_bwd(const SfmLossDesc* desc, float* loss5, void* ws, size_t ws_bytes, void* stream) {
+  return sfm::run(desc, true, true, 1.f, loss5, ws, ws_bytes, stream, "sfm_loss_fwd_bwd");
+}
+
+}  // extern "C"

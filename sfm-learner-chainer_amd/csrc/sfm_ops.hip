@@ -1,0 +1,526 @@
+// Operator-level kernels of libsfmwarp: the individually callable pieces of the view-synthesis
+// path (pose -> projection, projective inverse warp, the two samplers, pyramid resize).
+// The multi-scale fused loss lives in sfm_loss.hip.  gfx950 only.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "sfm_common.h"
+
+namespace sfm {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+  }
+  return SFM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// pose -> projection  (models/transform.py:64-91)
+// ------------------------------------------------------------------------------------------
+__global__ void pose_proj_fwd_kernel(const float* __restrict__ pose6, const float* __restrict__ K,
+                                     float* __restrict__ proj, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  Geom g;
+  make_geom(pose6 + n * 6, K + n * 9, g);
+  float* o = proj + n * 16;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) o[k] = g.P[k];
+  o[12] = 0.f;
+  o[13] = 0.f;
+  o[14] = 0.f;
+  o[15] = 1.f;
+}
+
+// gT3 (3x4) = K^T . gPm[0:3, :]   (K4^T . gPm restricted to the rows that reach R and t)
+__device__ __forceinline__ void kt_times_gpm(const float* K, const float* gPm3x4, float* gT3, bool accumulate) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float v = K[0 * 3 + i] * gPm3x4[0 * 4 + j] + K[1 * 3 + i] * gPm3x4[1 * 4 + j] + K[2 * 3 + i] * gPm3x4[2 * 4 + j];
+      gT3[i * 4 + j] = accumulate ? gT3[i * 4 + j] + v : v;
+    }
+}
+
+__global__ void pose_proj_bwd_kernel(const float* __restrict__ pose6, const float* __restrict__ K,
+                                     const float* __restrict__ g_proj, float* __restrict__ d_pose6, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float gT3[12];
+  kt_times_gpm(K + n * 9, g_proj + n * 16, gT3, false);
+  float d[6];
+  pose_backward(pose6 + n * 6, gT3, d);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) d_pose6[n * 6 + k] = d[k];
+}
+
+// ------------------------------------------------------------------------------------------
+// projective_inverse_warp  (models/transform.py:156-193)
+// one block = 256 consecutive pixels of one sample; the block's geometry is built once in LDS
+// ------------------------------------------------------------------------------------------
+constexpr int WARP_BLOCK = 256;
+
+__global__ void __launch_bounds__(WARP_BLOCK) warp_fwd_kernel(const float* __restrict__ src, const float* __restrict__ depth,
+                                                              const float* __restrict__ pose6, const float* __restrict__ K,
+                                                              float* __restrict__ warped, int C, int H, int W) {
+  __shared__ Geom g;
+  const int n = blockIdx.y;
+  if (threadIdx.x == 0) make_geom(pose6 + n * 6, K + n * 9, g);
+  __syncthreads();
+  const int P = H * W;
+  const int j = blockIdx.x * WARP_BLOCK + threadIdx.x;
+  if (j >= P) return;
+  const int y = j / W, x = j - y * W;
+  const float xf = (float)x, yf = (float)y;
+  const ScaleConst sc = make_scale_const(H, W);
+  const float D = depth[(size_t)n * P + j];
+  const float a0 = fmaf(g.M[0], xf, fmaf(g.M[1], yf, g.M[2]));
+  const float a1 = fmaf(g.M[3], xf, fmaf(g.M[4], yf, g.M[5]));
+  const float a2 = fmaf(g.M[6], xf, fmaf(g.M[7], yf, g.M[8]));
+  const Proj p = project(a0, a1, a2, g.P[3], g.P[7], g.P[11], D, sc, H, W);
+  const float* s = src + (size_t)n * C * P + p.v0 * W + p.u0;
+  float* o = warped + (size_t)n * C * P + j;
+  for (int c = 0; c < C; ++c) {
+    float val = 0.f;
+    if (p.inview) {
+      const Tap2 t = load_tap2(s + (size_t)c * P);
+      const Tap2 b = load_tap2(s + (size_t)c * P + W);
+      const float top = fmaf(p.fu, t.b - t.a, t.a);
+      const float bot = fmaf(p.fu, b.b - b.a, b.a);
+      val = fmaf(p.fv, bot - top, top);
+    }
+    o[(size_t)c * P] = val;
+  }
+}
+
+// per pixel: gq from g_warped, d_depth, and the 12 sums of gPm (block-reduced into ws)
+__global__ void __launch_bounds__(WARP_BLOCK) warp_bwd_kernel(const float* __restrict__ src, const float* __restrict__ depth,
+                                                              const float* __restrict__ pose6, const float* __restrict__ K,
+                                                              const float* __restrict__ g_warped, float* __restrict__ d_depth,
+                                                              float* __restrict__ d_src, float* __restrict__ part, int C, int H,
+                                                              int W) {
+  __shared__ Geom g;
+  __shared__ float red[WARP_BLOCK / 64][12];
+  const int n = blockIdx.y;
+  if (threadIdx.x == 0) make_geom(pose6 + n * 6, K + n * 9, g);
+  __syncthreads();
+  const int P = H * W;
+  const int j = blockIdx.x * WARP_BLOCK + threadIdx.x;
+  float acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+  if (j < P) {
+    const int y = j / W, x = j - y * W;
+    const float xf = (float)x, yf = (float)y;
+    const ScaleConst sc = make_scale_const(H, W);
+    const float D = depth[(size_t)n * P + j];
+    const float a0 = fmaf(g.M[0], xf, fmaf(g.M[1], yf, g.M[2]));
+    const float a1 = fmaf(g.M[3], xf, fmaf(g.M[4], yf, g.M[5]));
+    const float a2 = fmaf(g.M[6], xf, fmaf(g.M[7], yf, g.M[8]));
+    const Proj p = project(a0, a1, a2, g.P[3], g.P[7], g.P[11], D, sc, H, W);
+    float gU = 0.f, gV = 0.f;
+    if (p.inview) {
+      const size_t base = (size_t)n * C * P + p.v0 * W + p.u0;
+      for (int c = 0; c < C; ++c) {
+        const float gc = g_warped[(size_t)n * C * P + (size_t)c * P + j];
+        const Tap2 t = load_tap2(src + base + (size_t)c * P);
+        const Tap2 b = load_tap2(src + base + (size_t)c * P + W);
+        const float dxt = t.b - t.a, dxb = b.b - b.a;
+        const float top = fmaf(p.fu, dxt, t.a);
+        const float bot = fmaf(p.fu, dxb, b.a);
+        gU = fmaf(gc, fmaf(p.fv, dxb - dxt, dxt), gU);
+        gV = fmaf(gc, bot - top, gV);
+        if (d_src) {
+          float* ds = d_src + base + (size_t)c * P;
+          const float w00 = (1.f - p.fu) * (1.f - p.fv), w01 = p.fu * (1.f - p.fv);
+          const float w10 = (1.f - p.fu) * p.fv, w11 = p.fu * p.fv;
+          atomicAdd(ds, gc * w00);
+          atomicAdd(ds + 1, gc * w01);
+          atomicAdd(ds + W, gc * w10);
+          atomicAdd(ds + W + 1, gc * w11);
+        }
+      }
+    }
+    const float gq0 = gU * p.rz, gq1 = gV * p.rz;
+    const float gq2 = -(gU * p.U + gV * p.V) * p.rz;
+    d_depth[(size_t)n * P + j] = gq0 * a0 + gq1 * a1 + gq2 * a2;
+    const float r0 = fmaf(g.Kinv[0], xf, fmaf(g.Kinv[1], yf, g.Kinv[2]));
+    const float r1 = fmaf(g.Kinv[3], xf, fmaf(g.Kinv[4], yf, g.Kinv[5]));
+    const float r2 = fmaf(g.Kinv[6], xf, fmaf(g.Kinv[7], yf, g.Kinv[8]));
+    const float c0 = D * r0, c1 = D * r1, c2 = D * r2;
+    acc[0] = gq0 * c0; acc[1] = gq0 * c1; acc[2] = gq0 * c2;  acc[3] = gq0;
+    acc[4] = gq1 * c0; acc[5] = gq1 * c1; acc[6] = gq1 * c2;  acc[7] = gq1;
+    acc[8] = gq2 * c0; acc[9] = gq2 * c1; acc[10] = gq2 * c2; acc[11] = gq2;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    const float s = wave_sum(acc[k]);
+    if (lane == 0) red[wave][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 12) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < WARP_BLOCK / 64; ++w) s += red[w][threadIdx.x];
+    part[((size_t)n * gridDim.x + blockIdx.x) * 12 + threadIdx.x] = s;
+  }
+}
+
+// one wave per sample: fixed-order sum of the block partials, then the pose backward
+__global__ void __launch_bounds__(64) warp_bwd_pose_kernel(const float* __restrict__ pose6, const float* __restrict__ K,
+                                                           const float* __restrict__ part, float* __restrict__ d_pose6,
+                                                           int nblk) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  double acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) acc[k] = 0.0;
+  for (int b = lane; b < nblk; b += 64)
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] += (double)part[((size_t)n * nblk + b) * 12 + k];
+  float gPm[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    gPm[k] = (float)v;
+  }
+  if (lane == 0) {
+    float gT3[12], d[6];
+    kt_times_gpm(K + n * 9, gPm, gT3, false);
+    pose_backward(pose6 + n * 6, gT3, d);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) d_pose6[n * 6 + k] = d[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// F.spatial_transformer_sampler (call site models/transform.py:189): general semantics on the
+// zero-padded image, for arbitrary grids
+// ------------------------------------------------------------------------------------------
+struct PadTap {
+  int u0, v0;             // top-left tap in PADDED coordinates, u0 in [0,W], v0 in [0,H]
+  float wx0, wx1, wy0, wy1;
+  bool ok_u, ok_v;        // coordinate inside the padded image (gradient mask)
+};
+
+__device__ __forceinline__ PadTap pad_taps(float gx, float gy, int H, int W) {
+#pragma clang fp contract(off)
+  PadTap t;
+  const float up = (gx + 1.0f) * (float)(W - 1) * 0.5f + 1.0f;
+  const float vp = (gy + 1.0f) * (float)(H - 1) * 0.5f + 1.0f;
+  const float uc = fminf(fmaxf(up, 0.0f), (float)(W + 1));
+  const float vc = fminf(fmaxf(vp, 0.0f), (float)(H + 1));
+  t.u0 = min(max((int)floorf(uc), 0), W);
+  t.v0 = min(max((int)floorf(vc), 0), H);
+  t.wx0 = (float)(t.u0 + 1) - uc;
+  t.wx1 = uc - (float)t.u0;
+  t.wy0 = (float)(t.v0 + 1) - vc;
+  t.wy1 = vc - (float)t.v0;
+  t.ok_u = (up >= 0.0f) && (up <= (float)(W + 1));
+  t.ok_v = (vp >= 0.0f) && (vp <= (float)(H + 1));
+  return t;
+}
+
+__device__ __forceinline__ float pad_read(const float* img, int v, int u, int H, int W) {  // padded coords
+  return (u >= 1 && u <= W && v >= 1 && v <= H) ? img[(v - 1) * W + (u - 1)] : 0.0f;
+}
+
+__global__ void sampler_fwd_kernel(const float* __restrict__ x, const float* __restrict__ grid, float* __restrict__ y, int C,
+                                   int H, int W, int oP) {
+  const int n = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= oP) return;
+  const PadTap t = pad_taps(grid[((size_t)n * 2 + 0) * oP + j], grid[((size_t)n * 2 + 1) * oP + j], H, W);
+  const float w1 = t.wx0 * t.wy0, w2 = t.wx1 * t.wy0, w3 = t.wx0 * t.wy1, w4 = t.wx1 * t.wy1;
+  for (int c = 0; c < C; ++c) {
+    const float* img = x + ((size_t)n * C + c) * H * W;
+    float v = w1 * pad_read(img, t.v0, t.u0, H, W);
+    v += w2 * pad_read(img, t.v0, t.u0 + 1, H, W);
+    v += w3 * pad_read(img, t.v0 + 1, t.u0, H, W);
+    v += w4 * pad_read(img, t.v0 + 1, t.u0 + 1, H, W);
+    y[((size_t)n * C + c) * oP + j] = v;
+  }
+}
+
+__global__ void sampler_bwd_kernel(const float* __restrict__ x, const float* __restrict__ grid, const float* __restrict__ gy,
+                                   float* __restrict__ ggrid, float* __restrict__ gx, int C, int H, int W, int oP) {
+  const int n = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= oP) return;
+  const PadTap t = pad_taps(grid[((size_t)n * 2 + 0) * oP + j], grid[((size_t)n * 2 + 1) * oP + j], H, W);
+  float gu = 0.f, gv = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float* img = x + ((size_t)n * C + c) * H * W;
+    const float g = gy[((size_t)n * C + c) * oP + j];
+    const float x1 = pad_read(img, t.v0, t.u0, H, W), x2 = pad_read(img, t.v0, t.u0 + 1, H, W);
+    const float x3 = pad_read(img, t.v0 + 1, t.u0, H, W), x4 = pad_read(img, t.v0 + 1, t.u0 + 1, H, W);
+    gu += g * (-t.wy0 * x1 + t.wy0 * x2 - t.wy1 * x3 + t.wy1 * x4);
+    gv += g * (-t.wx0 * x1 - t.wx1 * x2 + t.wx0 * x3 + t.wx1 * x4);
+    if (gx) {
+      float* o = gx + ((size_t)n * C + c) * H * W;
+      const int u = t.u0, v = t.v0;
+      if (u >= 1 && u <= W && v >= 1 && v <= H) atomicAdd(o + (v - 1) * W + (u - 1), g * t.wx0 * t.wy0);
+      if (u + 1 >= 1 && u + 1 <= W && v >= 1 && v <= H) atomicAdd(o + (v - 1) * W + u, g * t.wx1 * t.wy0);
+      if (u >= 1 && u <= W && v + 1 >= 1 && v + 1 <= H) atomicAdd(o + v * W + (u - 1), g * t.wx0 * t.wy1);
+      if (u + 1 >= 1 && u + 1 <= W && v + 1 >= 1 && v + 1 <= H) atomicAdd(o + v * W + u, g * t.wx1 * t.wy1);
+    }
+  }
+  ggrid[((size_t)n * 2 + 0) * oP + j] = t.ok_u ? gu * ((float)(W - 1) * 0.5f) : 0.f;
+  ggrid[((size_t)n * 2 + 1) * oP + j] = t.ok_v ? gv * ((float)(H - 1) * 0.5f) : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------
+// SpatialTransformerSamplerInterp (models/spational_transformer_sampler_interp.py:32-149)
+// ------------------------------------------------------------------------------------------
+struct InterpTap {
+  int u0, v0, u1, v1;
+  float wx0, wx1, wy0, wy1;
+};
+
+__device__ __forceinline__ InterpTap interp_taps(float u, float v, int H, int W) {
+#pragma clang fp contract(off)
+  InterpTap t;
+  float u0 = floorf(u), v0 = floorf(v);                                    // :41-44
+  float u1 = u0 + 1.0f, v1 = v0 + 1.0f;
+  u0 = fminf(fmaxf(u0, 0.0f), (float)(W - 1));                             // :46-49
+  v0 = fminf(fmaxf(v0, 0.0f), (float)(H - 1));
+  u1 = fminf(fmaxf(u1, 0.0f), (float)(W - 1));
+  v1 = fminf(fmaxf(v1, 0.0f), (float)(H - 1));
+  t.wx0 = u1 - u;                                                          // :52-55
+  t.wx1 = u - u0;
+  t.wy0 = v1 - v;
+  t.wy1 = v - v0;
+  t.u0 = (int)u0; t.v0 = (int)v0; t.u1 = (int)u1; t.v1 = (int)v1;         // :66-69
+  return t;
+}
+
+__global__ void interp_fwd_kernel(const float* __restrict__ x, const float* __restrict__ grid, float* __restrict__ y, int C,
+                                  int H, int W, int oP) {
+#pragma clang fp contract(off)
+  const int n = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= oP) return;
+  const InterpTap t = interp_taps(grid[((size_t)n * 2 + 0) * oP + j], grid[((size_t)n * 2 + 1) * oP + j], H, W);
+  const float w1 = t.wx0 * t.wy0, w2 = t.wx1 * t.wy0, w3 = t.wx0 * t.wy1, w4 = t.wx1 * t.wy1;   // :57-60
+  for (int c = 0; c < C; ++c) {
+    const float* img = x + ((size_t)n * C + c) * H * W;
+    float v = w1 * img[t.v0 * W + t.u0];                                   // :72-75
+    v += w2 * img[t.v0 * W + t.u1];
+    v += w3 * img[t.v1 * W + t.u0];
+    v += w4 * img[t.v1 * W + t.u1];
+    y[((size_t)n * C + c) * oP + j] = v;
+  }
+}
+
+__global__ void interp_bwd_kernel(const float* __restrict__ x, const float* __restrict__ grid, const float* __restrict__ gy,
+                                  float* __restrict__ ggrid, int C, int H, int W, int oP) {
+#pragma clang fp contract(off)
+  const int n = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= oP) return;
+  const InterpTap t = interp_taps(grid[((size_t)n * 2 + 0) * oP + j], grid[((size_t)n * 2 + 1) * oP + j], H, W);
+  float su = 0.f, sv = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float* img = x + ((size_t)n * C + c) * H * W;
+    const float g = gy[((size_t)n * C + c) * oP + j];
+    const float x1 = img[t.v0 * W + t.u0], x2 = img[t.v0 * W + t.u1];
+    const float x3 = img[t.v1 * W + t.u0], x4 = img[t.v1 * W + t.u1];
+    float gu = -t.wy0 * x1;                                                // :129-132
+    gu += t.wy0 * x2;
+    gu -= t.wy1 * x3;
+    gu += t.wy1 * x4;
+    float gv = -t.wx0 * x1;                                                // :134-137
+    gv -= t.wx1 * x2;
+    gv += t.wx0 * x3;
+    gv += t.wx1 * x4;
+    su += gu * g;                                                          // :142-145
+    sv += gv * g;
+  }
+  ggrid[((size_t)n * 2 + 0) * oP + j] = su;
+  ggrid[((size_t)n * 2 + 1) * oP + j] = sv;
+}
+
+// ------------------------------------------------------------------------------------------
+// F.resize_images, align-corners bilinear (models/base_model.py:70-72)
+// ------------------------------------------------------------------------------------------
+__global__ void resize_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int oH, int oW) {
+#pragma clang fp contract(off)
+  const int nc = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= oH * oW) return;
+  const int oy = j / oW, ox = j - oy * oW;
+  // numpy.linspace(0, W-1, oW)[ox] = ox * step with step = (W-1)/(oW-1), evaluated in double
+  const float u = oW > 1 ? (float)((double)ox * ((double)(W - 1) / (double)(oW - 1))) : 0.f;
+  const float v = oH > 1 ? (float)((double)oy * ((double)(H - 1) / (double)(oH - 1))) : 0.f;
+  const int u0 = min(max((int)floorf(u), 0), max(W - 2, 0)), v0 = min(max((int)floorf(v), 0), max(H - 2, 0));
+  const int u1 = min(u0 + 1, W - 1), v1 = min(v0 + 1, H - 1);
+  const float wu1 = u - (float)u0, wv1 = v - (float)v0;
+  const float wu0 = 1.0f - wu1, wv0 = 1.0f - wv1;
+  const float* img = x + (size_t)nc * H * W;
+  const float top = img[v0 * W + u0] * wu0 + img[v0 * W + u1] * wu1;
+  const float bot = img[v1 * W + u0] * wu0 + img[v1 * W + u1] * wu1;
+  y[(size_t)nc * oH * oW + j] = top * wv0 + bot * wv1;
+}
+
+}  // namespace sfm
+
+using namespace sfm;
+
+extern "C" {
+
+int sfm_abi_version(void) { return SFM_ABI_VERSION; }
+const char* sfm_last_error(void) { return sfm::g_err; }
+
+#define SFM_REQUIRE(cond, code, ...) \
+  do {                               \
+    if (!(cond)) return fail(code, __VA_ARGS__); \
+  } while (0)
+
+int sfm_pose_proj_fwd(const float* pose6, const float* K, float* proj, int N, void* stream) {
+  if (N == 0) return SFM_OK;   // empty batch: nothing to do, pointers may be NULL
+  SFM_REQUIRE(pose6 && K && proj, SFM_ERR_NULL, "sfm_pose_proj_fwd: NULL pointer");
+  SFM_REQUIRE(N >= 0, SFM_ERR_SHAPE, "sfm_pose_proj_fwd: N=%d", N);
+  if (N == 0) return SFM_OK;
+  hipLaunchKernelGGL(pose_proj_fwd_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, pose6, K, proj, N);
+  return check_launch("sfm_pose_proj_fwd");
+}
+
+int sfm_pose_proj_bwd(const float* pose6, const float* K, const float* g_proj, float* d_pose6, int N, void* stream) {
+  if (N == 0) return SFM_OK;   // empty batch: nothing to do, pointers may be NULL
+  SFM_REQUIRE(pose6 && K && g_proj && d_pose6, SFM_ERR_NULL, "sfm_pose_proj_bwd: NULL pointer");
+  SFM_REQUIRE(N >= 0, SFM_ERR_SHAPE, "sfm_pose_proj_bwd: N=%d", N);
+  if (N == 0) return SFM_OK;
+  hipLaunchKernelGGL(pose_proj_bwd_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, pose6, K, g_proj, d_pose6, N);
+  return check_launch("sfm_pose_proj_bwd");
+}
+
+static int check_warp_shape(const char* who, int N, int C, int H, int W) {
+  SFM_REQUIRE(N >= 0 && N <= 65535, SFM_ERR_SHAPE, "%s: N=%d out of range [0,65535]", who, N);
+  SFM_REQUIRE(C >= 1, SFM_ERR_SHAPE, "%s: C=%d", who, C);
+  SFM_REQUIRE(H >= 3 && W >= 3, SFM_ERR_SHAPE, "%s: H=%d W=%d, need H,W >= 3", who, H, W);
+  SFM_REQUIRE((long long)C * H * W < (1ll << 31), SFM_ERR_SHAPE, "%s: C*H*W too large", who);
+  return SFM_OK;
+}
+
+int sfm_warp_fwd(const float* src, const float* depth, const float* pose6, const float* K, float* warped, int N, int C,
+                 int H, int W, void* stream) {
+  if (N == 0) return SFM_OK;   // empty batch: nothing to do, pointers may be NULL
+  SFM_REQUIRE(src && depth && pose6 && K && warped, SFM_ERR_NULL, "sfm_warp_fwd: NULL pointer");
+  if (int e = check_warp_shape("sfm_warp_fwd", N, C, H, W)) return e;
+  if (N == 0) return SFM_OK;
+  dim3 grid((H * W + WARP_BLOCK - 1) / WARP_BLOCK, N);
+  hipLaunchKernelGGL(warp_fwd_kernel, grid, dim3(WARP_BLOCK), 0, (hipStream_t)stream, src, depth, pose6, K, warped, C, H, W);
+  return check_launch("sfm_warp_fwd");
+}
+
+size_t sfm_warp_bwd_workspace_bytes(int N, int H, int W) {
+  if (N <= 0 || H <= 0 || W <= 0) return 0;
+  const size_t nblk = ((size_t)H * W + WARP_BLOCK - 1) / WARP_BLOCK;
+  return (size_t)N * nblk * 12 * sizeof(float);
+}
+
+int sfm_warp_bwd(const float* src, const float* depth, const float* pose6, const float* K, const float* g_warped,
+                 float* d_depth, float* d_pose6, float* d_src, void* ws, size_t ws_bytes, int N, int C, int H, int W,
+                 void* stream) {
+  if (N == 0) return SFM_OK;   // empty batch: nothing to do, pointers may be NULL
+  SFM_REQUIRE(src && depth && pose6 && K && g_warped && d_depth && d_pose6, SFM_ERR_NULL, "sfm_warp_bwd: NULL pointer");
+  if (int e = check_warp_shape("sfm_warp_bwd", N, C, H, W)) return e;
+  if (N == 0) return SFM_OK;
+  SFM_REQUIRE(ws && ws_bytes >= sfm_warp_bwd_workspace_bytes(N, H, W), SFM_ERR_WORKSPACE,
+              "sfm_warp_bwd: workspace of %zu bytes needed, got %zu", sfm_warp_bwd_workspace_bytes(N, H, W), ws_bytes);
+  const int nblk = (H * W + WARP_BLOCK - 1) / WARP_BLOCK;
+  hipLaunchKernelGGL(warp_bwd_kernel, dim3(nblk, N), dim3(WARP_BLOCK), 0, (hipStream_t)stream, src, depth, pose6, K, g_warped,
+                     d_depth, d_src, (float*)ws, C, H, W);
+  hipLaunchKernelGGL(warp_bwd_pose_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, pose6, K, (const float*)ws, d_pose6, nblk);
+  return check_launch("sfm_warp_bwd");
+}
+
+static int check_sampler_shape(const char* who, int N, int C, int H, int W, int oH, int oW) {
+  SFM_REQUIRE(N >= 0 && N <= 65535, SFM_ERR_SHAPE, "%s: N=%d out of range [0,65535]", who, N);
+  SFM_REQUIRE(C >= 1 && H >= 1 && W >= 1 && oH >= 0 && oW >= 0, SFM_ERR_SHAPE, "%s: bad shape C=%d H=%d W=%d oH=%d oW=%d", who,
+              C, H, W, oH, oW);
+  SFM_REQUIRE((long long)C * H * W < (1ll << 31) && (long long)C * oH * oW < (1ll << 31), SFM_ERR_SHAPE, "%s: too large", who);
+  return SFM_OK;
+}
+
+int sfm_sampler_fwd(const float* x, const float* grid, float* y, int N, int C, int H, int W, int oH, int oW, void* stream) {
+  if (N == 0) return SFM_OK;   // empty batch: nothing to do, pointers may be NULL
+  SFM_REQUIRE(x && grid && y, SFM_ERR_NULL, "sfm_sampler_fwd: NULL pointer");
+  if (int e = check_sampler_shape("sfm_sampler_fwd", N, C, H, W, oH, oW)) return e;
+  if (N == 0 || oH * oW == 0) return SFM_OK;
+  hipLaunchKernelGGL(sampler_fwd_kernel, dim3((oH * oW + 255) / 256, N), dim3(256), 0, (hipStream_t)stream, x, grid, y, C, H, W,
+                     oH * oW);
+  return check_launch("sfm_sampler_fwd");
+}
+
+int sfm_sampler_bwd(const float* x, const float* grid, const float* gy, float* ggrid, float* gx, int N, int C, int H, int W,
+                    int oH, int oW, void* stream) {
+  if (N == 0) return SFM_OK;   // empty batch: nothing to do, pointers may be NULL
+  SFM_REQUIRE(x && grid && gy && ggrid, SFM_ERR_NULL, "sfm_sampler_bwd: NULL pointer");
+  if (int e = check_sampler_shape("sfm_sampler_bwd", N, C, H, W, oH, oW)) return e;
+  if (N == 0 || oH * oW == 0) return SFM_OK;
+  hipLaunchKernelGGL(sampler_bwd_kernel, dim3((oH * oW + 255) / 256, N), dim3(256), 0, (hipStream_t)stream, x, grid, gy, ggrid,
+                     gx, C, H, W, oH * oW);
+  return check_launch("sfm_sampler_bwd");
+}
+
+int sfm_sampler_interp_fwd(const float* x, const float* grid, float* y, int N, int C, int H, int W, int oH, int oW,
+                           void* stream) {
+  if (N == 0) return SFM_OK;   // empty batch: nothing to do, pointers may be NULL
+  SFM_REQUIRE(x && grid && y, SFM_ERR_NULL, "sfm_sampler_interp_fwd: NULL pointer");
+  if (int e = check_sampler_shape("sfm_sampler_interp_fwd", N, C, H, W, oH, oW)) return e;
+  if (N == 0 || oH * oW == 0) return SFM_OK;
+  hipLaunchKernelGGL(interp_fwd_kernel, dim3((oH * oW + 255) / 256, N), dim3(256), 0, (hipStream_t)stream, x, grid, y, C, H, W,
+                     oH * oW);
+  return check_launch("sfm_sampler_interp_fwd");
+}
+
+int sfm_sampler_interp_bwd(const float* x, const float* grid, const float* gy, float* ggrid, float* gx, int N, int C, int H,
+                           int W, int oH, int oW, void* stream) {
+  if (N == 0) return SFM_OK;   // empty batch: nothing to do, pointers may be NULL
+  SFM_REQUIRE(x && grid && gy && ggrid, SFM_ERR_NULL, "sfm_sampler_interp_bwd: NULL pointer");
+  if (int e = check_sampler_shape("sfm_sampler_interp_bwd", N, C, H, W, oH, oW)) return e;
+  if (gx) {  // spational_transformer_sampler_interp.py:148: gx = zeros_like(x)
+    hipError_t e = hipMemsetAsync(gx, 0, (size_t)N * C * H * W * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return fail((int)e, "sfm_sampler_interp_bwd: memset: %s", hipGetErrorString(e));
+  }
+  if (N == 0 || oH * oW == 0) return SFM_OK;
+  hipLaunchKernelGGL(interp_bwd_kernel, dim3((oH * oW + 255) / 256, N), dim3(256), 0, (hipStream_t)stream, x, grid, gy, ggrid, C,
+                     H, W, oH * oW);
+  return check_launch("sfm_sampler_interp_bwd");
+}
+
+int sfm_resize_fwd(const float* x, float* y, int N, int C, int H, int W, int oH, int oW, void* stream) {
+  if (N == 0) return SFM_OK;   // empty batch: nothing to do, pointers may be NULL
+  SFM_REQUIRE(x && y, SFM_ERR_NULL, "sfm_resize_fwd: NULL pointer");
+  SFM_REQUIRE(N >= 0 && C >= 1 && H >= 1 && W >= 1 && oH >= 1 && oW >= 1, SFM_ERR_SHAPE, "sfm_resize_fwd: bad shape");
+  SFM_REQUIRE((long long)N * C <= 65535, SFM_ERR_SHAPE, "sfm_resize_fwd: N*C=%lld > 65535", (long long)N * C);
+  if (N == 0) return SFM_OK;
+  hipLaunchKernelGGL(resize_fwd_kernel, dim3((oH * oW + 255) / 256, N * C), dim3(256), 0, (hipStream_t)stream, x, y, H, W, oH, oW);
+  return check_launch("sfm_resize_fwd");
+}
+
+}  // extern "C"

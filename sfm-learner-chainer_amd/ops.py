@@ -1,0 +1,254 @@
+"""Thin array-level wrappers over the C ABI.  torch.Tensor on a ROCm device is used purely as
+the device-array container (allocation, stream, lifetime); all arithmetic happens in
+libsfmwarp.so.  Arrays are float32, C-contiguous, NCHW -- the reference's layout.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import SfmLossDesc, check, lib
+
+__all__ = ["pose_proj_fwd", "pose_proj_bwd", "warp_fwd", "warp_bwd", "sampler_fwd", "sampler_bwd",
+           "interp_fwd", "interp_bwd", "resize", "FusedLoss"]
+
+
+def _dev(t, name, ndim=None):
+    """float32 CUDA(ROCm) tensor, contiguous; anything else is a type error, as in the
+    reference's check_type_forward (spational_transformer_sampler_interp.py:11-24)."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s: expected a torch.Tensor on a ROCm device, got %s" % (name, type(t).__name__))
+    if not t.is_cuda:
+        raise TypeError("%s: CPU arrays are not supported by this build (GPU-only, no CPU fallback)" % name)
+    if t.dtype != torch.float32:
+        raise TypeError("%s: expected dtype float32 (dtype.char == 'f'), got %s" % (name, t.dtype))
+    if ndim is not None and t.dim() != ndim:
+        raise TypeError("%s: expected ndim == %d, got %d" % (name, ndim, t.dim()))
+    return t.contiguous()
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def pose_proj_fwd(pose6, K):
+    pose6, K = _dev(pose6, "pose6", 2), _dev(K, "K", 3)
+    N = pose6.shape[0]
+    if pose6.shape[1] != 6 or tuple(K.shape) != (N, 3, 3):
+        raise TypeError("pose6 must be (N,6) and K (N,3,3)")
+    out = torch.empty((N, 4, 4), dtype=torch.float32, device=pose6.device)
+    with torch.cuda.device(pose6.device):
+        check(lib.sfm_pose_proj_fwd(_p(pose6), _p(K), _p(out), N, _stream()))
+    return out
+
+
+def pose_proj_bwd(pose6, K, g_proj):
+    pose6, K, g_proj = _dev(pose6, "pose6", 2), _dev(K, "K", 3), _dev(g_proj, "g_proj", 3)
+    N = pose6.shape[0]
+    out = torch.empty((N, 6), dtype=torch.float32, device=pose6.device)
+    with torch.cuda.device(pose6.device):
+        check(lib.sfm_pose_proj_bwd(_p(pose6), _p(K), _p(g_proj), _p(out), N, _stream()))
+    return out
+
+
+def _warp_args(imgs, depth, pose6, K):
+    imgs = _dev(imgs, "imgs", 4)
+    N, Cc, H, W = imgs.shape
+    depth = _dev(depth, "depth")
+    if depth.numel() != N * H * W:
+        raise TypeError("depth must hold N*H*W values, got shape %s" % (tuple(depth.shape),))
+    pose6, K = _dev(pose6, "poses", 2), _dev(K, "K", 3)
+    if tuple(pose6.shape) != (N, 6) or tuple(K.shape) != (N, 3, 3):
+        raise TypeError("poses must be (N,6) and K (N,3,3) with N=%d" % N)
+    return imgs, depth, pose6, K, N, Cc, H, W
+
+
+def warp_fwd(imgs, depth, pose6, K):
+    """projective_inverse_warp forward.  depth: (N,H*W) (one row of the reference's broadcast)."""
+    imgs, depth, pose6, K, N, Cc, H, W = _warp_args(imgs, depth, pose6, K)
+    out = torch.empty_like(imgs)
+    with torch.cuda.device(imgs.device):
+        check(lib.sfm_warp_fwd(_p(imgs), _p(depth), _p(pose6), _p(K), _p(out), N, Cc, H, W, _stream()))
+    return out
+
+
+def warp_bwd(imgs, depth, pose6, K, g_warped, want_d_src=False):
+    imgs, depth, pose6, K, N, Cc, H, W = _warp_args(imgs, depth, pose6, K)
+    g_warped = _dev(g_warped, "g_warped", 4)
+    if g_warped.shape != imgs.shape:
+        raise TypeError("g_warped must have the shape of imgs")
+    d_depth = torch.empty((N, H * W), dtype=torch.float32, device=imgs.device)
+    d_pose = torch.empty((N, 6), dtype=torch.float32, device=imgs.device)
+    d_src = torch.zeros_like(imgs) if want_d_src else None
+    nbytes = lib.sfm_warp_bwd_workspace_bytes(N, H, W)
+    ws = torch.empty((max(nbytes, 4) // 4,), dtype=torch.float32, device=imgs.device)
+    with torch.cuda.device(imgs.device):
+        check(lib.sfm_warp_bwd(_p(imgs), _p(depth), _p(pose6), _p(K), _p(g_warped), _p(d_depth), _p(d_pose),
+                               _p(d_src), _p(ws), nbytes, N, Cc, H, W, _stream()))
+    return d_depth, d_pose, d_src
+
+
+def _sampler_args(x, grid):
+    x, grid = _dev(x, "x", 4), _dev(grid, "grid", 4)
+    if grid.shape[1] != 2:
+        raise TypeError("grid.shape[1] must be 2, got %d" % grid.shape[1])
+    if x.shape[0] != grid.shape[0]:
+        raise TypeError("x.shape[0] != grid.shape[0] (%d vs %d)" % (x.shape[0], grid.shape[0]))
+    N, Cc, H, W = x.shape
+    return x, grid, N, Cc, H, W, grid.shape[2], grid.shape[3]
+
+
+def _sampler(fwd, x, grid):
+    x, grid, N, Cc, H, W, oH, oW = _sampler_args(x, grid)
+    y = torch.empty((N, Cc, oH, oW), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(fwd(_p(x), _p(grid), _p(y), N, Cc, H, W, oH, oW, _stream()))
+    return y
+
+
+def _sampler_b(bwd, x, grid, gy, want_gx):
+    x, grid, N, Cc, H, W, oH, oW = _sampler_args(x, grid)
+    gy = _dev(gy, "gy", 4)
+    if tuple(gy.shape) != (N, Cc, oH, oW):
+        raise TypeError("gy must be (N,C,oH,oW)")
+    ggrid = torch.empty_like(grid)
+    gx = torch.zeros_like(x) if want_gx else None
+    with torch.cuda.device(x.device):
+        check(bwd(_p(x), _p(grid), _p(gy), _p(ggrid), _p(gx), N, Cc, H, W, oH, oW, _stream()))
+    return gx, ggrid
+
+
+def sampler_fwd(x, grid):
+    return _sampler(lib.sfm_sampler_fwd, x, grid)
+
+
+def sampler_bwd(x, grid, gy, want_gx=True):
+    return _sampler_b(lib.sfm_sampler_bwd, x, grid, gy, want_gx)
+
+
+def interp_fwd(x, grid):
+    return _sampler(lib.sfm_sampler_interp_fwd, x, grid)
+
+
+def interp_bwd(x, grid, gy, want_gx=True):
+    return _sampler_b(lib.sfm_sampler_interp_bwd, x, grid, gy, want_gx)
+
+
+def resize(x, out_hw):
+    x = _dev(x, "x", 4)
+    N, Cc, H, W = x.shape
+    oH, oW = int(out_hw[0]), int(out_hw[1])
+    y = torch.empty((N, Cc, oH, oW), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.sfm_resize_fwd(_p(x), _p(y), N, Cc, H, W, oH, oW, _stream()))
+    return y
+
+
+class FusedLoss:
+    """One bound instance of the fused multi-scale loss (sfm_loss_fwd / _bwd / _fwd_bwd):
+    descriptor + caller-owned workspace and outputs.  Re-usable across steps as long as the
+    input tensors keep their addresses (call `bind` again otherwise)."""
+
+    def __init__(self, smooth_reg=0.0, exp_reg=0.0, ssim_rate=0.0, smooth_mode="second_order"):
+        if smooth_mode not in _lib.SMOOTH_MODES:
+            raise ValueError("smooth_mode must be one of %s" % sorted(k for k in _lib.SMOOTH_MODES if k))
+        self.smooth_reg = float(smooth_reg or 0.0)
+        self.exp_reg = float(exp_reg or 0.0)
+        self.ssim_rate = float(ssim_rate or 0.0)
+        self.smooth_mode = _lib.SMOOTH_MODES[smooth_mode]
+        self.desc = None
+        self._keep = None
+
+    def bind(self, tgt_pyr, src_pyr, intrinsics, disps, poses, masks=None, norm_B=None, want_d_src=False):
+        S = len(disps)
+        if not (len(tgt_pyr) == len(src_pyr) == S):
+            raise TypeError("tgt_pyr, src_pyr and disps must have one entry per scale")
+        if S > _lib.SFM_MAX_SCALES or len(poses) > _lib.SFM_MAX_SRC:
+            raise TypeError("at most %d scales and %d sources" % (_lib.SFM_MAX_SCALES, _lib.SFM_MAX_SRC))
+        tgt_pyr = [_dev(t, "tgt_pyr[%d]" % s, 4) for s, t in enumerate(tgt_pyr)]
+        src_pyr = [_dev(t, "src_pyr[%d]" % s, 4) for s, t in enumerate(src_pyr)]
+        disps = [_dev(t, "disps[%d]" % s, 4) for s, t in enumerate(disps)]
+        poses = [_dev(t, "poses[%d]" % i, 2) for i, t in enumerate(poses)]
+        intrinsics = _dev(intrinsics, "intrinsics", 4)
+        B = tgt_pyr[0].shape[0]
+        n_src = len(poses)
+        dev = tgt_pyr[0].device
+        if tuple(intrinsics.shape) != (B, S, 3, 3):
+            raise TypeError("intrinsics must be (B,%d,3,3), got %s" % (S, tuple(intrinsics.shape)))
+        use_masks = self.exp_reg > 0
+        if use_masks:
+            if masks is None:
+                raise ValueError("exp_reg > 0 needs the explainability logits (masks)")
+            masks = [_dev(t, "masks[%d]" % s, 4) for s, t in enumerate(masks)]
+        d = SfmLossDesc()
+        d.B, d.norm_B, d.n_src, d.n_scales = B, int(norm_B if norm_B is not None else B), n_src, S
+        d.smooth_reg, d.exp_reg, d.ssim_rate, d.smooth_mode = self.smooth_reg, self.exp_reg, self.ssim_rate, self.smooth_mode
+        d.intrinsics = intrinsics.data_ptr()
+        d_disps, d_masks, d_srcs = [], [], []
+        for s in range(S):
+            h, w = tgt_pyr[s].shape[2:]
+            if tuple(tgt_pyr[s].shape) != (B, 3, h, w) or tuple(src_pyr[s].shape) != (B, 3 * n_src, h, w) \
+                    or tuple(disps[s].shape) != (B, 1, h, w):
+                raise TypeError("scale %d: expected tgt (B,3,h,w), src (B,3*n_src,h,w), disp (B,1,h,w)" % s)
+            d.H[s], d.W[s] = h, w
+            d.tgt[s], d.src[s], d.disp[s] = tgt_pyr[s].data_ptr(), src_pyr[s].data_ptr(), disps[s].data_ptr()
+            d_disps.append(torch.empty_like(disps[s]))
+            d.d_disp[s] = d_disps[-1].data_ptr()
+            if use_masks:
+                if tuple(masks[s].shape) != (B, n_src, h, w):
+                    raise TypeError("masks[%d] must be (B,n_src,h,w)" % s)
+                d.mask_logits[s] = masks[s].data_ptr()
+                d_masks.append(torch.empty_like(masks[s]))
+                d.d_mask[s] = d_masks[-1].data_ptr()
+            if want_d_src:
+                d_srcs.append(torch.zeros_like(src_pyr[s]))
+                d.d_src[s] = d_srcs[-1].data_ptr()
+        d_poses = []
+        for i in range(n_src):
+            if tuple(poses[i].shape) != (B, 6):
+                raise TypeError("poses[%d] must be (B,6)" % i)
+            d.pose[i] = poses[i].data_ptr()
+            d_poses.append(torch.empty_like(poses[i]))
+            d.d_pose[i] = d_poses[-1].data_ptr()
+        nbytes = lib.sfm_loss_workspace_bytes(C.byref(d))
+        if nbytes == 0:
+            check(lib.sfm_loss_fwd(C.byref(d), None, None, 0, None))   # re-run the validation for its message
+            raise ValueError(_lib.last_error() or "invalid loss descriptor")
+        self.ws = torch.empty((nbytes // 4 + 64,), dtype=torch.float32, device=dev)
+        off = (-self.ws.data_ptr()) % 256
+        self._ws_ptr = self.ws.data_ptr() + off
+        self._ws_bytes = nbytes
+        self.loss5 = torch.zeros((5,), dtype=torch.float32, device=dev)
+        self.desc, self.device = d, dev
+        self.d_disps, self.d_poses, self.d_masks, self.d_srcs = d_disps, d_poses, (d_masks if use_masks else None), \
+            (d_srcs if want_d_src else None)
+        self._keep = (tgt_pyr, src_pyr, intrinsics, disps, poses, masks)
+        return self
+
+    def _zero_d_src(self):
+        if self.d_srcs is not None:
+            for t in self.d_srcs:
+                t.zero_()
+
+    def forward(self):
+        with torch.cuda.device(self.device):
+            check(lib.sfm_loss_fwd(C.byref(self.desc), _p(self.loss5), C.c_void_p(self._ws_ptr), self._ws_bytes, _stream()))
+        return self.loss5
+
+    def backward(self, gy=1.0):
+        self._zero_d_src()
+        with torch.cuda.device(self.device):
+            check(lib.sfm_loss_bwd(C.byref(self.desc), float(gy), C.c_void_p(self._ws_ptr), self._ws_bytes, _stream()))
+        return self.d_disps, self.d_poses, self.d_masks, self.d_srcs
+
+    def forward_backward(self):
+        self._zero_d_src()
+        with torch.cuda.device(self.device):
+            check(lib.sfm_loss_fwd_bwd(C.byref(self.desc), _p(self.loss5), C.c_void_p(self._ws_ptr), self._ws_bytes, _stream()))
+        return self.loss5

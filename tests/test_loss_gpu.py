@@ -1,0 +1,203 @@
+"""GPU parity of the fused multi-scale loss (sfm_loss_fwd / _bwd / _fwd_bwd through the C ABI)
+against the CPU oracle, on identical seeded inputs.
+
+Tolerances (fp32, north_star: 1e-4 relative on the loss):
+  * the five reported scalars ............. 1e-4 relative
+  * d_disp / d_pose / d_mask / d_src ...... 2e-3 of the array's largest magnitude, element-wise,
+    outside knife-edge pixels (see tests/util.py); they are sums of many fp32 terms whose
+    order differs between the oracle (NumPy) and the wave-level reductions.
+"""
+import numpy as np
+import pytest
+
+from oracle import sfm_oracle as O
+from util import assert_close_masked, dilate, to_dev, to_np
+
+pytestmark = pytest.mark.gpu
+
+LOSS_RTOL = 1e-4
+GRAD_TOL = 2e-3
+KEYS = ["total_loss", "pixel_loss", "smooth_loss", "exp_loss", "ssim_loss"]
+
+
+def _oracle(d, cfg, norm_B=None, want_d_src=False):
+    return O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], d["masks"],
+                      backward=True, want_d_src=want_d_src, keep_warped=True, norm_batch=norm_B, **cfg)
+
+
+def _bind(ops, dev, d, cfg, norm_B=None, want_d_src=False):
+    fl = ops.FusedLoss(**cfg)
+    fl.bind([to_dev(a, dev) for a in d["tgt_pyr"]], [to_dev(a, dev) for a in d["src_pyr"]],
+            to_dev(d["intrinsics"], dev), [to_dev(a, dev) for a in d["disps"]],
+            [to_dev(a, dev) for a in d["poses"]],
+            [to_dev(a, dev) for a in d["masks"]] if d["masks"] is not None else None,
+            norm_B=norm_B, want_d_src=want_d_src)
+    return fl
+
+
+def _check_losses(loss5, ref):
+    got = to_np(loss5)
+    for k, name in enumerate(KEYS):
+        want = ref[name]
+        assert abs(got[k] - want) <= LOSS_RTOL * max(abs(want), 1e-6), (name, got[k], want)
+
+
+def _knife(ref, s, n_src, thr=2e-5):
+    """pixels of scale s whose projection into ANY source is within thr of the |x|=1 boundary,
+    dilated by the 5x5 footprint of the SSIM backward"""
+    m = (ref["margin"][s] < thr).any(axis=1)          # (B,h,w)
+    assert m.mean() < 1e-3, "too many knife-edge pixels (%g): the exclusion would hide real errors" % m.mean()
+    return dilate(m, 2)[:, None]                      # (B,1,h,w)
+
+
+def _check_grads(fl, ref, n_src, check_src=False, check_mask=False):
+    for s, (g, w) in enumerate(zip(fl.d_disps, ref["d_disps"])):
+        assert_close_masked(to_np(g), w, GRAD_TOL, _knife(ref, s, n_src), what="d_disp[%d]" % s)
+    for i, (g, w) in enumerate(zip(fl.d_poses, ref["d_poses"])):
+        # a flipped knife-edge pixel moves a pose gradient by ~1/(#pixels): covered by the tolerance
+        assert_close_masked(to_np(g), w, GRAD_TOL, what="d_pose[%d]" % i)
+    if check_mask:
+        for s, (g, w) in enumerate(zip(fl.d_masks, ref["d_masks"])):
+            assert_close_masked(to_np(g), w, GRAD_TOL, what="d_mask[%d]" % s)
+    if check_src:
+        for s, (g, w) in enumerate(zip(fl.d_srcs, ref["d_srcs"])):
+            # scatter targets of knife-edge pixels: compare in aggregate
+            err = np.abs(to_np(g) - w)
+            scale = np.abs(w).max()
+            assert (err > GRAD_TOL * scale).mean() < 1e-3, ("d_src[%d]" % s, err.max(), scale)
+
+
+CONFIGS = {
+    "l1": dict(),
+    "l1_smooth": dict(smooth_reg=0.1),
+    "ssim_smooth": dict(smooth_reg=0.1, ssim_rate=0.15),
+    "ssim_only": dict(ssim_rate=0.15),
+    "edge_aware": dict(smooth_reg=0.1, ssim_rate=0.15, smooth_mode="edge_aware"),
+    "edge_aware_l1": dict(smooth_reg=0.3, smooth_mode="edge_aware"),
+    "explain": dict(smooth_reg=0.1, exp_reg=0.2),
+    "explain_alpha": dict(smooth_reg=0.1, exp_reg=0.2, ssim_rate=0.15),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+@pytest.mark.parametrize("shape", [(2, 32, 48, 2, 3), (1, 37, 70, 2, 1), (2, 20, 130, 4, 2)])
+def test_fused_loss_matches_oracle(ops, synth, dev, name, shape):
+    B, H, W, n_src, n_scales = shape
+    cfg = CONFIGS[name]
+    d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=n_scales, seed=11, with_masks=True)
+    ref = _oracle(d, cfg, want_d_src=True)
+    fl = _bind(ops, dev, d, cfg, want_d_src=True)
+    _check_losses(fl.forward(), ref)
+    fl.backward(1.0)
+    _check_grads(fl, ref, n_src, check_src=True, check_mask=bool(cfg.get("exp_reg")))
+    # the fused launch returns the same loss and the same gradients
+    g_sep = [to_np(t).copy() for t in fl.d_disps] + [to_np(t).copy() for t in fl.d_poses]
+    _check_losses(fl.forward_backward(), ref)
+    g_fused = [to_np(t) for t in fl.d_disps] + [to_np(t) for t in fl.d_poses]
+    for a, b in zip(g_sep, g_fused):   # two instantiations of one template: same math, ulp-level differences
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-5 * np.abs(a).max())
+
+
+def test_upstream_gradient_scales_linearly(ops, synth, dev):
+    cfg = CONFIGS["ssim_smooth"]
+    d = synth.make_inputs(B=2, H=32, W=48, n_src=2, n_scales=2, seed=5)
+    fl = _bind(ops, dev, d, cfg)
+    fl.backward(1.0)
+    g1 = [to_np(t).copy() for t in fl.d_disps + fl.d_poses]
+    fl.backward(-2.5)
+    g2 = [to_np(t) for t in fl.d_disps + fl.d_poses]
+    for a, b in zip(g1, g2):
+        np.testing.assert_allclose(b, -2.5 * a, rtol=0, atol=2e-5 * np.abs(a).max())
+
+
+def test_batch_shard_is_additive(ops, synth, dev):
+    """norm_B = global batch: the shard losses add up to the full-batch loss and the
+    per-sample gradients are those of the full batch."""
+    cfg = CONFIGS["ssim_smooth"]
+    d = synth.make_inputs(B=4, H=32, W=48, n_src=2, n_scales=2, seed=9)
+    full = _bind(ops, dev, d, cfg)
+    lf = to_np(full.forward_backward()).astype(np.float64)
+    tot = np.zeros(5)
+    for lo in (0, 2):
+        sl = slice(lo, lo + 2)
+        part = dict(d, tgt_pyr=[a[sl] for a in d["tgt_pyr"]], src_pyr=[a[sl] for a in d["src_pyr"]],
+                    intrinsics=d["intrinsics"][sl], disps=[a[sl] for a in d["disps"]],
+                    poses=[a[sl] for a in d["poses"]])
+        sh = _bind(ops, dev, part, cfg, norm_B=4)
+        tot += to_np(sh.forward_backward()).astype(np.float64)
+        for s in range(2):
+            np.testing.assert_allclose(to_np(sh.d_disps[s]), to_np(full.d_disps[s])[sl], rtol=1e-5, atol=1e-10)
+        for i in range(2):
+            np.testing.assert_allclose(to_np(sh.d_poses[i]), to_np(full.d_poses[i])[sl], rtol=1e-5, atol=1e-10)
+    np.testing.assert_allclose(tot, lf, rtol=1e-5)
+
+
+@pytest.mark.parametrize("cfg_name,B,H,W,n_src", [("l1_smooth", 8, 128, 416, 2), ("ssim_smooth", 4, 128, 416, 2)])
+def test_baseline_configs_vs_oracle(ops, synth, dev, cfg_name, B, H, W, n_src):
+    """BASELINE.json cfg2 (B=8, L1 + smoothness) and cfg3's loss mode at a batch the oracle
+    finishes in seconds, full 128x416 resolution, 4 scales."""
+    cfg = CONFIGS[cfg_name]
+    d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=4, seed=1)
+    ref = _oracle(d, cfg)
+    fl = _bind(ops, dev, d, cfg)
+    _check_losses(fl.forward(), ref)
+    _check_losses(fl.forward_backward(), ref)
+    _check_grads(fl, ref, n_src)
+
+
+def test_full_size_properties(ops, synth, dev):
+    """cfg3 at full size (B=32): size-independent properties instead of an oracle run --
+    determinism (bitwise), fused == separate, finite outputs, and loss(identical images) == 0."""
+    import torch
+    cfg = CONFIGS["ssim_smooth"]
+    d = synth.make_inputs(B=32, H=128, W=416, n_src=2, n_scales=4, seed=1)
+    fl = _bind(ops, dev, d, cfg)
+    l1 = to_np(fl.forward_backward()).copy()
+    g1 = [to_np(t).copy() for t in fl.d_disps + fl.d_poses]
+    l2 = to_np(fl.forward_backward()).copy()
+    g2 = [to_np(t) for t in fl.d_disps + fl.d_poses]
+    np.testing.assert_array_equal(l1, l2)
+    for a, b in zip(g1, g2):
+        np.testing.assert_array_equal(a, b)
+        assert np.isfinite(a).all()
+    lf = to_np(fl.forward())
+    np.testing.assert_allclose(lf, l1, rtol=2e-5)
+    torch.cuda.synchronize()
+
+
+def test_identity_pose_identical_images_give_zero_photometric_loss(ops, synth, dev):
+    """pose = 0 => I^ = src inside a 1-px zero frame; with
+    src == tgt the L1 and SSIM terms vanish on the interior and the frame is masked out."""
+    d = synth.make_inputs(B=2, H=32, W=64, n_src=2, n_scales=2, seed=3)
+    # power-of-two intrinsics make K . K^-1 exact
+    K = np.zeros((2, 3, 3), np.float32)
+    K[:, 0, 0] = 64.0
+    K[:, 1, 1] = 32.0
+    K[:, 0, 2] = 32.0
+    K[:, 1, 2] = 16.0
+    K[:, 2, 2] = 1.0
+    d["intrinsics"] = synth.multi_scale_intrinsics(K, 2)
+    d["poses"] = [np.zeros((2, 6), np.float32) for _ in range(2)]
+    d["src_pyr"] = [np.concatenate([t, t], axis=1) for t in d["tgt_pyr"]]
+    fl = _bind(ops, dev, d, dict(ssim_rate=0.15))
+    loss = to_np(fl.forward())
+    assert abs(loss[1]) < 2e-6          # pixel: exact 0 up to the fp32 rounding of U = q0/z
+    # SSIM is NOT zero next to the zero frame (unmasked zeros enter the 3x3 windows), but must match the oracle
+    ref = O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], ssim_rate=0.15)
+    assert abs(loss[4] - ref["ssim_loss"]) <= 1e-4 * max(ref["ssim_loss"], 1e-6)
+
+
+def test_argument_errors(ops, synth, dev):
+    d = synth.make_inputs(B=1, H=16, W=24, n_src=2, n_scales=1, seed=3)
+    with pytest.raises(ValueError):
+        ops.FusedLoss(smooth_mode="bogus")
+    with pytest.raises(ValueError):          # exp_reg without masks
+        _bind(ops, dev, d, dict(exp_reg=0.2))
+    with pytest.raises(TypeError):           # CPU tensors are rejected, no fallback
+        import torch
+        ops.FusedLoss().bind([torch.from_numpy(a) for a in d["tgt_pyr"]], [torch.from_numpy(a) for a in d["src_pyr"]],
+                             torch.from_numpy(d["intrinsics"]), [torch.from_numpy(a) for a in d["disps"]],
+                             [torch.from_numpy(a) for a in d["poses"]])
+    tiny = synth.make_inputs(B=1, H=16, W=24, n_src=1, n_scales=4, seed=3)   # smallest scale 2x3 < 3
+    with pytest.raises((TypeError, ValueError)):
+        _bind(ops, dev, tiny, dict())

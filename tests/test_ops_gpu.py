@@ -1,0 +1,153 @@
+"""GPU parity of the operator-level entry points of the C ABI against (a) the golden vectors
+produced by the reference's own code and (b) the CPU oracle."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import sfm_oracle as O
+from util import assert_close_masked, to_dev, to_np
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "interp_sampler_*.npz"))))
+def test_interp_sampler_matches_reference_golden_bit_exact(ops, dev, path):
+    """SpatialTransformerSamplerInterp._forward/_backward
+    (models/spational_transformer_sampler_interp.py:32-149) -- outputs of the reference's code."""
+    z = np.load(path)
+    x, grid, gy = (to_dev(z[k], dev) for k in ("x", "grid", "gy"))
+    y = to_np(ops.interp_fwd(x, grid))
+    gx, ggrid = ops.interp_bwd(x, grid, gy)
+    np.testing.assert_array_equal(y, z["y"])
+    np.testing.assert_array_equal(to_np(ggrid), z["ggrid"])
+    np.testing.assert_array_equal(to_np(gx), z["gx"])          # == 0 (:148)
+
+
+def test_pose_proj_matches_oracle_and_odom_util_golden(ops, dev):
+    z = np.load(os.path.join(GOLD, "euler_odom_util.npz"))
+    r = z["r_xyz"].astype(np.float32)
+    N = r.shape[0]
+    rng = np.random.RandomState(0)
+    pose = np.concatenate([r, rng.normal(0, 0.1, size=(N, 3)).astype(np.float32)], axis=1)
+    K = np.tile(np.eye(3, dtype=np.float32), (N, 1, 1))
+    proj = to_np(ops.pose_proj_fwd(to_dev(pose, dev), to_dev(K, dev)))
+    # with K = I the upper-left 3x3 is euler2mat: compare with kitti_eval/odom_util.py:167-200
+    np.testing.assert_allclose(proj[:, :3, :3], z["R"], atol=5e-7)
+    np.testing.assert_allclose(proj[:, :3, 3], pose[:, 3:], atol=0)
+    np.testing.assert_array_equal(proj[:, 3], np.tile(np.array([0, 0, 0, 1], np.float32), (N, 1)))
+    K = np.tile(np.array([[241.7, 0, 204.2], [0, 246.3, 59.0], [0, 0, 1]], np.float32), (N, 1, 1))
+    K[:, 0, 1] = rng.normal(0, 0.5, N)       # general (skewed) K
+    proj = to_np(ops.pose_proj_fwd(to_dev(pose, dev), to_dev(K, dev)))
+    want = O.proj_tgt_to_src(pose, K)
+    np.testing.assert_allclose(proj, want, rtol=2e-6, atol=2e-5)
+    g = rng.normal(size=(N, 4, 4)).astype(np.float32)
+    got = to_np(ops.pose_proj_bwd(to_dev(pose, dev), to_dev(K, dev), to_dev(g, dev)))
+    want = O.proj_tgt_to_src_backward(pose.astype(np.float64), K.astype(np.float64), g.astype(np.float64), np.float64)
+    np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-4 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 16, 52), (1, 3, 37, 70), (2, 1, 9, 11), (1, 5, 128, 416), (2, 3, 128, 416)])
+@pytest.mark.parametrize("texture", ["smooth", "noise"])
+def test_projective_inverse_warp_fwd_bwd(ops, synth, dev, shape, texture):
+    """projective_inverse_warp (models/transform.py:156-193): warped pixels to 1e-4 relative
+    on image-like (smooth) sources, outside knife-edge pixels; backward against the oracle's
+    hand-derived one.  On white noise (|dI/dx| ~ 1 per pixel) every fp32 rounding of the
+    sampling coordinate (1 ulp of U ~ 400 px is 3e-5 px) shows up directly in the pixel value, so
+    two fp32 evaluation orders of the same formula agree to ~5e-4 only; that case checks the
+    coordinate error stays at the rounding level."""
+    N, C, H, W = shape
+    d = synth.make_inputs(B=N, H=H, W=W, n_src=2, n_scales=1, seed=4)
+    rng = np.random.RandomState(1)
+    if texture == "noise":
+        imgs = rng.uniform(-1, 1, size=(N, C, H, W)).astype(np.float32)
+        tol = 5e-4
+    else:
+        imgs = np.concatenate([d["tgt"], d["src"].reshape(N, -1, H, W)], axis=1)[:, :C].copy()
+        tol = 1e-4
+    imgs[imgs == 0] = 0.5
+    depth = (1.0 / d["disps"][0]).reshape(N, H * W).astype(np.float32)
+    depthes = np.broadcast_to(depth[:, None], (N, 3, H * W))
+    pose, K = d["poses"][0], d["intrinsics"][:, 0]
+    want, aux = O.projective_inverse_warp(imgs, depthes, pose, K, return_aux=True)
+    knife = (aux["margin"] < 2e-5)[:, None]
+    targs = [to_dev(a, dev) for a in (imgs, depth, pose, K)]
+    got = to_np(ops.warp_fwd(*targs))
+    assert (aux["margin"] < 2e-5).mean() < 1e-3
+    assert_close_masked(got, want, tol, knife, what="warped")
+    # exactly-zero pixels (out of view) agree as a set, away from the knife edge
+    zero_g, zero_w = (got == 0).all(1, keepdims=True), (want == 0).all(1, keepdims=True)
+    assert not ((zero_g != zero_w) & ~knife).any()
+    g = rng.normal(size=(N, C, H, W)).astype(np.float32)
+    w_dep, w_pose, w_src = O.projective_inverse_warp_backward(imgs, depthes, pose, K, g, want_gimgs=True)
+    d_depth, d_pose, d_src = ops.warp_bwd(*targs, to_dev(g, dev), want_d_src=True)
+    assert_close_masked(to_np(d_depth).reshape(N, 1, H, W), w_dep.sum(1).reshape(N, 1, H, W), 10 * tol, knife, what="d_depth")
+    assert_close_masked(to_np(d_pose), w_pose, 1e-3, what="d_pose")
+    err = np.abs(to_np(d_src) - w_src)
+    assert (err > 10 * tol * np.abs(w_src).max()).mean() < 1e-3
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 8, 13, 8, 13), (1, 2, 5, 7, 11, 3), (2, 3, 16, 52, 16, 52)])
+def test_normalized_sampler_fwd_bwd(ops, dev, shape):
+    """F.spatial_transformer_sampler as called at models/transform.py:189, arbitrary grids
+    including the zero-pad ring and far outside."""
+    N, C, H, W, oH, oW = shape
+    rng = np.random.RandomState(2)
+    x = rng.uniform(-1, 1, size=(N, C, H, W)).astype(np.float32)
+    grid = rng.uniform(-1.6, 1.6, size=(N, 2, oH, oW)).astype(np.float32)
+    grid[:, :, 0, 0] = [-1.0, 1.0]
+    gy = rng.normal(size=(N, C, oH, oW)).astype(np.float32)
+    want = O.spatial_transformer_sampler(x, grid)
+    got = to_np(ops.sampler_fwd(to_dev(x, dev), to_dev(grid, dev)))
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+    wgx, wgg = O.spatial_transformer_sampler_backward(x, grid, gy)
+    gx, gg = ops.sampler_bwd(to_dev(x, dev), to_dev(grid, dev), to_dev(gy, dev))
+    np.testing.assert_allclose(to_np(gg), wgg, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(to_np(gx), wgx, rtol=1e-4, atol=1e-5)
+
+
+def test_interp_equals_normalized_sampler_in_range(ops, dev):
+    """SURVEY.md §8(c) pin (4): A8 == A8' on in-range coordinates after normalise -> pixel."""
+    rng = np.random.RandomState(3)
+    N, C, H, W = 2, 3, 12, 20
+    x = rng.uniform(-1, 1, size=(N, C, H, W)).astype(np.float32)
+    u = rng.uniform(0.01, W - 1.01, size=(N, H, W)).astype(np.float32)
+    v = rng.uniform(0.01, H - 1.01, size=(N, H, W)).astype(np.float32)
+    pix = np.stack([u, v], axis=1)
+    nrm = np.stack([u / ((W - 1) / 2.) - 1, v / ((H - 1) / 2.) - 1], axis=1).astype(np.float32)
+    a = to_np(ops.interp_fwd(to_dev(x, dev), to_dev(pix, dev)))
+    b = to_np(ops.sampler_fwd(to_dev(x, dev), to_dev(nrm, dev)))
+    np.testing.assert_allclose(a, b, atol=2e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 128, 416), (1, 6, 37, 70)])
+def test_resize_matches_oracle(ops, dev, shape):
+    rng = np.random.RandomState(4)
+    x = rng.uniform(-1, 1, size=shape).astype(np.float32)
+    H, W = shape[2:]
+    for s in (1, 2, 3):
+        oh, ow = H // 2 ** s, W // 2 ** s
+        want = O.resize_images(x, (oh, ow))
+        got = to_np(ops.resize(to_dev(x, dev), (oh, ow)))
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=2e-6)
+
+
+def test_type_checks(ops, dev):
+    """check_type_forward of the reference (spational_transformer_sampler_interp.py:11-24)."""
+    import torch
+    x = torch.zeros((2, 3, 4, 5), device=dev)
+    with pytest.raises(TypeError):
+        ops.interp_fwd(x, torch.zeros((2, 3, 4, 5), device=dev))        # grid.shape[1] != 2
+    with pytest.raises(TypeError):
+        ops.interp_fwd(x, torch.zeros((1, 2, 4, 5), device=dev))        # batch mismatch
+    with pytest.raises(TypeError):
+        ops.interp_fwd(x.double(), torch.zeros((2, 2, 4, 5), device=dev))
+    with pytest.raises(TypeError):
+        ops.interp_fwd(x.cpu(), torch.zeros((2, 2, 4, 5)))              # no CPU path
+    with pytest.raises(TypeError):
+        ops.warp_fwd(torch.zeros((1, 3, 2, 8), device=dev), torch.ones((1, 16), device=dev),
+                     torch.zeros((1, 6), device=dev), torch.eye(3, device=dev)[None])   # H < 3
+    y = ops.interp_fwd(torch.zeros((0, 3, 4, 5), device=dev), torch.zeros((0, 2, 4, 5), device=dev))
+    assert tuple(y.shape) == (0, 3, 4, 5)                                # empty batch
