@@ -35,7 +35,8 @@ class SfmLossDesc(C.Structure):
     ]
 
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsfmwarp.so")
+# SFMWARP_LIB selects another build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("SFMWARP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsfmwarp.so")
 
 # every symbol declared in include/sfmwarp.h: name -> (restype, argtypes)
 _I, _V, _Z = C.c_int, C.c_void_p, C.c_size_t

@@ -150,13 +150,30 @@ __device__ __forceinline__ void pose_backward(const float* pose6, const float* g
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
+// a / b from r ~= 1/b (v_rcp_f32, 1 ulp) with one residual correction: the result is the
+// correctly rounded quotient except in rare double-rounding cases, at 3 instructions instead
+// of the ~10 of the IEEE division sequence.  Keeps exact quotients exact ((w-1)*D/D == w-1), which
+// is what decides the reference's strict `-1 < x < 1` test (models/transform.py:129) on the
+// image border.
+__device__ __forceinline__ float div_r(float a, float b, float r) {
+  const float q = a * r;
+  const float e = fmaf(-q, b, a);
+  return fmaf(e, r, q);
+}
+// 1 / b, refined the same way
+__device__ __forceinline__ float rcp_refined(float b) {
+  const float r = rcp(b);
+  const float e = fmaf(-b, r, 1.0f);
+  return fmaf(e, r, r);
+}
+
 // lane l receives the value of lane l-1; lane 0 receives 0   (DPP wave_shr:1)
 __device__ __forceinline__ float from_left(float x) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, true));
 }
 // lane l receives the value of lane l+1; lane 63 receives 0  (DPP wave_shl:1)
 __device__ __forceinline__ float from_right(float x) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float hsum3(float x) { return from_left(x) + x + from_right(x); }
 
@@ -194,7 +211,8 @@ struct Proj {
 };
 
 struct ScaleConst {  // per-scale constants derived from (H, W)
-  float inv_half_w, inv_half_h;  // 1 / ((W-1)/2), 1 / ((H-1)/2)
+  float half_w, half_h;          // (W-1)/2, (H-1)/2          (transform.py:124-125)
+  float inv_half_w, inv_half_h;  // their reciprocals
   float wm1, hm1;                // W-1, H-1
 };
 
@@ -202,8 +220,10 @@ __device__ __forceinline__ ScaleConst make_scale_const(int H, int W) {
   ScaleConst s;
   s.wm1 = (float)(W - 1);
   s.hm1 = (float)(H - 1);
-  s.inv_half_w = 1.0f / ((float)(W - 1) * 0.5f);
-  s.inv_half_h = 1.0f / ((float)(H - 1) * 0.5f);
+  s.half_w = (float)(W - 1) * 0.5f;
+  s.half_h = (float)(H - 1) * 0.5f;
+  s.inv_half_w = 1.0f / s.half_w;
+  s.inv_half_h = 1.0f / s.half_h;
   return s;
 }
 
@@ -218,10 +238,10 @@ __device__ __forceinline__ Proj project(const float aray0, const float aray1, co
   const float q2 = fmaf(D, aray2, p23);
   const float z = q2 + 1e-10f;
   o.rz = rcp(z);
-  o.U = q0 * o.rz;
-  o.V = q1 * o.rz;
-  const float xn = fmaf(o.U, sc.inv_half_w, -1.0f);
-  const float yn = fmaf(o.V, sc.inv_half_h, -1.0f);
+  o.U = div_r(q0, z, o.rz);                                     // transform.py:124
+  o.V = div_r(q1, z, o.rz);                                     // transform.py:125
+  const float xn = div_r(o.U, sc.half_w, sc.inv_half_w) - 1.0f;
+  const float yn = div_r(o.V, sc.half_h, sc.inv_half_h) - 1.0f;
   o.inview = (xn > -1.0f) && (xn < 1.0f) && (yn > -1.0f) && (yn < 1.0f);
   // sampler: u_pad = (xn + 1) * (W - 1) / 2 + 1 on the zero-padded image
   const float up = (xn + 1.0f) * sc.wm1 * 0.5f + 1.0f;

@@ -21,6 +21,7 @@
 #include <string.h>
 
 #include "sfm_common.h"
+#include "sfm_ssim_pass.h"
 
 namespace sfm {
 
@@ -268,7 +269,7 @@ __device__ __forceinline__ void source_pass(const LossArgs& A, const ScaleArgs& 
       const int off = r * w + x;
       const float yf = (float)r;
       const float disp = dplane[off];
-      cur.D = rcp(disp);                                             // base_model.py:60
+      cur.D = rcp_refined(disp);                                     // base_model.py:60
 #pragma unroll
       for (int c = 0; c < 3; ++c) cur.it[c] = tplane[c * P + off];
       if (EXPL) {
@@ -525,7 +526,35 @@ __global__ void __launch_bounds__(64) loss_kernel(const LossArgs A) {
     first = false;
   }
   for (int i = 0; i < A.n_src; ++i) {
-    source_pass<SSIM, GRAD, LOSS, EXPL>(A, S, sc, b, i, s, lane, x, xin, outl, y0, y1, gacc, first, acc_pix, acc_ssim, acc_exp, item);
+    if constexpr (SSIM) {
+      SsimCtx C;
+      const Geom* __restrict__ gp = A.geom + ((size_t)(b * A.n_scales + s) * A.n_src + i);
+      const float xf = (float)x;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        C.M1[k] = uniform(gp->M[k * 3 + 1]);
+        C.P3[k] = uniform(gp->P[k * 4 + 3]);
+        C.K1[k] = uniform(gp->Kinv[k * 3 + 1]);
+        C.mx[k] = fmaf(uniform(gp->M[k * 3 + 0]), xf, uniform(gp->M[k * 3 + 2]));
+        C.kx[k] = fmaf(uniform(gp->Kinv[k * 3 + 0]), xf, uniform(gp->Kinv[k * 3 + 2]));
+        C.tp[k] = S.tgt + ((size_t)b * 3 + k) * P;
+        C.sp[k] = S.src + (((size_t)b * A.n_src + i) * 3 + k) * P;
+      }
+      C.k_pix = A.gy * (1.0f - A.alpha) * S.inv_cnt;
+      C.kq = -0.5f * A.gy * A.alpha * S.inv_cnt;
+      C.h = h; C.w = w; C.y0 = y0; C.y1 = y1;
+      C.dp = S.disp + (size_t)b * P;
+      C.dsp = (GRAD && S.d_src) ? S.d_src + ((size_t)b * A.n_src + i) * 3 * P : nullptr;
+      C.P = P;
+      C.sc = sc;
+      C.xc = (unsigned)min(max(x, 0), w - 1);
+      C.xin = xin;
+      C.outf = outl ? 1.f : 0.f;
+      C.lane = lane;
+      ssim_source_pass<GRAD, LOSS>(C, gacc, first, acc_pix, acc_ssim, GRAD ? A.part_gpm + ((size_t)item * A.n_src + i) * 12 : nullptr);
+    } else {
+      source_pass<false, GRAD, LOSS, EXPL>(A, S, sc, b, i, s, lane, x, xin, outl, y0, y1, gacc, first, acc_pix, acc_ssim, acc_exp, item);
+    }
     first = false;
   }
   if (GRAD) {

@@ -1,0 +1,263 @@
+// Photometric pass with SSIM for one (wave, source): the hot loop of the fused loss.
+//
+// Per row r the wave runs a 3-stage software pipeline over a register ring:
+//   A  warp row r      (models/transform.py:156-193): finish the bilinear taps whose gathers were
+//                      issued one step earlier, then issue the gathers of row r+1 and the
+//                      disparity load of row r+2, so that their latency is covered by B and C
+//   B  SSIM at row r-1 (models/base_model.py:126-142) from the separable 3x3 sums
+//                      (horizontal: DPP wave shifts; vertical: ring), and the partials
+//                      a,b,e = kappa * dS/d{mu_x, E[xx], E[xy]}
+//   C  gradients at row r-2: transposed 3x3 pool of a,b,e  ->  dL/dI^  ->  dL/d(u,v)  ->
+//                      dL/dq  ->  d_depth (LDS tile, summed over sources) and the 12 sums of dL/dPm
+// The ring is rotated statically (the loop body is instantiated three times), so no register
+// moves are spent on it.
+//
+// SSIM in scaled sums (Sx = 9 mu_x etc.), algebraically models/base_model.py:130-140:
+//   N1 = 2 Sx Sy + 81 c1        N2 = 18 Sxy - 2 Sx Sy + 81 c2
+//   D1 = Sx^2 + Sy^2 + 81 c1    D2 = 9 (Sxx + Syy) - (Sx^2 + Sy^2) + 81 c2      SSIM = N1 N2 / (D1 D2)
+#pragma once
+#include "sfm_common.h"
+
+namespace sfm {
+
+struct SsimCtx {
+  // uniform (SGPR)
+  float M1[3], P3[3], K1[3];
+  float k_pix;   // dL/d(sum |e|)        = gy (1-alpha) / (norm_B 3 h w)   base_model.py:111,117
+  float kq;      // -1/2 dL/d(sum ssim)  = -gy alpha / (2 norm_B 3 h w)    base_model.py:115,117,142
+  int h, w, y0, y1;
+  const float* tp[3];   // target planes of this sample
+  const float* sp[3];   // source planes of this (sample, source)
+  const float* dp;      // disparity plane
+  float* dsp;           // d_src planes of this (sample, source) or nullptr
+  size_t P;
+  ScaleConst sc;
+  // per lane
+  float mx[3], kx[3];   // M[k][0] x + M[k][2],  Kinv[j][0] x + Kinv[j][2]
+  unsigned xc;          // column, clamped into the image (address-safe for halo lanes)
+  bool xin;             // column inside the image
+  float outf;           // 1 for an output lane, else 0
+  int lane;
+};
+
+struct RowS {            // a warped row as the later stages need it (per lane = per pixel)
+  float ih[3], it[3];    // I^ (0 where not in view / outside the image), I (0 outside the image)
+  float du[3], dv[3];    // dI^/du, dI^/dv, pre-multiplied by 1/z (0 where not in view)
+  float U, V, D;         // q0/z, q1/z, depth
+  float nm;              // 1 - mask, mask = all three channels of I^ exactly 0   base_model.py:96
+};
+struct RowH { float x[3], xx[3], xy[3], y[3], yy[3]; };   // horizontal 3-sums of I^, I^2, I^ I, I, I^2
+struct RowG { float a[3], b[3], e[3]; };                  // horizontal 3-sums of the SSIM partials
+
+struct Pipe {            // a row whose gathers are in flight
+  Tap2 t[3], b[3];
+  float it[3];
+  float fu, fv, U, V, rz, D;
+  bool inview;
+};
+
+__device__ __forceinline__ void zero(RowS& s) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) s.ih[c] = s.it[c] = s.du[c] = s.dv[c] = 0.f;
+  s.U = s.V = s.D = s.nm = 0.f;
+}
+__device__ __forceinline__ void zero(RowH& s) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) s.x[c] = s.xx[c] = s.xy[c] = s.y[c] = s.yy[c] = 0.f;
+}
+__device__ __forceinline__ void zero(RowG& s) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) s.a[c] = s.b[c] = s.e[c] = 0.f;
+}
+
+// stage A, first half: project row r and issue its loads (row r is inside the image)
+__device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const float disp, Pipe& ps) {
+  const float yf = (float)r;
+  ps.D = rcp_refined(disp);                                         // base_model.py:60
+  const float a0 = fmaf(C.M1[0], yf, C.mx[0]), a1 = fmaf(C.M1[1], yf, C.mx[1]), a2 = fmaf(C.M1[2], yf, C.mx[2]);
+  const Proj p = project(a0, a1, a2, C.P3[0], C.P3[1], C.P3[2], ps.D, C.sc, C.h, C.w);
+  ps.U = p.U; ps.V = p.V; ps.rz = p.rz; ps.fu = p.fu; ps.fv = p.fv;
+  ps.inview = p.inview && C.xin;
+  const unsigned off = (unsigned)(p.v0 * C.w + p.u0);
+  const unsigned offt = (unsigned)r * (unsigned)C.w + C.xc;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    ps.t[c] = load_tap2(C.sp[c] + off);
+    ps.b[c] = load_tap2(C.sp[c] + off + (unsigned)C.w);
+    ps.it[c] = C.tp[c][offt];
+  }
+}
+
+// stage A, second half: bilinear value and derivatives from the gathered taps
+__device__ __forceinline__ void finish_row(const SsimCtx& C, const Pipe& ps, RowS& s) {
+  const float rzi = ps.inview ? ps.rz : 0.f;
+  unsigned nz = 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float dxt = ps.t[c].b - ps.t[c].a, dxb = ps.b[c].b - ps.b[c].a;
+    const float top = fmaf(ps.fu, dxt, ps.t[c].a);
+    const float bot = fmaf(ps.fu, dxb, ps.b[c].a);
+    const float dvv = bot - top;
+    const float val = ps.inview ? fmaf(ps.fv, dvv, top) : 0.f;
+    s.ih[c] = val;
+    s.dv[c] = dvv * rzi;
+    s.du[c] = fmaf(ps.fv, dxb - dxt, dxt) * rzi;
+    s.it[c] = C.xin ? ps.it[c] : 0.f;
+    nz |= __float_as_uint(val);
+  }
+  s.U = ps.U; s.V = ps.V; s.D = ps.D;
+  s.nm = ((nz << 1) != 0u) ? 1.f : 0.f;                             // base_model.py:96 (+-0 both count as 0)
+}
+
+template <bool GRAD, bool LOSS>
+__device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const int r, const int rend, Pipe& ps, float& disp_next,
+                                              RowS& s0, const RowS& s1, const RowS& s2, RowH& h0, const RowH& h1, const RowH& h2,
+                                              RowG& g0, const RowG& g1, const RowG& g2, float* gacc, const bool first,
+                                              float& acc_pix, float& acc_ssim, float* gpm) {
+  const int h = C.h, w = C.w;
+  // ---------------- A: finish row r, put row r+1 in flight ----------------
+  if (r >= 0 && r < h) finish_row(C, ps, s0);
+  else zero(s0);
+  const int rn = r + 1, rnn = r + 2;
+  if (rn < rend && rn >= 0 && rn < h) issue_row(C, rn, disp_next, ps);
+  if (rnn < rend && rnn >= 0 && rnn < h) disp_next = C.dp[(unsigned)rnn * (unsigned)w + C.xc];
+
+  // horizontal 3-sums of row r
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    h0.x[c] = hsum3(s0.ih[c]);
+    h0.xx[c] = hsum3(s0.ih[c] * s0.ih[c]);
+    h0.xy[c] = hsum3(s0.ih[c] * s0.it[c]);
+    h0.y[c] = hsum3(s0.it[c]);
+    h0.yy[c] = hsum3(s0.it[c] * s0.it[c]);
+  }
+
+  // ---------------- B: SSIM at row r-1 ----------------
+  const int rb = r - 1;
+  const float C1 = 81.f * 0.0001f, C2 = 81.f * 0.0009f;             // 81 c1, 81 c2   base_model.py:127-128
+  float ssum = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float Sx = h2.x[c] + h1.x[c] + h0.x[c];
+    const float Sy = h2.y[c] + h1.y[c] + h0.y[c];
+    const float Sxx = h2.xx[c] + h1.xx[c] + h0.xx[c];
+    const float Syy = h2.yy[c] + h1.yy[c] + h0.yy[c];
+    const float Sxy = h2.xy[c] + h1.xy[c] + h0.xy[c];
+    const float pxy = Sx * Sy;
+    const float sq = fmaf(Sx, Sx, Sy * Sy);
+    const float N1 = fmaf(2.f, pxy, C1);
+    const float N2 = fmaf(-2.f, pxy, fmaf(18.f, Sxy, C2));
+    const float D1 = sq + C1;
+    const float D2 = fmaf(9.f, Sxx + Syy, C2) - sq;
+    const float rD = rcp(D1 * D2);
+    const float Sv = N1 * N2 * rD;                                  // base_model.py:140
+    const float e = fmaf(-0.5f, Sv, 0.5f);                          // (1 - SSIM) / 2, base_model.py:142
+    if (LOSS) ssum += fminf(fmaxf(e, 0.f), 1.f);
+    if (GRAD) {
+      // kappa = dL/dS at this pixel; s1.nm is 0 outside the image and on masked pixels (base_model.py:114)
+      const float kap = (e > 0.f && e < 1.f) ? C.kq * s1.nm * rD : 0.f;      // F.clip backward
+      const float u3 = fmaf(-(Sv * Sx), D2 - D1, Sy * (N2 - N1));
+      g0.a[c] = hsum3(2.f * kap * u3);              // (1/9) kappa dS/dmu_x
+      g0.b[c] = hsum3(-9.f * kap * Sv * D1);        // (1/9) kappa dS/dE[xx]
+      g0.e[c] = hsum3(18.f * kap * N1);             // (1/9) kappa dS/dE[xy]
+    }
+  }
+  if (LOSS) {
+    if (rb >= C.y0 && rb < C.y1) {
+      const float wgt = s1.nm * C.outf;
+      acc_ssim = fmaf(ssum, wgt, acc_ssim);                          // base_model.py:114-115
+      const float e1 = fabsf(s1.ih[0] - s1.it[0]) + fabsf(s1.ih[1] - s1.it[1]) + fabsf(s1.ih[2] - s1.it[2]);   // :95
+      acc_pix = fmaf(e1, wgt, acc_pix);                              // :98-100,:111
+    }
+  }
+
+  // ---------------- C: gradients at row r-2 ----------------
+  if (GRAD) {
+    const int rc = r - 2;
+    if (rc >= C.y0 && rc < C.y1) {
+      const float kpn = C.k_pix * s2.nm;
+      float gq0 = 0.f, gq1 = 0.f;
+      float gI[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float Aq = g2.a[c] + g1.a[c] + g0.a[c];
+        const float Bq = g2.b[c] + g1.b[c] + g0.b[c];
+        const float Eq = g2.e[c] + g1.e[c] + g0.e[c];
+        const float d = s2.ih[c] - s2.it[c];
+        // F.absolute backward: kpn * sign(d), sign(0) = 0 (kpn carries the sign of the upstream gradient)
+        const float sg = (d != 0.f) ? __uint_as_float(__float_as_uint(kpn) ^ (__float_as_uint(d) & 0x80000000u)) : 0.f;
+        const float g = fmaf(s2.it[c], Eq, fmaf(2.f * s2.ih[c], Bq, Aq)) + sg;
+        gI[c] = g;
+        gq0 = fmaf(g, s2.du[c], gq0);
+        gq1 = fmaf(g, s2.dv[c], gq1);
+      }
+      gq0 *= C.outf;
+      gq1 *= C.outf;
+      const float gq2 = -fmaf(gq0, s2.U, gq1 * s2.V);
+      const float yf = (float)rc;
+      const float a0 = fmaf(C.M1[0], yf, C.mx[0]), a1 = fmaf(C.M1[1], yf, C.mx[1]), a2 = fmaf(C.M1[2], yf, C.mx[2]);
+      const float gD = fmaf(gq0, a0, fmaf(gq1, a1, gq2 * a2));
+      const float gdisp = -gD * s2.D * s2.D;                         // d(1/d) = -1/d^2, base_model.py:60
+      float* ga = gacc + (rc - C.y0) * 64 + C.lane;
+      *ga = first ? gdisp : (*ga + gdisp);
+      const float cc0 = s2.D * fmaf(C.K1[0], yf, C.kx[0]);
+      const float cc1 = s2.D * fmaf(C.K1[1], yf, C.kx[1]);
+      const float cc2 = s2.D * fmaf(C.K1[2], yf, C.kx[2]);
+      gpm[0] = fmaf(gq0, cc0, gpm[0]); gpm[1] = fmaf(gq0, cc1, gpm[1]); gpm[2] = fmaf(gq0, cc2, gpm[2]); gpm[3] += gq0;
+      gpm[4] = fmaf(gq1, cc0, gpm[4]); gpm[5] = fmaf(gq1, cc1, gpm[5]); gpm[6] = fmaf(gq1, cc2, gpm[6]); gpm[7] += gq1;
+      gpm[8] = fmaf(gq2, cc0, gpm[8]); gpm[9] = fmaf(gq2, cc1, gpm[9]); gpm[10] = fmaf(gq2, cc2, gpm[10]); gpm[11] += gq2;
+      if (C.dsp != nullptr) {   // optional dL/d(src): scatter of dL/dI^ over the four taps (uniform branch)
+        const Proj p = project(a0, a1, a2, C.P3[0], C.P3[1], C.P3[2], s2.D, C.sc, h, w);
+        if (p.inview && C.outf != 0.f) {
+          float* ds = C.dsp + (unsigned)(p.v0 * w + p.u0);
+          const float w00 = (1.f - p.fu) * (1.f - p.fv), w01 = p.fu * (1.f - p.fv), w10 = (1.f - p.fu) * p.fv, w11 = p.fu * p.fv;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            atomicAdd(ds + c * C.P, gI[c] * w00);
+            atomicAdd(ds + c * C.P + 1, gI[c] * w01);
+            atomicAdd(ds + c * C.P + w, gI[c] * w10);
+            atomicAdd(ds + c * C.P + w + 1, gI[c] * w11);
+          }
+        }
+      }
+    }
+  }
+}
+
+// One source of one wave.  HS = halo of this pass (2 with gradients, 1 forward only).
+template <bool GRAD, bool LOSS>
+__device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, const bool first, float& acc_pix, float& acc_ssim,
+                                                 float* gpm_out /* 12 floats in global memory, or nullptr */) {
+  constexpr int HS = GRAD ? 2 : 1;
+  const int rbeg = C.y0 - HS, rend = C.y1 + HS;
+  float gpm[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) gpm[k] = 0.f;
+  RowS S0, S1, S2;
+  RowH H0, H1, H2;
+  RowG G0, G1, G2;
+  zero(S0); zero(S1); zero(S2);
+  zero(H0); zero(H1); zero(H2);
+  zero(G0); zero(G1); zero(G2);
+  Pipe ps;
+  float disp_next = 1.f;
+  // prologue: row rbeg in flight, disparity of row rbeg+1 loaded
+  if (rbeg >= 0 && rbeg < C.h) issue_row(C, rbeg, C.dp[(unsigned)rbeg * (unsigned)C.w + C.xc], ps);
+  if (rbeg + 1 >= 0 && rbeg + 1 < C.h) disp_next = C.dp[(unsigned)(rbeg + 1) * (unsigned)C.w + C.xc];
+  for (int r = rbeg; r < rend; r += 3) {
+    ssim_row_step<GRAD, LOSS>(C, r, rend, ps, disp_next, S0, S2, S1, H0, H2, H1, G0, G2, G1, gacc, first, acc_pix, acc_ssim, gpm);
+    if (r + 1 < rend)
+      ssim_row_step<GRAD, LOSS>(C, r + 1, rend, ps, disp_next, S1, S0, S2, H1, H0, H2, G1, G0, G2, gacc, first, acc_pix, acc_ssim, gpm);
+    if (r + 2 < rend)
+      ssim_row_step<GRAD, LOSS>(C, r + 2, rend, ps, disp_next, S2, S1, S0, H2, H1, H0, G2, G1, G0, gacc, first, acc_pix, acc_ssim, gpm);
+  }
+  if (GRAD) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      const float v = wave_sum(gpm[k]);
+      if (C.lane == 0) gpm_out[k] = v;
+    }
+  }
+}
+
+}  // namespace sfm

@@ -42,11 +42,16 @@ def _check_losses(loss5, ref):
         assert abs(got[k] - want) <= LOSS_RTOL * max(abs(want), 1e-6), (name, got[k], want)
 
 
-def _knife(ref, s, n_src, thr=2e-5):
-    """pixels of scale s whose projection into ANY source is within thr of the |x|=1 boundary,
-    dilated by the 5x5 footprint of the SSIM backward"""
-    m = (ref["margin"][s] < thr).any(axis=1)          # (B,h,w)
-    assert m.mean() < 1e-3, "too many knife-edge pixels (%g): the exclusion would hide real errors" % m.mean()
+def _knife(ref, s, n_src, thr=2e-5, cell_thr=3e-4, abs_thr=2e-5):
+    """pixels of scale s whose projection into ANY source is within thr of the |x|=1 decision
+    boundary (models/transform.py:129), or within cell_thr px of a cell boundary of the bilinear
+    lattice (where dI^/du is discontinuous, so a coordinate that differs in its last bits picks
+    another, equally valid, one-sided derivative), or where |I^ - I| < abs_thr in some channel
+    (the kink of F.absolute, models/base_model.py:95: the sign of a difference at rounding level is
+    arbitrary); dilated by the 5x5 footprint of the SSIM backward"""
+    m = (ref["margin"][s] < thr).any(axis=1) | (ref["cell_margin"][s] < cell_thr).any(axis=1) \
+        | (ref["abs_margin"][s] < abs_thr).any(axis=1)   # (B,h,w)
+    assert m.mean() < 2.5e-3 * n_src, "too many knife-edge pixels (%g): the exclusion would hide real errors" % m.mean()
     return dilate(m, 2)[:, None]                      # (B,1,h,w)
 
 
@@ -178,6 +183,9 @@ def test_identity_pose_identical_images_give_zero_photometric_loss(ops, synth, d
     K[:, 2, 2] = 1.0
     d["intrinsics"] = synth.multi_scale_intrinsics(K, 2)
     d["poses"] = [np.zeros((2, 6), np.float32) for _ in range(2)]
+    # a power-of-two depth keeps every product of the projection exact, in the reference's
+    # evaluation order too, so the 1-px frame is decided exactly (not by rounding)
+    d["disps"] = [np.full_like(a, 4.0) for a in d["disps"]]
     d["src_pyr"] = [np.concatenate([t, t], axis=1) for t in d["tgt_pyr"]]
     fl = _bind(ops, dev, d, dict(ssim_rate=0.15))
     loss = to_np(fl.forward())

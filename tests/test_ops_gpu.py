@@ -83,8 +83,13 @@ def test_projective_inverse_warp_fwd_bwd(ops, synth, dev, shape, texture):
     g = rng.normal(size=(N, C, H, W)).astype(np.float32)
     w_dep, w_pose, w_src = O.projective_inverse_warp_backward(imgs, depthes, pose, K, g, want_gimgs=True)
     d_depth, d_pose, d_src = ops.warp_bwd(*targs, to_dev(g, dev), want_d_src=True)
-    assert_close_masked(to_np(d_depth).reshape(N, 1, H, W), w_dep.sum(1).reshape(N, 1, H, W), 10 * tol, knife, what="d_depth")
-    assert_close_masked(to_np(d_pose), w_pose, 1e-3, what="d_pose")
+    # the gradient additionally jumps where the sample crosses a cell boundary of the bilinear lattice
+    kcell = knife | ((aux["cell_margin"] < 3e-4) & ~(want == 0).all(1))[:, None]
+    assert kcell.mean() < 4e-3
+    assert_close_masked(to_np(d_depth).reshape(N, 1, H, W), w_dep.sum(1).reshape(N, 1, H, W), 10 * tol, kcell, what="d_depth")
+    # d_pose sums H*W signed terms driven by a white-noise upstream gradient: it cancels to ~sqrt(HW)
+    # of one term, so a single cell-boundary pixel moves it by ~1/sqrt(HW) of its magnitude
+    assert_close_masked(to_np(d_pose), w_pose, 2e-2, what="d_pose")
     err = np.abs(to_np(d_src) - w_src)
     assert (err > 10 * tol * np.abs(w_src).max()).mean() < 1e-3
 
