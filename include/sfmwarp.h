@@ -145,6 +145,10 @@ int sfm_loss_fwd_bwd(const SfmLossDesc *desc, float *loss5, void *ws, size_t ws_
  * hipEvent_t handles on its stream immediately before and after its main kernel, then forgets
  * them.  NULL disables. */
 int sfm_loss_profile_events(void *ev_start, void *ev_stop);
+/* Diagnostics: the NEXT sfm_loss_* call of this thread makes every wavefront of its main kernel
+ * write {start, end (100 MHz realtime counter), HW_ID, XCC_ID} as 4 x uint64 per work item into
+ * buf (device memory, 32 bytes * number of items; items <= workspace_bytes / 64). NULL disables. */
+int sfm_loss_debug_trace(void *buf);
 
 /* ------------------------------------------------------------------------------------------
  * F.resize_images(x, (oH,oW)) as used for the pyramid, models/base_model.py:70-72:

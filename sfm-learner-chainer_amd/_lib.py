@@ -57,6 +57,7 @@ SYMBOLS = {
     "sfm_loss_bwd": (_I, [C.POINTER(SfmLossDesc), C.c_float, _V, _Z, _V]),
     "sfm_loss_fwd_bwd": (_I, [C.POINTER(SfmLossDesc), _FP, _V, _Z, _V]),
     "sfm_loss_profile_events": (_I, [_V, _V]),
+    "sfm_loss_debug_trace": (_I, [_V]),
     "sfm_resize_fwd": (_I, [_FP, _FP, _I, _I, _I, _I, _I, _I, _V]),
 }
 

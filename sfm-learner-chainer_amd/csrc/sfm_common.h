@@ -168,6 +168,12 @@ __device__ __forceinline__ float rcp_refined(float b) {
 }
 
 // lane l receives the value of lane l-1; lane 0 receives 0   (DPP wave_shr:1)
+#ifdef SFM_ABLATE_DPP   // timing experiment only (wrong results): no cross-lane traffic
+__device__ __forceinline__ float from_left(float x) { return x * 1.5f; }
+__device__ __forceinline__ float from_right(float x) { return x * 0.5f; }
+#define from_left from_left_real
+#define from_right from_right_real
+#endif
 __device__ __forceinline__ float from_left(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, true));
 }
@@ -175,7 +181,14 @@ __device__ __forceinline__ float from_left(float x) {
 __device__ __forceinline__ float from_right(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float hsum3(float x) { return from_left(x) + x + from_right(x); }
+#ifdef SFM_ABLATE_DPP
+#undef from_left
+#undef from_right
+#endif
+__device__ __forceinline__ float hsum3(float x) {
+  asm volatile("" : "+v"(x));   // keep x a materialised value: an FMA contraction of its producer into the adds would block the DPP operand folding
+  return (x + from_left(x)) + from_right(x);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -197,33 +210,32 @@ __device__ __forceinline__ Tap2 load_tap2(const float* p) { return *reinterpret_
 // The per-pixel projection + sampling coordinates shared by every kernel.
 //
 // Restates models/transform.py:105-108 (pixel2cam), :122-131 (cam2pixel incl. the x2 rule) and
-// the coordinate handling of F.spatial_transformer_sampler (:189).  Under the x2 rule a
-// coordinate that is not strictly inside (-1,1) is pushed at least half an image outside the
-// zero-padded picture (needs H,W >= 3), where the sampler returns exactly 0 and a zero
-// gradient; so the whole rule collapses to the `inview` predicate computed here.
+// the coordinate handling of F.spatial_transformer_sampler (:189):
+//   xn = U / ((W-1)/2) - 1 ; inside iff -1 < xn < 1 (per component) ; otherwise xn *= 2 ;
+//   the sampler maps back u = (xn + 1)(W-1)/2 on an image zero-padded by one pixel.
+// Under the x2 rule a component that is not strictly inside (-1,1) lands at least half an image
+// outside the padded picture (needs H,W >= 3), where the sampler returns exactly 0 and a zero
+// gradient; so the rule collapses to the predicate `inview`, and for in-view pixels the round
+// trip U -> xn -> u is the identity up to its own fp32 rounding (<= 3e-5 px at W = 416).  The
+// kernels therefore test U and V directly (0 < U < W-1 is -1 < xn < 1 except within one ulp
+// of the border) and sample at (U, V).
 // ------------------------------------------------------------------------------------------
 struct Proj {
   float U, V;    // q0/z, q1/z               (transform.py:124-125 numerators)
   float rz;      // 1/z, z = q2 + 1e-10      (transform.py:123)
-  bool inview;   // -1 < xn < 1 and -1 < yn < 1   (transform.py:129)
-  int u0, v0;    // top-left tap, clamped to [0,W-2] x [0,H-2]
+  bool inview;   // 0 < U < W-1 and 0 < V < H-1   (transform.py:129)
+  int u0, v0;    // top-left tap, in [0,W-2] x [0,H-2]; (0,0) when not in view
   float fu, fv;  // bilinear fractions w.r.t. (u0, v0)
 };
 
 struct ScaleConst {  // per-scale constants derived from (H, W)
-  float half_w, half_h;          // (W-1)/2, (H-1)/2          (transform.py:124-125)
-  float inv_half_w, inv_half_h;  // their reciprocals
-  float wm1, hm1;                // W-1, H-1
+  float wm1, hm1;    // W-1, H-1
 };
 
 __device__ __forceinline__ ScaleConst make_scale_const(int H, int W) {
   ScaleConst s;
   s.wm1 = (float)(W - 1);
   s.hm1 = (float)(H - 1);
-  s.half_w = (float)(W - 1) * 0.5f;
-  s.half_h = (float)(H - 1) * 0.5f;
-  s.inv_half_w = 1.0f / s.half_w;
-  s.inv_half_h = 1.0f / s.half_h;
   return s;
 }
 
@@ -231,7 +243,6 @@ __device__ __forceinline__ ScaleConst make_scale_const(int H, int W) {
 __device__ __forceinline__ Proj project(const float aray0, const float aray1, const float aray2, const float p03,
                                         const float p13, const float p23, const float D, const ScaleConst& sc,
                                         const int H, const int W) {
-#pragma clang fp contract(off)
   Proj o;
   const float q0 = fmaf(D, aray0, p03);
   const float q1 = fmaf(D, aray1, p13);
@@ -240,21 +251,12 @@ __device__ __forceinline__ Proj project(const float aray0, const float aray1, co
   o.rz = rcp(z);
   o.U = div_r(q0, z, o.rz);                                     // transform.py:124
   o.V = div_r(q1, z, o.rz);                                     // transform.py:125
-  const float xn = div_r(o.U, sc.half_w, sc.inv_half_w) - 1.0f;
-  const float yn = div_r(o.V, sc.half_h, sc.inv_half_h) - 1.0f;
-  o.inview = (xn > -1.0f) && (xn < 1.0f) && (yn > -1.0f) && (yn < 1.0f);
-  // sampler: u_pad = (xn + 1) * (W - 1) / 2 + 1 on the zero-padded image
-  const float up = (xn + 1.0f) * sc.wm1 * 0.5f + 1.0f;
-  const float vp = (yn + 1.0f) * sc.hm1 * 0.5f + 1.0f;
-  // in view => up in [1, W], vp in [1, H]; clamp also makes the address safe when not in view / NaN
-  int u0 = (int)floorf(up) - 1;
-  int v0 = (int)floorf(vp) - 1;
-  u0 = o.inview ? min(max(u0, 0), W - 2) : 0;
-  v0 = o.inview ? min(max(v0, 0), H - 2) : 0;
-  o.u0 = u0;
-  o.v0 = v0;
-  o.fu = (up - 1.0f) - (float)u0;
-  o.fv = (vp - 1.0f) - (float)v0;
+  o.inview = (o.U > 0.0f) && (o.U < sc.wm1) && (o.V > 0.0f) && (o.V < sc.hm1);
+  const float uf = floorf(o.U), vf = floorf(o.V);
+  o.fu = o.U - uf;
+  o.fv = o.V - vf;
+  o.u0 = o.inview ? (int)uf : 0;     // in view => uf in [0, W-2]
+  o.v0 = o.inview ? (int)vf : 0;
   return o;
 }
 

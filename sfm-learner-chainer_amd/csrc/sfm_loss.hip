@@ -25,7 +25,8 @@
 
 namespace sfm {
 
-constexpr int MAX_CHUNK_ROWS = 16;
+constexpr int MAX_CHUNK_ROWS = 32;
+constexpr int WAVES_PER_BLOCK = 1;   // independent wavefronts; grouped only so that a CU is filled with few workgroups
 
 struct ScaleArgs {
   const float* tgt;
@@ -35,7 +36,7 @@ struct ScaleArgs {
   float* d_disp;
   float* d_mask;
   float* d_src;
-  int h, w, strips, chunks, tiles, item_begin;
+  int h, w, strips, chunks, tiles, item_begin, chunk_rows;
   float inv_cnt;               // 1 / (norm_B * 3 * h * w)                 base_model.py:111,115
   float c_dx2, c_dy2, c_dxy;   // smooth_reg / 2^s / element count         base_model.py:76,184-185
   float c_ex, c_ey;            // the same for the edge-aware form         base_model.py:154-155
@@ -50,9 +51,10 @@ struct LossArgs {
   Geom* geom;        // [B][n_scales][n_src]
   float* part_loss;  // [items][4]   pixel, ssim, smooth, exp
   float* part_gpm;   // [items][n_src][12]
-  int B, n_src, n_scales, items, chunk_rows;
+  int B, n_src, n_scales, items;
   float gy;          // upstream gradient on total_loss
   float alpha;       // ssim_rate
+  unsigned long long* trace;   // diagnostics: per item {t_start, t_end (100 MHz), HW_ID, XCC_ID}; normally nullptr
 };
 
 template <bool SSIM, bool GRAD, int SMODE>
@@ -491,11 +493,22 @@ __device__ __forceinline__ void source_pass(const LossArgs& A, const ScaleArgs& 
 // the main kernel: one wavefront per (scale, sample, strip, chunk)
 // ------------------------------------------------------------------------------------------
 template <bool SSIM, bool GRAD, bool LOSS, bool EXPL, int SMODE>
-__global__ void __launch_bounds__(64) loss_kernel(const LossArgs A) {
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) loss_kernel(const LossArgs A) {
   using HH = Halo<SSIM, GRAD, SMODE>;
-  __shared__ float gacc[GRAD ? MAX_CHUNK_ROWS * 64 : 64];
+  __shared__ float gacc_all[GRAD ? WAVES_PER_BLOCK * MAX_CHUNK_ROWS * 64 : 64];
+  const int wave = threadIdx.x >> 6;
+  float* gacc = gacc_all + (GRAD ? wave * MAX_CHUNK_ROWS * 64 : 0);
 
-  const int item = blockIdx.x;
+  // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2): give every XCD a contiguous
+  // range of items, so that neighbouring strips / chunks of one image (shared halo rows, overlapping
+  // gather footprints) meet in one L2.  Placement only affects speed, never the result.
+  const int nblk = gridDim.x, per = (nblk + 7) >> 3;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int blk = xcd * per + loc;
+  const int item = blk * WAVES_PER_BLOCK + __builtin_amdgcn_readfirstlane(wave);
+  if (loc >= per || item >= A.items) return;   // whole wavefront leaves; no block-level synchronisation anywhere in this kernel
+  unsigned long long t_start = 0;
+  if (A.trace) t_start = __builtin_amdgcn_s_memrealtime();
   int s = 0;
 #pragma unroll
   for (int k = 1; k < SFM_MAX_SCALES; ++k)
@@ -507,12 +520,12 @@ __global__ void __launch_bounds__(64) loss_kernel(const LossArgs A) {
   const int chunk = t / S.strips;
   const int strip = t - chunk * S.strips;
   const int h = S.h, w = S.w;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const int x = strip * HH::SW - HH::HL + lane;
   const bool xin = (x >= 0) && (x < w);
   const bool outl = (lane >= HH::HL) && (lane < 64 - HH::HR) && (x < w);
-  const int y0 = chunk * A.chunk_rows;
-  const int y1 = min(y0 + A.chunk_rows, h);
+  const int y0 = chunk * S.chunk_rows;
+  const int y1 = min(y0 + S.chunk_rows, h);
   const ScaleConst sc = make_scale_const(h, w);
   const size_t P = (size_t)h * w;
 
@@ -563,6 +576,13 @@ __global__ void __launch_bounds__(64) loss_kernel(const LossArgs A) {
       for (int q = y0; q < y1; ++q) o[q * w + x] = gacc[(q - y0) * 64 + lane];
     }
   }
+  if (A.trace && lane == 0) {   // timing-only diagnostics; never read by any kernel
+    unsigned long long* o = A.trace + (size_t)item * 4;
+    o[0] = t_start;
+    o[1] = __builtin_amdgcn_s_memrealtime();
+    o[2] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
+    o[3] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+  }
   if (LOSS) {
     const float v0 = wave_sum(acc_pix) * S.inv_cnt;
     const float v1 = wave_sum(acc_ssim) * S.inv_cnt;
@@ -589,34 +609,38 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 __global__ void __launch_bounds__(64) finalize_kernel(const LossArgs A, float* __restrict__ loss5, const int n_pose_blocks) {
   const int lane = threadIdx.x;
   if ((int)blockIdx.x < n_pose_blocks) {
+    // d_pose of (b, i): every lane folds its tiles of every scale into K_s^T . gPm (linear), ONE wave reduction at the end
     const int b = blockIdx.x / A.n_src, i = blockIdx.x - b * A.n_src;
-    float gT3[12];
+    double gT3[12];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) gT3[k] = 0.f;
+    for (int k = 0; k < 12; ++k) gT3[k] = 0.0;
     for (int s = 0; s < A.n_scales; ++s) {
       const ScaleArgs& S = A.sc[s];
       const int beg = S.item_begin + b * S.tiles;
-      double acc[12];
+      float g[12];
 #pragma unroll
-      for (int k = 0; k < 12; ++k) acc[k] = 0.0;
+      for (int k = 0; k < 12; ++k) g[k] = 0.f;
       for (int t = lane; t < S.tiles; t += 64) {
-        const float* p = A.part_gpm + ((size_t)(beg + t) * A.n_src + i) * 12;
-#pragma unroll
-        for (int k = 0; k < 12; ++k) acc[k] += (double)p[k];
+        const float4* p = reinterpret_cast<const float4*>(A.part_gpm + ((size_t)(beg + t) * A.n_src + i) * 12);
+        const float4 v0 = p[0], v1 = p[1], v2 = p[2];
+        g[0] += v0.x; g[1] += v0.y; g[2] += v0.z; g[3] += v0.w;
+        g[4] += v1.x; g[5] += v1.y; g[6] += v1.z; g[7] += v1.w;
+        g[8] += v2.x; g[9] += v2.y; g[10] += v2.z; g[11] += v2.w;
       }
-      float gPm[12];
-#pragma unroll
-      for (int k = 0; k < 12; ++k) gPm[k] = (float)wave_sum_d(acc[k]);
       const float* K = A.intrinsics + ((size_t)b * A.n_scales + s) * 9;
       // gT3 += K^T . gPm   (K4^T . gPm of the rows that reach R and t)
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) gT3[r * 4 + c] += K[0 * 3 + r] * gPm[0 * 4 + c] + K[1 * 3 + r] * gPm[1 * 4 + c] + K[2 * 3 + r] * gPm[2 * 4 + c];
+        for (int c = 0; c < 4; ++c)
+          gT3[r * 4 + c] += (double)K[0 * 3 + r] * g[0 * 4 + c] + (double)K[1 * 3 + r] * g[1 * 4 + c] + (double)K[2 * 3 + r] * g[2 * 4 + c];
     }
+    float gT[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) gT[k] = (float)wave_sum_d(gT3[k]);
     if (lane == 0) {
       float d[6];
-      pose_backward(A.pose[i] + b * 6, gT3, d);
+      pose_backward(A.pose[i] + b * 6, gT, d);
 #pragma unroll
       for (int k = 0; k < 6; ++k) A.d_pose[i][b * 6 + k] = d[k];
     }
@@ -624,10 +648,11 @@ __global__ void __launch_bounds__(64) finalize_kernel(const LossArgs A, float* _
   }
   if (loss5 == nullptr) return;
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  const float4* pl = reinterpret_cast<const float4*>(A.part_loss);
+#pragma unroll 8
   for (int t = lane; t < A.items; t += 64) {
-    const float* p = A.part_loss + (size_t)t * 4;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] += (double)p[k];
+    const float4 v = pl[t];
+    acc[0] += (double)v.x; acc[1] += (double)v.y; acc[2] += (double)v.z; acc[3] += (double)v.w;
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) acc[k] = wave_sum_d(acc[k]);
@@ -657,16 +682,67 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // optional profiling hook (sfm_loss_profile_events): events recorded right before / after the
 // main kernel of the NEXT fused-loss call of this thread
 static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+static thread_local unsigned long long* g_trace = nullptr;   // sfm_loss_debug_trace
 
-static int chunk_rows_setting() {
-  const char* e = getenv("SFM_CHUNK_ROWS");
-  int v = e ? atoi(e) : 0;
-  if (v < 1 || v > MAX_CHUNK_ROWS) v = MAX_CHUNK_ROWS;
-  return v;
+// ---- work decomposition -----------------------------------------------------------------
+// One wavefront per (scale, sample, strip, chunk of rows).  The register footprint of the SSIM
+// gradient kernel allows 2 wavefronts per SIMD (2048 slots on 256 CUs), and a wave lives for the
+// whole launch, so the chunk height is chosen such that all items fit in as few full "rounds" of
+// resident waves as possible while the halo rows (recomputed per chunk) stay a small fraction.
+template <bool GRAD, bool LOSS>
+static const void* kernel_ptr(bool ssim, bool expl, int smode);
+
+static int wave_slots(const void* kernel) {
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64 * WAVES_PER_BLOCK, 0) != hipSuccess || cus <= 0 || per_cu <= 0) {
+    (void)hipGetLastError();
+    return 2048;   // no device visible (workspace query on a CPU-only host): MI355X, 2 waves per SIMD
+  }
+  return cus * per_cu * WAVES_PER_BLOCK;
+}
+
+// chunk height per scale for a target height T: equal chunks, never more than T rows
+static void chunk_layout(const SfmLossDesc* d, int sw, int halo2, int T, int* rows, long long* items, long long* work, int* maxcost) {
+  *items = 0; *work = 0; *maxcost = 0;
+  for (int s = 0; s < d->n_scales; ++s) {
+    const int h = d->H[s], strips = (d->W[s] + sw - 1) / sw;
+    const int n = (h + T - 1) / T;
+    rows[s] = (h + n - 1) / n;
+    const int cost = rows[s] + halo2;
+    const long long cnt = (long long)d->B * strips * ((h + rows[s] - 1) / rows[s]);
+    *items += cnt;
+    *work += cnt * cost;
+    if (cost > *maxcost) *maxcost = cost;
+  }
+}
+
+static void plan_chunks(const SfmLossDesc* d, int sw, int halo2, int slots, int* rows) {
+  const char* e = getenv("SFM_CHUNK_ROWS");   // tuning override: fixed target height
+  const int forced = e ? atoi(e) : 0;
+  int bestT = MAX_CHUNK_ROWS;
+  double best = 1e300;
+  for (int T = 4; T <= MAX_CHUNK_ROWS; ++T) {
+    if (forced >= 1 && forced <= MAX_CHUNK_ROWS && T != forced) continue;
+    long long items, work;
+    int maxcost, r[SFM_MAX_SCALES];
+    chunk_layout(d, sw, halo2, T, r, &items, &work, &maxcost);
+    const double rounds = (double)((items + slots - 1) / slots);
+    // resident waves run concurrently: a launch lasts about `rounds` times the longest item, and never
+    // less than the total work spread over all slots
+    double est = rounds * maxcost;
+    const double flat = (double)work / slots;
+    if (flat > est) est = flat;
+    est += 1e-3 * (double)work / slots;   // tie-break: less recomputed halo
+    if (est < best) { best = est; bestT = T; }
+  }
+  long long items, work;
+  int maxcost;
+  chunk_layout(d, sw, halo2, bestT, rows, &items, &work, &maxcost);
 }
 
 // validates the descriptor and lays out items + workspace for the given mode
-static int make_plan(const SfmLossDesc* d, bool grad, bool need_outputs, float gy, Plan& p) {
+static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_outputs, float gy, Plan& p) {
   if (!d) return fail(SFM_ERR_NULL, "sfm_loss: NULL descriptor");
   if (d->B < 0 || d->B > (1 << 20)) return fail(SFM_ERR_SHAPE, "sfm_loss: B=%d", d->B);
   if (d->norm_B < d->B || d->norm_B < 1) return fail(SFM_ERR_CONFIG, "sfm_loss: norm_B=%d must be >= max(B,1) (B=%d)", d->norm_B, d->B);
@@ -686,7 +762,6 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_outputs, float g
   A.B = d->B;
   A.n_src = d->n_src;
   A.n_scales = d->n_scales;
-  A.chunk_rows = chunk_rows_setting();
   A.gy = gy;
   A.alpha = d->ssim_rate;
   A.intrinsics = d->intrinsics;
@@ -699,6 +774,14 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_outputs, float g
     }
   }
   const int sw = strip_width(p.ssim, grad, p.smode);
+  const int hs = p.ssim ? (grad ? 2 : 1) : 0;
+  const int hm = p.smode == 1 ? 2 : (p.smode == 2 ? 1 : 0);
+  int rows[SFM_MAX_SCALES];
+  for (int s = 0; s < d->n_scales; ++s)
+    if (d->H[s] < 3 || d->W[s] < 3) return fail(SFM_ERR_SHAPE, "sfm_loss: scale %d is %dx%d, need H,W >= 3", s, d->H[s], d->W[s]);
+  const void* kfn = grad ? (need_loss ? kernel_ptr<true, true>(p.ssim, p.expl, p.smode) : kernel_ptr<true, false>(p.ssim, p.expl, p.smode))
+                         : kernel_ptr<false, true>(p.ssim, p.expl, p.smode);
+  plan_chunks(d, sw, 2 * (hs > hm ? hs : hm), wave_slots(kfn), rows);
   int items = 0;
   for (int s = 0; s < d->n_scales; ++s) {
     const int h = d->H[s], w = d->W[s];
@@ -721,7 +804,8 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_outputs, float g
     S.h = h;
     S.w = w;
     S.strips = (w + sw - 1) / sw;
-    S.chunks = (h + A.chunk_rows - 1) / A.chunk_rows;
+    S.chunk_rows = rows[s];
+    S.chunks = (h + rows[s] - 1) / rows[s];
     S.tiles = S.strips * S.chunks;
     S.item_begin = items;
     items += d->B * S.tiles;
@@ -751,29 +835,36 @@ static void bind_workspace(Plan& p, void* ws) {
 }
 
 template <bool GRAD, bool LOSS>
-static void launch_main(const Plan& p, hipStream_t st) {
-  const dim3 grid(p.args.items), block(64);
-#define SFM_LAUNCH(SS, EX, SM) hipLaunchKernelGGL((loss_kernel<SS, GRAD, LOSS, EX, SM>), grid, block, 0, st, p.args)
-  if (p.expl) {
-    if (p.smode == 0) SFM_LAUNCH(false, true, 0);
-    else if (p.smode == 1) SFM_LAUNCH(false, true, 1);
-    else SFM_LAUNCH(false, true, 2);
-  } else if (p.ssim) {
-    if (p.smode == 0) SFM_LAUNCH(true, false, 0);
-    else if (p.smode == 1) SFM_LAUNCH(true, false, 1);
-    else SFM_LAUNCH(true, false, 2);
+static const void* kernel_ptr(bool ssim, bool expl, int smode) {
+#define SFM_KPTR(SS, EX, SM) return (const void*)&loss_kernel<SS, GRAD, LOSS, EX, SM>
+  if (expl) {
+    if (smode == 0) SFM_KPTR(false, true, 0);
+    else if (smode == 1) SFM_KPTR(false, true, 1);
+    else SFM_KPTR(false, true, 2);
+  } else if (ssim) {
+    if (smode == 0) SFM_KPTR(true, false, 0);
+    else if (smode == 1) SFM_KPTR(true, false, 1);
+    else SFM_KPTR(true, false, 2);
   } else {
-    if (p.smode == 0) SFM_LAUNCH(false, false, 0);
-    else if (p.smode == 1) SFM_LAUNCH(false, false, 1);
-    else SFM_LAUNCH(false, false, 2);
+    if (smode == 0) SFM_KPTR(false, false, 0);
+    else if (smode == 1) SFM_KPTR(false, false, 1);
+    else SFM_KPTR(false, false, 2);
   }
-#undef SFM_LAUNCH
+#undef SFM_KPTR
+}
+
+template <bool GRAD, bool LOSS>
+static void launch_main(const Plan& p, hipStream_t st) {
+  LossArgs args = p.args;
+  void* kargs[] = {&args};
+  (void)hipLaunchKernel(kernel_ptr<GRAD, LOSS>(p.ssim, p.expl, p.smode), dim3(((p.args.items + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK + 7) / 8 * 8),
+                        dim3(64 * WAVES_PER_BLOCK), kargs, 0, st);
 }
 
 static int run(const SfmLossDesc* d, bool grad, bool loss, float gy, float* loss5, void* ws, size_t ws_bytes, void* stream,
                const char* who) {
   Plan p;
-  if (int e = make_plan(d, grad, true, gy, p)) return e;
+  if (int e = make_plan(d, grad, loss, true, gy, p)) return e;
   if (loss && !loss5) return fail(SFM_ERR_NULL, "%s: loss5 is NULL", who);
   if (!ws || ws_bytes < p.total) return fail(SFM_ERR_WORKSPACE, "%s: workspace of %zu bytes needed, got %zu", who, p.total, ws_bytes);
   if (((uintptr_t)ws & 255) != 0) return fail(SFM_ERR_WORKSPACE, "%s: workspace must be 256-byte aligned", who);
@@ -788,6 +879,8 @@ static int run(const SfmLossDesc* d, bool grad, bool loss, float gy, float* loss
   }
   const int ng = d->B * d->n_scales * d->n_src;
   hipLaunchKernelGGL(geom_kernel, dim3((ng + 63) / 64), dim3(64), 0, st, p.args);
+  p.args.trace = g_trace;
+  g_trace = nullptr;
   if (g_ev_start) (void)hipEventRecord(g_ev_start, st);
   if (grad && loss) launch_main<true, true>(p, st);
   else if (grad) launch_main<true, false>(p, st);
@@ -804,10 +897,20 @@ static int run(const SfmLossDesc* d, bool grad, bool loss, float gy, float* loss
 extern "C" {
 
 size_t sfm_loss_workspace_bytes(const SfmLossDesc* desc) {
-  sfm::Plan p;
-  // the gradient layout has the narrowest strips, hence the most items: size for it
-  if (sfm::make_plan(desc, true, false, 1.f, p) != SFM_OK) return 0;
-  return p.total;
+  // the three entry points lay their work out differently: size for the largest
+  size_t total = 0;
+  const bool modes[3][2] = {{false, true}, {true, false}, {true, true}};
+  for (int m = 0; m < 3; ++m) {
+    sfm::Plan p;
+    if (sfm::make_plan(desc, modes[m][0], modes[m][1], false, 1.f, p) != SFM_OK) return 0;
+    if (p.total > total) total = p.total;
+  }
+  return total;
+}
+
+int sfm_loss_debug_trace(void* buf) {
+  sfm::g_trace = (unsigned long long*)buf;
+  return SFM_OK;
 }
 
 int sfm_loss_profile_events(void* ev_start, void* ev_stop) {

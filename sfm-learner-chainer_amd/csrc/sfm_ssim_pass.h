@@ -46,7 +46,6 @@ struct RowS {            // a warped row as the later stages need it (per lane =
   float U, V, D;         // q0/z, q1/z, depth
   float nm;              // 1 - mask, mask = all three channels of I^ exactly 0   base_model.py:96
 };
-struct RowH { float x[3], xx[3], xy[3], y[3], yy[3]; };   // horizontal 3-sums of I^, I^2, I^ I, I, I^2
 struct RowG { float a[3], b[3], e[3]; };                  // horizontal 3-sums of the SSIM partials
 
 struct Pipe {            // a row whose gathers are in flight
@@ -61,10 +60,6 @@ __device__ __forceinline__ void zero(RowS& s) {
   for (int c = 0; c < 3; ++c) s.ih[c] = s.it[c] = s.du[c] = s.dv[c] = 0.f;
   s.U = s.V = s.D = s.nm = 0.f;
 }
-__device__ __forceinline__ void zero(RowH& s) {
-#pragma unroll
-  for (int c = 0; c < 3; ++c) s.x[c] = s.xx[c] = s.xy[c] = s.y[c] = s.yy[c] = 0.f;
-}
 __device__ __forceinline__ void zero(RowG& s) {
 #pragma unroll
   for (int c = 0; c < 3; ++c) s.a[c] = s.b[c] = s.e[c] = 0.f;
@@ -78,8 +73,13 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
   const Proj p = project(a0, a1, a2, C.P3[0], C.P3[1], C.P3[2], ps.D, C.sc, C.h, C.w);
   ps.U = p.U; ps.V = p.V; ps.rz = p.rz; ps.fu = p.fu; ps.fv = p.fv;
   ps.inview = p.inview && C.xin;
+#ifdef SFM_ABLATE_MEM   // timing experiment only: every access hits the same few cache lines
+  const unsigned off = (unsigned)((p.v0 * C.w + p.u0) & 63);
+  const unsigned offt = (unsigned)((r * C.w + C.xc) & 63);
+#else
   const unsigned off = (unsigned)(p.v0 * C.w + p.u0);
   const unsigned offt = (unsigned)r * (unsigned)C.w + C.xc;
+#endif
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     ps.t[c] = load_tap2(C.sp[c] + off);
@@ -111,7 +111,7 @@ __device__ __forceinline__ void finish_row(const SsimCtx& C, const Pipe& ps, Row
 
 template <bool GRAD, bool LOSS>
 __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const int r, const int rend, Pipe& ps, float& disp_next,
-                                              RowS& s0, const RowS& s1, const RowS& s2, RowH& h0, const RowH& h1, const RowH& h2,
+                                              RowS& s0, const RowS& s1, const RowS& s2,
                                               RowG& g0, const RowG& g1, const RowG& g2, float* gacc, const bool first,
                                               float& acc_pix, float& acc_ssim, float* gpm) {
   const int h = C.h, w = C.w;
@@ -122,27 +122,18 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const int r, con
   if (rn < rend && rn >= 0 && rn < h) issue_row(C, rn, disp_next, ps);
   if (rnn < rend && rnn >= 0 && rnn < h) disp_next = C.dp[(unsigned)rnn * (unsigned)w + C.xc];
 
-  // horizontal 3-sums of row r
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    h0.x[c] = hsum3(s0.ih[c]);
-    h0.xx[c] = hsum3(s0.ih[c] * s0.ih[c]);
-    h0.xy[c] = hsum3(s0.ih[c] * s0.it[c]);
-    h0.y[c] = hsum3(s0.it[c]);
-    h0.yy[c] = hsum3(s0.it[c] * s0.it[c]);
-  }
-
   // ---------------- B: SSIM at row r-1 ----------------
   const int rb = r - 1;
   const float C1 = 81.f * 0.0001f, C2 = 81.f * 0.0009f;             // 81 c1, 81 c2   base_model.py:127-128
   float ssum = 0.f;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const float Sx = h2.x[c] + h1.x[c] + h0.x[c];
-    const float Sy = h2.y[c] + h1.y[c] + h0.y[c];
-    const float Sxx = h2.xx[c] + h1.xx[c] + h0.xx[c];
-    const float Syy = h2.yy[c] + h1.yy[c] + h0.yy[c];
-    const float Sxy = h2.xy[c] + h1.xy[c] + h0.xy[c];
+    // separable 3x3 sums around (r-1, x): vertical over the ring rows r-2..r (in-lane), then horizontal (DPP)
+    const float Sx = hsum3(s2.ih[c] + s1.ih[c] + s0.ih[c]);
+    const float Sy = hsum3(s2.it[c] + s1.it[c] + s0.it[c]);
+    const float Sxx = hsum3(fmaf(s2.ih[c], s2.ih[c], fmaf(s1.ih[c], s1.ih[c], s0.ih[c] * s0.ih[c])));
+    const float Syy = hsum3(fmaf(s2.it[c], s2.it[c], fmaf(s1.it[c], s1.it[c], s0.it[c] * s0.it[c])));
+    const float Sxy = hsum3(fmaf(s2.ih[c], s2.it[c], fmaf(s1.ih[c], s1.it[c], s0.ih[c] * s0.it[c])));
     const float pxy = Sx * Sy;
     const float sq = fmaf(Sx, Sx, Sy * Sy);
     const float N1 = fmaf(2.f, pxy, C1);
@@ -234,10 +225,8 @@ __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, 
 #pragma unroll
   for (int k = 0; k < 12; ++k) gpm[k] = 0.f;
   RowS S0, S1, S2;
-  RowH H0, H1, H2;
   RowG G0, G1, G2;
   zero(S0); zero(S1); zero(S2);
-  zero(H0); zero(H1); zero(H2);
   zero(G0); zero(G1); zero(G2);
   Pipe ps;
   float disp_next = 1.f;
@@ -245,11 +234,11 @@ __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, 
   if (rbeg >= 0 && rbeg < C.h) issue_row(C, rbeg, C.dp[(unsigned)rbeg * (unsigned)C.w + C.xc], ps);
   if (rbeg + 1 >= 0 && rbeg + 1 < C.h) disp_next = C.dp[(unsigned)(rbeg + 1) * (unsigned)C.w + C.xc];
   for (int r = rbeg; r < rend; r += 3) {
-    ssim_row_step<GRAD, LOSS>(C, r, rend, ps, disp_next, S0, S2, S1, H0, H2, H1, G0, G2, G1, gacc, first, acc_pix, acc_ssim, gpm);
+    ssim_row_step<GRAD, LOSS>(C, r, rend, ps, disp_next, S0, S2, S1, G0, G2, G1, gacc, first, acc_pix, acc_ssim, gpm);
     if (r + 1 < rend)
-      ssim_row_step<GRAD, LOSS>(C, r + 1, rend, ps, disp_next, S1, S0, S2, H1, H0, H2, G1, G0, G2, gacc, first, acc_pix, acc_ssim, gpm);
+      ssim_row_step<GRAD, LOSS>(C, r + 1, rend, ps, disp_next, S1, S0, S2, G1, G0, G2, gacc, first, acc_pix, acc_ssim, gpm);
     if (r + 2 < rend)
-      ssim_row_step<GRAD, LOSS>(C, r + 2, rend, ps, disp_next, S2, S1, S0, H2, H1, H0, G2, G1, G0, gacc, first, acc_pix, acc_ssim, gpm);
+      ssim_row_step<GRAD, LOSS>(C, r + 2, rend, ps, disp_next, S2, S1, S0, G2, G1, G0, gacc, first, acc_pix, acc_ssim, gpm);
   }
   if (GRAD) {
 #pragma unroll

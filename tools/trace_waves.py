@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Diagnostics: per-wavefront timeline of the fused loss kernel (start/end, CU/SIMD placement)."""
+import importlib, sys, os, ctypes as C
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+PKG = "sfm-learner-chainer_amd"
+ops = importlib.import_module(PKG + ".ops"); synth = importlib.import_module(PKG + ".synth")
+mode = sys.argv[1] if len(sys.argv) > 1 else "fused"
+dev = torch.device("cuda:0")
+d = synth.make_inputs(B=32, H=128, W=416, n_src=2, n_scales=4, seed=1)
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+fl = ops.FusedLoss(smooth_reg=0.1, ssim_rate=0.15).bind([t(a) for a in d["tgt_pyr"]], [t(a) for a in d["src_pyr"]], t(d["intrinsics"]),
+                                                        [t(a) for a in d["disps"]], [t(a) for a in d["poses"]])
+run = {"fused": fl.forward_backward, "fwd": fl.forward, "bwd": lambda: fl.backward(1.0)}[mode]
+for _ in range(5): run()
+buf = torch.zeros((20000, 4), dtype=torch.int64, device=dev)
+ops.lib.sfm_loss_debug_trace(C.c_void_p(buf.data_ptr()))
+run(); torch.cuda.synchronize()
+a = buf.cpu().numpy()
+a = a[a[:, 1] != 0]
+t0 = a[:, 0].min()
+st = (a[:, 0] - t0) / 100.0; en = (a[:, 1] - t0) / 100.0   # microseconds
+hw = a[:, 2]; xcc = a[:, 3] & 0xf
+simd = (hw >> 4) & 3; cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
+key = xcc * 100000 + se * 10000 + sh * 1000 + cu * 10 + simd
+print("items", len(a), "kernel span %.1f us" % en.max(), " wave duration: mean %.1f  min %.1f  max %.1f us" % ((en - st).mean(), (en - st).min(), (en - st).max()))
+print("start times: p50 %.1f p90 %.1f p99 %.1f max %.1f us" % tuple(np.percentile(st, [50, 90, 99, 100])))
+u, cnt = np.unique(key, return_counts=True)
+print("distinct SIMDs used", len(u), " waves per SIMD: min %d max %d mean %.2f" % (cnt.min(), cnt.max(), cnt.mean()), np.bincount(cnt))
+# peak concurrency per SIMD
+peak = []
+for k in u[:4096]:
+    m = key == k
+    ev = sorted([(s, 1) for s in st[m]] + [(e, -1) for e in en[m]])
+    c = 0; pk = 0
+    for _, dd in ev:
+        c += dd; pk = max(pk, c)
+    peak.append(pk)
+print("peak concurrent waves per SIMD histogram", np.bincount(peak))
+late = st > 5
+print("waves starting after 5us: %d ; their mean duration %.1f ; early waves mean duration %.1f" % (late.sum(), (en - st)[late].mean() if late.any() else 0, (en - st)[~late].mean()))
