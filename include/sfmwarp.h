@@ -53,19 +53,21 @@ int sfm_pose_proj_bwd(const float *pose6, const float *K, const float *g_proj, f
  * projective_inverse_warp(imgs, depthes, poses, K), models/transform.py:156-193
  * (pixel2cam :94-109, cam2pixel :111-133 incl. the x2 rule :128-131, and the
  * F.spatial_transformer_sampler call :189).
- *   src (N,C,H,W) ; depth (N,H*W) -- ONE row of the reference's (N,3,H*W) broadcast
- *   (models/base_model.py:82-84) ; pose6 (N,6) ; K (N,3,3)  ->  warped (N,C,H,W).
+ *   src (N,C,H,W) ; depth (N,depth_rows,H*W) ; pose6 (N,6) ; K (N,3,3)  ->  warped (N,C,H,W).
+ *   depth_rows = 3: the reference's `depthes` (N,3,H*W), one depth per camera coordinate (:107);
+ *   depth_rows = 1: ONE row of it, for the case the caller knows the three rows are the
+ *   broadcast of models/base_model.py:82-84 (d_depth is then the sum over the three rows).
  * Backward for an upstream gradient g_warped (N,C,H,W):
- *   d_depth (N,H*W)   overwritten; already summed over the 3 broadcast rows
+ *   d_depth (N,depth_rows,H*W) overwritten
  *   d_pose6 (N,6)     overwritten
  *   d_src   (N,C,H,W) or NULL; ACCUMULATED into (zero it first) with float atomics
  *   ws: sfm_warp_bwd_workspace_bytes(N,H,W) bytes of scratch.
  * H, W >= 3 (below that the reference's x2 rule no longer implies zero fill).
  * ---------------------------------------------------------------------------------------- */
-int sfm_warp_fwd(const float *src, const float *depth, const float *pose6, const float *K, float *warped,
-                 int N, int C, int H, int W, void *stream);
+int sfm_warp_fwd(const float *src, const float *depth, int depth_rows, const float *pose6, const float *K,
+                 float *warped, int N, int C, int H, int W, void *stream);
 size_t sfm_warp_bwd_workspace_bytes(int N, int H, int W);
-int sfm_warp_bwd(const float *src, const float *depth, const float *pose6, const float *K,
+int sfm_warp_bwd(const float *src, const float *depth, int depth_rows, const float *pose6, const float *K,
                  const float *g_warped, float *d_depth, float *d_pose6, float *d_src, void *ws,
                  size_t ws_bytes, int N, int C, int H, int W, void *stream);
 

@@ -9,6 +9,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# PyTorch ships its own libamdhip64; libsfmwarp.so must bind to that SAME runtime instance (device
+# pointers, streams and events are shared with torch), so torch has to be loaded first.  Loading
+# /opt/rocm's copy first and torch's afterwards leaves this library without a visible device.
+import torch  # noqa: F401
+
 SFM_MAX_SCALES = 8
 SFM_MAX_SRC = 8
 SFM_ABI_VERSION = 1
@@ -45,9 +50,9 @@ SYMBOLS = {
     "sfm_last_error": (C.c_char_p, []),
     "sfm_pose_proj_fwd": (_I, [_FP, _FP, _FP, _I, _V]),
     "sfm_pose_proj_bwd": (_I, [_FP, _FP, _FP, _FP, _I, _V]),
-    "sfm_warp_fwd": (_I, [_FP, _FP, _FP, _FP, _FP, _I, _I, _I, _I, _V]),
+    "sfm_warp_fwd": (_I, [_FP, _FP, _I, _FP, _FP, _FP, _I, _I, _I, _I, _V]),
     "sfm_warp_bwd_workspace_bytes": (_Z, [_I, _I, _I]),
-    "sfm_warp_bwd": (_I, [_FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _V, _Z, _I, _I, _I, _I, _V]),
+    "sfm_warp_bwd": (_I, [_FP, _FP, _I, _FP, _FP, _FP, _FP, _FP, _FP, _V, _Z, _I, _I, _I, _I, _V]),
     "sfm_sampler_fwd": (_I, [_FP, _FP, _FP, _I, _I, _I, _I, _I, _I, _V]),
     "sfm_sampler_bwd": (_I, [_FP, _FP, _FP, _FP, _FP, _I, _I, _I, _I, _I, _I, _V]),
     "sfm_sampler_interp_fwd": (_I, [_FP, _FP, _FP, _I, _I, _I, _I, _I, _I, _V]),

@@ -239,14 +239,9 @@ __device__ __forceinline__ ScaleConst make_scale_const(int H, int W) {
   return s;
 }
 
-// aray = M . (x, y, 1) ;  q = D * aray + P[:,3]
-__device__ __forceinline__ Proj project(const float aray0, const float aray1, const float aray2, const float p03,
-                                        const float p13, const float p23, const float D, const ScaleConst& sc,
-                                        const int H, const int W) {
+// from q = Pm . (c, 1)   (transform.py:122)
+__device__ __forceinline__ Proj project_q(const float q0, const float q1, const float q2, const ScaleConst& sc) {
   Proj o;
-  const float q0 = fmaf(D, aray0, p03);
-  const float q1 = fmaf(D, aray1, p13);
-  const float q2 = fmaf(D, aray2, p23);
   const float z = q2 + 1e-10f;
   o.rz = rcp(z);
   o.U = div_r(q0, z, o.rz);                                     // transform.py:124
@@ -258,6 +253,14 @@ __device__ __forceinline__ Proj project(const float aray0, const float aray1, co
   o.u0 = o.inview ? (int)uf : 0;     // in view => uf in [0, W-2]
   o.v0 = o.inview ? (int)vf : 0;
   return o;
+}
+
+// one depth per pixel (the reference's (N,3,H*W) broadcast, base_model.py:82-84):
+// aray = M . (x, y, 1) ;  q = D * aray + P[:,3]
+__device__ __forceinline__ Proj project(const float aray0, const float aray1, const float aray2, const float p03,
+                                        const float p13, const float p23, const float D, const ScaleConst& sc,
+                                        const int H, const int W) {
+  return project_q(fmaf(D, aray0, p03), fmaf(D, aray1, p13), fmaf(D, aray2, p23), sc);
 }
 
 }  // namespace sfm

@@ -83,7 +83,7 @@ constexpr int WARP_BLOCK = 256;
 
 __global__ void __launch_bounds__(WARP_BLOCK) warp_fwd_kernel(const float* __restrict__ src, const float* __restrict__ depth,
                                                               const float* __restrict__ pose6, const float* __restrict__ K,
-                                                              float* __restrict__ warped, int C, int H, int W) {
+                                                              float* __restrict__ warped, int C, int H, int W, int drows) {
   __shared__ Geom g;
   const int n = blockIdx.y;
   if (threadIdx.x == 0) make_geom(pose6 + n * 6, K + n * 9, g);
@@ -94,11 +94,22 @@ __global__ void __launch_bounds__(WARP_BLOCK) warp_fwd_kernel(const float* __res
   const int y = j / W, x = j - y * W;
   const float xf = (float)x, yf = (float)y;
   const ScaleConst sc = make_scale_const(H, W);
-  const float D = depth[(size_t)n * P + j];
-  const float a0 = fmaf(g.M[0], xf, fmaf(g.M[1], yf, g.M[2]));
-  const float a1 = fmaf(g.M[3], xf, fmaf(g.M[4], yf, g.M[5]));
-  const float a2 = fmaf(g.M[6], xf, fmaf(g.M[7], yf, g.M[8]));
-  const Proj p = project(a0, a1, a2, g.P[3], g.P[7], g.P[11], D, sc, H, W);
+  Proj p;
+  if (drows == 1) {
+    const float D = depth[(size_t)n * P + j];
+    const float a0 = fmaf(g.M[0], xf, fmaf(g.M[1], yf, g.M[2]));
+    const float a1 = fmaf(g.M[3], xf, fmaf(g.M[4], yf, g.M[5]));
+    const float a2 = fmaf(g.M[6], xf, fmaf(g.M[7], yf, g.M[8]));
+    p = project(a0, a1, a2, g.P[3], g.P[7], g.P[11], D, sc, H, W);
+  } else {   // three independent depth rows: c_j = D_j * (Kinv . pix)_j   (transform.py:105-107)
+    float c[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      c[r] = depth[((size_t)n * 3 + r) * P + j] * fmaf(g.Kinv[r * 3 + 0], xf, fmaf(g.Kinv[r * 3 + 1], yf, g.Kinv[r * 3 + 2]));
+    p = project_q(fmaf(g.P[0], c[0], fmaf(g.P[1], c[1], fmaf(g.P[2], c[2], g.P[3]))),
+                  fmaf(g.P[4], c[0], fmaf(g.P[5], c[1], fmaf(g.P[6], c[2], g.P[7]))),
+                  fmaf(g.P[8], c[0], fmaf(g.P[9], c[1], fmaf(g.P[10], c[2], g.P[11]))), sc);
+  }
   const float* s = src + (size_t)n * C * P + p.v0 * W + p.u0;
   float* o = warped + (size_t)n * C * P + j;
   for (int c = 0; c < C; ++c) {
@@ -119,7 +130,7 @@ __global__ void __launch_bounds__(WARP_BLOCK) warp_bwd_kernel(const float* __res
                                                               const float* __restrict__ pose6, const float* __restrict__ K,
                                                               const float* __restrict__ g_warped, float* __restrict__ d_depth,
                                                               float* __restrict__ d_src, float* __restrict__ part, int C, int H,
-                                                              int W) {
+                                                              int W, int drows) {
   __shared__ Geom g;
   __shared__ float red[WARP_BLOCK / 64][12];
   const int n = blockIdx.y;
@@ -134,11 +145,16 @@ __global__ void __launch_bounds__(WARP_BLOCK) warp_bwd_kernel(const float* __res
     const int y = j / W, x = j - y * W;
     const float xf = (float)x, yf = (float)y;
     const ScaleConst sc = make_scale_const(H, W);
-    const float D = depth[(size_t)n * P + j];
-    const float a0 = fmaf(g.M[0], xf, fmaf(g.M[1], yf, g.M[2]));
-    const float a1 = fmaf(g.M[3], xf, fmaf(g.M[4], yf, g.M[5]));
-    const float a2 = fmaf(g.M[6], xf, fmaf(g.M[7], yf, g.M[8]));
-    const Proj p = project(a0, a1, a2, g.P[3], g.P[7], g.P[11], D, sc, H, W);
+    const float r0 = fmaf(g.Kinv[0], xf, fmaf(g.Kinv[1], yf, g.Kinv[2]));
+    const float r1 = fmaf(g.Kinv[3], xf, fmaf(g.Kinv[4], yf, g.Kinv[5]));
+    const float r2 = fmaf(g.Kinv[6], xf, fmaf(g.Kinv[7], yf, g.Kinv[8]));
+    float Dj[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) Dj[r] = depth[((size_t)n * drows + (drows == 1 ? 0 : r)) * P + j];
+    const float c0 = Dj[0] * r0, c1 = Dj[1] * r1, c2 = Dj[2] * r2;
+    const Proj p = project_q(fmaf(g.P[0], c0, fmaf(g.P[1], c1, fmaf(g.P[2], c2, g.P[3]))),
+                             fmaf(g.P[4], c0, fmaf(g.P[5], c1, fmaf(g.P[6], c2, g.P[7]))),
+                             fmaf(g.P[8], c0, fmaf(g.P[9], c1, fmaf(g.P[10], c2, g.P[11]))), sc);
     float gU = 0.f, gV = 0.f;
     if (p.inview) {
       const size_t base = (size_t)n * C * P + p.v0 * W + p.u0;
@@ -164,11 +180,17 @@ __global__ void __launch_bounds__(WARP_BLOCK) warp_bwd_kernel(const float* __res
     }
     const float gq0 = gU * p.rz, gq1 = gV * p.rz;
     const float gq2 = -(gU * p.U + gV * p.V) * p.rz;
-    d_depth[(size_t)n * P + j] = gq0 * a0 + gq1 * a1 + gq2 * a2;
-    const float r0 = fmaf(g.Kinv[0], xf, fmaf(g.Kinv[1], yf, g.Kinv[2]));
-    const float r1 = fmaf(g.Kinv[3], xf, fmaf(g.Kinv[4], yf, g.Kinv[5]));
-    const float r2 = fmaf(g.Kinv[6], xf, fmaf(g.Kinv[7], yf, g.Kinv[8]));
-    const float c0 = D * r0, c1 = D * r1, c2 = D * r2;
+    // g_c = Pm^T . gq ; g_depthes[j] = g_c[j] * ray[j]   (transform.py:107,122 backward)
+    const float gd0 = (g.P[0] * gq0 + g.P[4] * gq1 + g.P[8] * gq2) * r0;
+    const float gd1 = (g.P[1] * gq0 + g.P[5] * gq1 + g.P[9] * gq2) * r1;
+    const float gd2 = (g.P[2] * gq0 + g.P[6] * gq1 + g.P[10] * gq2) * r2;
+    if (drows == 1) {
+      d_depth[(size_t)n * P + j] = gd0 + gd1 + gd2;     // broadcast_to backward: sum of the three rows
+    } else {
+      d_depth[((size_t)n * 3 + 0) * P + j] = gd0;
+      d_depth[((size_t)n * 3 + 1) * P + j] = gd1;
+      d_depth[((size_t)n * 3 + 2) * P + j] = gd2;
+    }
     acc[0] = gq0 * c0; acc[1] = gq0 * c1; acc[2] = gq0 * c2;  acc[3] = gq0;
     acc[4] = gq1 * c0; acc[5] = gq1 * c1; acc[6] = gq1 * c2;  acc[7] = gq1;
     acc[8] = gq2 * c0; acc[9] = gq2 * c1; acc[10] = gq2 * c2; acc[11] = gq2;
@@ -425,14 +447,15 @@ static int check_warp_shape(const char* who, int N, int C, int H, int W) {
   return SFM_OK;
 }
 
-int sfm_warp_fwd(const float* src, const float* depth, const float* pose6, const float* K, float* warped, int N, int C,
-                 int H, int W, void* stream) {
+int sfm_warp_fwd(const float* src, const float* depth, int depth_rows, const float* pose6, const float* K, float* warped,
+                 int N, int C, int H, int W, void* stream) {
   if (N == 0) return SFM_OK;   // empty batch: nothing to do, pointers may be NULL
   SFM_REQUIRE(src && depth && pose6 && K && warped, SFM_ERR_NULL, "sfm_warp_fwd: NULL pointer");
   if (int e = check_warp_shape("sfm_warp_fwd", N, C, H, W)) return e;
-  if (N == 0) return SFM_OK;
+  SFM_REQUIRE(depth_rows == 1 || depth_rows == 3, SFM_ERR_SHAPE, "sfm_warp_fwd: depth_rows=%d, must be 1 or 3", depth_rows);
   dim3 grid((H * W + WARP_BLOCK - 1) / WARP_BLOCK, N);
-  hipLaunchKernelGGL(warp_fwd_kernel, grid, dim3(WARP_BLOCK), 0, (hipStream_t)stream, src, depth, pose6, K, warped, C, H, W);
+  hipLaunchKernelGGL(warp_fwd_kernel, grid, dim3(WARP_BLOCK), 0, (hipStream_t)stream, src, depth, pose6, K, warped, C, H, W,
+                     depth_rows);
   return check_launch("sfm_warp_fwd");
 }
 
@@ -442,18 +465,18 @@ size_t sfm_warp_bwd_workspace_bytes(int N, int H, int W) {
   return (size_t)N * nblk * 12 * sizeof(float);
 }
 
-int sfm_warp_bwd(const float* src, const float* depth, const float* pose6, const float* K, const float* g_warped,
-                 float* d_depth, float* d_pose6, float* d_src, void* ws, size_t ws_bytes, int N, int C, int H, int W,
-                 void* stream) {
+int sfm_warp_bwd(const float* src, const float* depth, int depth_rows, const float* pose6, const float* K,
+                 const float* g_warped, float* d_depth, float* d_pose6, float* d_src, void* ws, size_t ws_bytes, int N, int C,
+                 int H, int W, void* stream) {
   if (N == 0) return SFM_OK;   // empty batch: nothing to do, pointers may be NULL
   SFM_REQUIRE(src && depth && pose6 && K && g_warped && d_depth && d_pose6, SFM_ERR_NULL, "sfm_warp_bwd: NULL pointer");
   if (int e = check_warp_shape("sfm_warp_bwd", N, C, H, W)) return e;
-  if (N == 0) return SFM_OK;
+  SFM_REQUIRE(depth_rows == 1 || depth_rows == 3, SFM_ERR_SHAPE, "sfm_warp_bwd: depth_rows=%d, must be 1 or 3", depth_rows);
   SFM_REQUIRE(ws && ws_bytes >= sfm_warp_bwd_workspace_bytes(N, H, W), SFM_ERR_WORKSPACE,
               "sfm_warp_bwd: workspace of %zu bytes needed, got %zu", sfm_warp_bwd_workspace_bytes(N, H, W), ws_bytes);
   const int nblk = (H * W + WARP_BLOCK - 1) / WARP_BLOCK;
   hipLaunchKernelGGL(warp_bwd_kernel, dim3(nblk, N), dim3(WARP_BLOCK), 0, (hipStream_t)stream, src, depth, pose6, K, g_warped,
-                     d_depth, d_src, (float*)ws, C, H, W);
+                     d_depth, d_src, (float*)ws, C, H, W, depth_rows);
   hipLaunchKernelGGL(warp_bwd_pose_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, pose6, K, (const float*)ws, d_pose6, nblk);
   return check_launch("sfm_warp_bwd");
 }

@@ -61,35 +61,40 @@ def _warp_args(imgs, depth, pose6, K):
     imgs = _dev(imgs, "imgs", 4)
     N, Cc, H, W = imgs.shape
     depth = _dev(depth, "depth")
-    if depth.numel() != N * H * W:
-        raise TypeError("depth must hold N*H*W values, got shape %s" % (tuple(depth.shape),))
+    if depth.numel() == N * H * W:
+        drows = 1
+    elif depth.numel() == 3 * N * H * W:
+        drows = 3
+    else:
+        raise TypeError("depthes must be (N,3,H*W) or (N,H*W), got shape %s" % (tuple(depth.shape),))
     pose6, K = _dev(pose6, "poses", 2), _dev(K, "K", 3)
     if tuple(pose6.shape) != (N, 6) or tuple(K.shape) != (N, 3, 3):
         raise TypeError("poses must be (N,6) and K (N,3,3) with N=%d" % N)
-    return imgs, depth, pose6, K, N, Cc, H, W
+    return imgs, depth, drows, pose6, K, N, Cc, H, W
 
 
 def warp_fwd(imgs, depth, pose6, K):
-    """projective_inverse_warp forward.  depth: (N,H*W) (one row of the reference's broadcast)."""
-    imgs, depth, pose6, K, N, Cc, H, W = _warp_args(imgs, depth, pose6, K)
+    """projective_inverse_warp forward.  depth: (N,3,H*W) as in the reference, or (N,H*W) = one
+    row of its broadcast (models/base_model.py:82-84)."""
+    imgs, depth, drows, pose6, K, N, Cc, H, W = _warp_args(imgs, depth, pose6, K)
     out = torch.empty_like(imgs)
     with torch.cuda.device(imgs.device):
-        check(lib.sfm_warp_fwd(_p(imgs), _p(depth), _p(pose6), _p(K), _p(out), N, Cc, H, W, _stream()))
+        check(lib.sfm_warp_fwd(_p(imgs), _p(depth), drows, _p(pose6), _p(K), _p(out), N, Cc, H, W, _stream()))
     return out
 
 
 def warp_bwd(imgs, depth, pose6, K, g_warped, want_d_src=False):
-    imgs, depth, pose6, K, N, Cc, H, W = _warp_args(imgs, depth, pose6, K)
+    imgs, depth, drows, pose6, K, N, Cc, H, W = _warp_args(imgs, depth, pose6, K)
     g_warped = _dev(g_warped, "g_warped", 4)
     if g_warped.shape != imgs.shape:
         raise TypeError("g_warped must have the shape of imgs")
-    d_depth = torch.empty((N, H * W), dtype=torch.float32, device=imgs.device)
+    d_depth = torch.empty((N, 3, H * W) if drows == 3 else (N, H * W), dtype=torch.float32, device=imgs.device)
     d_pose = torch.empty((N, 6), dtype=torch.float32, device=imgs.device)
     d_src = torch.zeros_like(imgs) if want_d_src else None
     nbytes = lib.sfm_warp_bwd_workspace_bytes(N, H, W)
     ws = torch.empty((max(nbytes, 4) // 4,), dtype=torch.float32, device=imgs.device)
     with torch.cuda.device(imgs.device):
-        check(lib.sfm_warp_bwd(_p(imgs), _p(depth), _p(pose6), _p(K), _p(g_warped), _p(d_depth), _p(d_pose),
+        check(lib.sfm_warp_bwd(_p(imgs), _p(depth), drows, _p(pose6), _p(K), _p(g_warped), _p(d_depth), _p(d_pose),
                                _p(d_src), _p(ws), nbytes, N, Cc, H, W, _stream()))
     return d_depth, d_pose, d_src
 

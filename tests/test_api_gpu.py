@@ -1,0 +1,128 @@
+"""GPU tests of the drop-in surface: the reference's operators and loss link under their own
+names (Variable in, Variable out, .backward()), against the oracle."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle import sfm_oracle as O
+from util import assert_close_masked, dilate, to_dev, to_np
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+cs = importlib.import_module("sfm-learner-chainer_amd.chainer_surface")
+fn = importlib.import_module("sfm-learner-chainer_amd.functions")
+links = importlib.import_module("sfm-learner-chainer_amd.links")
+
+
+def test_interp_function_call_and_backward_like_the_reference(dev):
+    z = np.load(os.path.join(GOLD, "interp_sampler_small.npz"))
+    x = cs.Variable(to_dev(z["x"], dev))
+    grid = cs.Variable(to_dev(z["grid"], dev))
+    y = fn.spatial_transformer_sampler_interp(x, grid)
+    assert isinstance(y, cs.Variable) and y.creator is not None
+    np.testing.assert_array_equal(to_np(y.data), z["y"])
+    y.grad = to_dev(z["gy"], dev)
+    y.backward()
+    np.testing.assert_array_equal(to_np(grid.grad), z["ggrid"])
+    assert not to_np(x.grad).any()                       # gx == 0 (:148)
+
+
+def test_projective_inverse_warp_function(synth, dev):
+    N, H, W = 2, 32, 52
+    d = synth.make_inputs(B=N, H=H, W=W, n_src=2, n_scales=1, seed=6)
+    imgs = d["src_pyr"][0][:, :3].copy()
+    depth = (1.0 / d["disps"][0]).reshape(N, 1, H * W).astype(np.float32)
+    rng = np.random.RandomState(0)
+    # general case: three DIFFERENT depth rows (the reference's signature allows it, transform.py:98,107)
+    depthes = (np.broadcast_to(depth, (N, 3, H * W)) * (1 + 0.02 * rng.standard_normal((N, 3, 1)))).astype(np.float32)
+    pose, K = d["poses"][0], d["intrinsics"][:, 0]
+    dv, pv = cs.Variable(to_dev(depthes, dev)), cs.Variable(to_dev(pose, dev))
+    out = fn.projective_inverse_warp(to_dev(imgs, dev), dv, pv, to_dev(K, dev))
+    want, aux = O.projective_inverse_warp(imgs, depthes, pose, K, return_aux=True)
+    knife = (aux["margin"] < 2e-5)[:, None]
+    assert_close_masked(to_np(out.data), want, 1e-4, knife, what="warped (3 depth rows)")
+    g = (want - d["tgt_pyr"][0]).astype(np.float32)      # an L2-style upstream gradient
+    out.grad = to_dev(g, dev)
+    out.backward()
+    w_dep, w_pose, _ = O.projective_inverse_warp_backward(imgs, depthes, pose, K, g)
+    kcell = knife | ((aux["cell_margin"] < 3e-4) & ~(want == 0).all(1))[:, None]
+    assert_close_masked(to_np(dv.grad).reshape(N, 3, H, W), w_dep.reshape(N, 3, H, W), 1e-3, kcell, what="g_depthes")
+    assert_close_masked(to_np(pv.grad), w_pose, 2e-3, what="g_poses")
+
+
+def test_proj_tgt_to_src_function(dev):
+    rng = np.random.RandomState(1)
+    vec = rng.normal(0, 0.05, (4, 6)).astype(np.float32)
+    K = np.tile(np.array([[241.7, 0, 204.2], [0, 246.3, 59.0], [0, 0, 1]], np.float32), (4, 1, 1))
+    v = cs.Variable(to_dev(vec, dev))
+    P = fn.proj_tgt_to_src(v, to_dev(K, dev), 4)
+    np.testing.assert_allclose(to_np(P.data), O.proj_tgt_to_src(vec, K), rtol=2e-6, atol=2e-5)
+    g = rng.normal(size=(4, 4, 4)).astype(np.float32)
+    P.grad = to_dev(g, dev)
+    P.backward()
+    want = O.proj_tgt_to_src_backward(vec.astype(np.float64), K.astype(np.float64), g.astype(np.float64), np.float64)
+    np.testing.assert_allclose(to_np(v.grad), want, rtol=0, atol=2e-4 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("config", [
+    {"smooth_reg": 0.1, "exp_reg": 0, "seq_len": 3},                          # experiments/sfm_learner_v1.yml
+    {"smooth_reg": 0.1, "exp_reg": 0, "seq_len": 3, "ssim_rate": 0.15},       # experiments/sfm_learner_v1_ssim.yml
+    {"smooth_reg": 0.1, "exp_reg": 0.2, "seq_len": 5},                        # experiments/sfm_learner_v1_odom.yml
+])
+def test_sfm_learner_loss_link(synth, dev, config):
+    """SFMLearner.__call__ (models/base_model.py:48-124) from the network outputs onwards:
+    the pyramid is built on the device (F.resize_images, :70-72)."""
+    n_src = config["seq_len"] - 1
+    B, H, W, S = 2, 32, 104, 3
+    d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=S, seed=8, with_masks=True)
+    link = links.SFMLearnerLoss(config)
+    disps = [cs.Variable(to_dev(a, dev)) for a in d["disps"]]
+    poses = [cs.Variable(to_dev(a, dev)) for a in d["poses"]]
+    masks = [cs.Variable(to_dev(a, dev)) for a in d["masks"]]
+    K = to_dev(d["intrinsics"], dev)
+    loss = link(to_dev(d["tgt"], dev), to_dev(d["src"], dev), K, K, disps, poses, masks)
+    cfg = dict(smooth_reg=config["smooth_reg"], exp_reg=config["exp_reg"], ssim_rate=config.get("ssim_rate", 0.0))
+    ref = O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], d["masks"], backward=True,
+                     keep_warped=True, **cfg)
+    assert isinstance(loss, cs.Variable) and loss.shape == ()
+    assert abs(float(loss.data) - ref.total_loss) <= 1e-4 * abs(ref.total_loss)
+    rep = cs.get_report()
+    for k in ("total_loss", "pixel_loss", "smooth_loss", "exp_loss", "ssim_loss"):     # :119-123
+        assert abs(float(rep[k]) - ref[k]) <= 1e-4 * max(abs(ref[k]), 1e-6), k
+    loss.backward()
+    for s in range(S):
+        m = (ref["margin"][s] < 2e-5).any(1) | (ref["cell_margin"][s] < 3e-4).any(1) | (ref["abs_margin"][s] < 2e-5).any(1)
+        assert_close_masked(to_np(disps[s].grad), ref.d_disps[s], 2e-3, dilate(m, 2)[:, None], what="disp.grad[%d]" % s)
+    for i in range(n_src):
+        assert_close_masked(to_np(poses[i].grad), ref.d_poses[i], 2e-3, what="pose.grad[%d]" % i)
+    if config["exp_reg"]:
+        for s in range(S):
+            assert_close_masked(to_np(masks[s].grad), ref.d_masks[s], 2e-3, what="mask.grad[%d]" % s)
+    else:
+        assert all(m.grad is None for m in masks)
+
+
+def test_loss_link_without_backprop_and_with_upstream_gradient(synth, dev):
+    d = synth.make_inputs(B=2, H=32, W=52, n_src=2, n_scales=2, seed=2)
+    link = links.SFMLearnerLoss({"smooth_reg": 0.1, "exp_reg": 0, "seq_len": 3, "ssim_rate": 0.15})
+    K = to_dev(d["intrinsics"], dev)
+    args = (to_dev(d["tgt"], dev), to_dev(d["src"], dev), K, K)
+    mk = lambda: ([cs.Variable(to_dev(a, dev)) for a in d["disps"]], [cs.Variable(to_dev(a, dev)) for a in d["poses"]])
+    with cs.no_backprop_mode():                           # models/base_model.py:190-191
+        disps, poses = mk()
+        l0 = link(*args, disps, poses)
+    assert l0.creator is None
+    disps, poses = mk()
+    l1 = link(*args, disps, poses)
+    np.testing.assert_allclose(float(l1.data), float(l0.data), rtol=2e-5)
+    l1.backward()
+    g1 = to_np(disps[0].grad).copy()
+    disps2, poses2 = mk()
+    l2 = link(*args, disps2, poses2)
+    import torch
+    l2.grad = torch.full((), 3.0, device=dev)            # e.g. a loss scale
+    l2.backward()
+    np.testing.assert_allclose(to_np(disps2[0].grad), 3.0 * g1, rtol=1e-6, atol=1e-12)

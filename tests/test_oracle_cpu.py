@@ -1,0 +1,192 @@
+"""CPU tests of the oracle itself: it must reproduce every golden vector produced by the
+reference's own code, satisfy the analytic known-answer cases of SURVEY.md App. A.4, and its
+hand-derived backward must agree with fp64 central differences."""
+import glob
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle import sfm_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+synth = importlib.import_module("sfm-learner-chainer_amd.synth")
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "interp_sampler_*.npz"))))
+def test_interp_sampler_restated_bit_exact(path):
+    z = np.load(path)
+    y = O.interp_sampler_forward(z["x"], z["grid"])
+    gx, gg = O.interp_sampler_backward(z["x"], z["grid"], z["gy"])
+    np.testing.assert_array_equal(y, z["y"])
+    np.testing.assert_array_equal(gg, z["ggrid"])
+    np.testing.assert_array_equal(gx, z["gx"])
+    assert not gx.any()                                    # :148 gx = zeros_like(x)
+
+
+def test_golden_fixture_set_is_complete():
+    names = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLD, "*.npz")))
+    assert names == ["euler_odom_util.npz", "interp_sampler_border.npz", "interp_sampler_c1.npz",
+                     "interp_sampler_c5.npz", "interp_sampler_kitti_s3.npz", "interp_sampler_ragged.npz",
+                     "interp_sampler_small.npz"]
+
+
+def test_interp_sampler_semantics_from_the_golden_border_case():
+    """measured on the reference (SURVEY.md §8(a) A8'): exactly 0 outside [0,W-1) x [0,H-1)."""
+    z = np.load(os.path.join(GOLD, "interp_sampler_border.npz"))
+    W = z["x"].shape[3]
+    u = z["grid"][0, 0, 0]
+    y = z["y"][0, :, 0]
+    outside = (u < 0) | (u >= W - 1)
+    assert outside.any() and (~outside).any()
+    assert (y[:, outside] == 0).all()
+
+
+def test_euler2mat_matches_odom_util_golden():
+    z = np.load(os.path.join(GOLD, "euler_odom_util.npz"))
+    np.testing.assert_allclose(O.euler2mat(z["r_xyz"], np.float64), z["R"], atol=1e-15)
+    np.testing.assert_allclose(O.euler2mat(z["r_xyz"], np.float32), z["R"], atol=3e-7)
+
+
+def test_batch_inv3_matches_lapack():
+    rng = np.random.RandomState(0)
+    K = np.tile(np.array([[241.7, 0, 204.2], [0, 246.3, 59.0], [0, 0, 1]]), (5, 1, 1)) + rng.normal(0, 1, (5, 3, 3))
+    np.testing.assert_allclose(O.batch_inv3(K), np.linalg.inv(K), rtol=1e-10)
+
+
+def _pow2_case(B=1, H=16, W=32):
+    d = synth.make_inputs(B=B, H=H, W=W, n_src=1, n_scales=1, seed=2)
+    K = np.zeros((B, 3, 3), np.float32)
+    K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2], K[:, 2, 2] = 32.0, 16.0, 16.0, 8.0, 1.0
+    return d, K
+
+
+def test_identity_pose_returns_source_inside_a_zero_frame():
+    """App. A.4 (1)"""
+    d, K = _pow2_case()
+    img = d["src_pyr"][0][:, :3]
+    H, W = img.shape[2:]
+    depth = np.full((1, 3, H * W), 0.5, np.float32)
+    out = O.projective_inverse_warp(img, depth, np.zeros((1, 6), np.float32), K)
+    # not bit-exact: the reference's normalise -> sampler de-normalise round trip perturbs U by ~1e-5 px
+    np.testing.assert_allclose(out[:, :, 1:-1, 1:-1], img[:, :, 1:-1, 1:-1], atol=1e-6)
+    frame = np.ones((H, W), bool)
+    frame[1:-1, 1:-1] = False
+    assert (out[:, :, frame] == 0).all()
+
+
+def test_pure_x_translation_is_an_integer_shift_with_zero_fill():
+    """App. A.4 (2): U = x + fx tx / D"""
+    d, K = _pow2_case()
+    img = d["src_pyr"][0][:, :3]
+    H, W = img.shape[2:]
+    depth = np.full((1, 3, H * W), 0.5, np.float32)
+    pose = np.zeros((1, 6), np.float32)
+    pose[0, 3] = 3 * 0.5 / 32.0                           # shift of exactly +3 px
+    out = O.projective_inverse_warp(img, depth, pose, K)
+    np.testing.assert_allclose(out[:, :, 1:-1, 1:W - 4], img[:, :, 1:-1, 4:W - 1], atol=1e-6)
+    assert (out[:, :, :, W - 4:] == 0).all()
+
+
+def test_pure_z_translation_zooms_about_the_principal_point():
+    """App. A.4 (3): U = cx + (x - cx) D / (D + tz)"""
+    d, K = _pow2_case()
+    img = d["src_pyr"][0][:, :3]
+    H, W = img.shape[2:]
+    depth = np.full((1, 3, H * W), 1.0, np.float32)
+    pose = np.zeros((1, 6), np.float32)
+    pose[0, 5] = 1.0                                      # D / (D + tz) = 1/2
+    _, aux = O.projective_inverse_warp(img, depth, pose, K, return_aux=True)
+    xs = np.tile(np.arange(W, dtype=np.float32), H)
+    ys = np.repeat(np.arange(H, dtype=np.float32), W)
+    np.testing.assert_allclose(aux["U"][0, 0], 16 + (xs - 16) / 2, atol=1e-5)
+    np.testing.assert_allclose(aux["V"][0, 0], 8 + (ys - 8) / 2, atol=1e-5)
+
+
+def test_zero_losses_for_identical_images_and_affine_disparity():
+    """App. A.4 (5)"""
+    rng = np.random.RandomState(0)
+    x = rng.uniform(-1, 1, (2, 3, 12, 20)).astype(np.float32)
+    assert np.abs(O.compute_ssim(x, x)).max() < 1e-4      # SSIM == 1 up to fp32 cancellation in sigma
+    yy, xx = np.meshgrid(np.arange(12.0), np.arange(20.0), indexing="ij")
+    ramp = (0.25 * xx + 0.5 * yy + 1.0)[None, None].astype(np.float32)
+    assert O.compute_smooth_loss(ramp) == 0.0
+
+
+def test_sampler_equals_interp_sampler_in_range():
+    """SURVEY.md §8(c) pin (4): the restated Chainer sampler agrees with the reference's own
+    (golden-pinned) interp sampler wherever both are defined the same way."""
+    rng = np.random.RandomState(3)
+    N, C, H, W = 2, 3, 12, 20
+    x = rng.uniform(-1, 1, (N, C, H, W)).astype(np.float32)
+    u = rng.uniform(0.01, W - 1.01, (N, H, W)).astype(np.float32)
+    v = rng.uniform(0.01, H - 1.01, (N, H, W)).astype(np.float32)
+    a = O.interp_sampler_forward(x, np.stack([u, v], 1))
+    b = O.spatial_transformer_sampler(x, np.stack([u / ((W - 1) / 2.) - 1, v / ((H - 1) / 2.) - 1], 1).astype(np.float32))
+    np.testing.assert_allclose(a, b, atol=2e-5)
+
+
+def test_x2_rule_makes_out_of_range_pixels_exactly_zero():
+    d = synth.make_inputs(B=2, H=16, W=52, n_src=2, n_scales=1, seed=5, trans_sigma=0.08)
+    img = d["src_pyr"][0][:, :3]
+    depth = np.broadcast_to((1.0 / d["disps"][0]).reshape(2, 1, -1), (2, 3, 16 * 52))
+    out, aux = O.projective_inverse_warp(img, depth, d["poses"][0], d["intrinsics"][:, 0], return_aux=True)
+    outside = (aux["mask"] == 2).any(axis=1).reshape(2, 16, 52)
+    assert outside.any() and (~outside).any()
+    assert (out[:, :, :, :][np.broadcast_to(outside[:, None], out.shape)] == 0).all()
+
+
+def test_resize_matches_the_synthetic_pyramid_builder():
+    rng = np.random.RandomState(1)
+    x = rng.uniform(-1, 1, (2, 3, 32, 52)).astype(np.float32)
+    for s in (1, 2):
+        np.testing.assert_array_equal(O.resize_images(x, (32 >> s, 52 >> s)), synth._resize_align_corners(x, 32 >> s, 52 >> s))
+    np.testing.assert_array_equal(O.get_multi_scale_intrinsics(np.eye(3, dtype=np.float32)[None] * 8, 3),
+                                  synth.multi_scale_intrinsics(np.eye(3, dtype=np.float32)[None] * 8, 3))
+
+
+@pytest.mark.parametrize("cfg", [dict(smooth_reg=0.1, ssim_rate=0.15), dict(smooth_reg=0.1, exp_reg=0.2, ssim_rate=0.15),
+                                 dict(smooth_reg=0.5, smooth_mode="edge_aware"), dict()])
+def test_hand_derived_backward_matches_fp64_finite_differences(cfg):
+    f64 = np.float64
+    d = synth.make_inputs(B=2, H=16, W=24, n_src=2, n_scales=2, seed=3, with_masks=True, trans_sigma=0.004)
+    for k in ("disps", "poses", "src_pyr", "masks"):
+        d[k] = [np.array(a, dtype=f64) for a in d[k]]
+
+    def run(**kw):
+        return O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], d["masks"], dtype=f64, **cfg, **kw)
+
+    r = run(backward=True, want_d_src=True)
+    rng = np.random.RandomState(0)
+    eps = 1e-7
+    groups = [("disp", d["disps"], r.d_disps), ("pose", d["poses"], r.d_poses), ("src", d["src_pyr"], r.d_srcs)]
+    if cfg.get("exp_reg"):
+        groups.append(("mask", d["masks"], r.d_masks))
+    for name, arrs, grads in groups:
+        for a, g in zip(arrs, grads):
+            for _ in range(6):
+                idx = tuple(rng.randint(0, n) for n in a.shape)
+                old = a[idx]
+                a[idx] = old + eps
+                lp = run().total_loss
+                a[idx] = old - eps
+                lm = run().total_loss
+                a[idx] = old
+                num = (lp - lm) / (2 * eps)
+                assert abs(num - g[idx]) <= 2e-3 * max(abs(num), abs(g[idx])) + 2e-9, (name, idx, num, g[idx])
+
+
+def test_shard_normalisation_is_additive():
+    """norm_batch: the losses of two half-batch shards add up to the full-batch loss."""
+    cfg = dict(smooth_reg=0.1, ssim_rate=0.15)
+    d = synth.make_inputs(B=4, H=16, W=24, n_src=2, n_scales=2, seed=9)
+    full = O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], backward=True, **cfg)
+    tot = 0.0
+    for lo in (0, 2):
+        sl = slice(lo, lo + 2)
+        part = O.sfm_loss([a[sl] for a in d["tgt_pyr"]], [a[sl] for a in d["src_pyr"]], d["intrinsics"][sl],
+                          [a[sl] for a in d["disps"]], [a[sl] for a in d["poses"]], backward=True, norm_batch=4, **cfg)
+        tot += part.total_loss
+        np.testing.assert_allclose(part.d_disps[0], full.d_disps[0][sl], rtol=1e-5, atol=1e-12)
+    assert abs(tot - full.total_loss) < 1e-6 * abs(full.total_loss)
