@@ -4,9 +4,11 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = forward + backward of the multi-scale photometric loss (sfm_loss_fwd + sfm_loss_bwd
-through the C ABI) over one synthetic batch that is already resident in HBM, plus -- for
-N > 1 -- the RCCL all-reduce of the five reported scalars.  The workload at any N is
+One "step" = forward + backward of the multi-scale photometric loss through the C ABI over one
+synthetic batch that is already resident in HBM -- by default the single fused launch
+(sfm_loss_fwd_bwd: loss and all gradients, what SFMLearnerLoss.__call__ runs when backprop is
+enabled); `--mode separate` times sfm_loss_fwd followed by sfm_loss_bwd instead -- plus, for
+N > 1, the RCCL all-reduce of the five reported scalars.  The workload at any N is
 BASELINE.json configs[2]/[3]: B = 32 samples PER GPU, 128x416, 4 scales, 2 sources,
 L1 + SSIM(0.15) + second-order smoothness(0.1) (experiments/sfm_learner_v1_ssim.yml), weak scaling.
 
@@ -99,10 +101,11 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
-    ap.add_argument("--mode", default="separate", choices=["separate", "fused"],
+    ap.add_argument("--mode", default="fused", choices=["separate", "fused"],
                     help="separate: sfm_loss_fwd then sfm_loss_bwd (the reference's forward / loss.backward()); "
                          "fused: one sfm_loss_fwd_bwd launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch of the workload (experiments only)")
     args = ap.parse_args()
 
     import numpy as np
@@ -124,6 +127,8 @@ def main():
     ops = importlib.import_module(PKG + ".ops")
     synth = importlib.import_module(PKG + ".synth")
     B, H, W, n_src, n_scales, cfg, desc = WORKLOADS[args.workload]
+    if args.batch > 0:
+        B, desc = args.batch, desc + " [per-GPU batch overridden to %d]" % args.batch
     d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=n_scales, seed=1 + rank)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     fl = ops.FusedLoss(**cfg).bind([t(a) for a in d["tgt_pyr"]], [t(a) for a in d["src_pyr"]], t(d["intrinsics"]),

@@ -190,10 +190,22 @@ __device__ __forceinline__ float hsum3(float x) {
   return (x + from_left(x)) + from_right(x);
 }
 
+// Sum over the 64 lanes, entirely in the VALU (DPP row shifts + row broadcasts); the result is valid
+// in lane 63 and returned as a wave-uniform value.  (A __shfl_xor butterfly goes through
+// ds_bpermute: ~100+ cycles of LDS latency per step, 6 dependent steps per value.)
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  int x = __builtin_bit_cast(int, v);
+#define SFM_DPP_ADD(ctrl, rmask, bmask)                                                                      \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, bmask, true))
+  SFM_DPP_ADD(0x111, 0xf, 0xf);   // row_shr:1
+  SFM_DPP_ADD(0x112, 0xf, 0xf);   // row_shr:2
+  SFM_DPP_ADD(0x114, 0xf, 0xf);   // row_shr:4   (lanes 15 of each row: sums of 8 = after next: 16)
+  SFM_DPP_ADD(0x118, 0xf, 0xf);   // row_shr:8   -> lane 15 of every row of 16 holds the row sum
+  SFM_DPP_ADD(0x142, 0xa, 0xf);   // row_bcast:15 into rows 1 and 3 -> lanes 31, 63 hold sums of 32
+  SFM_DPP_ADD(0x143, 0xc, 0xf);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+#undef SFM_DPP_ADD
+  (void)x;
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 __device__ __forceinline__ float uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }

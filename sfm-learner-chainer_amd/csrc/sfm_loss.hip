@@ -100,10 +100,14 @@ __device__ __forceinline__ void smooth2_pass(const LossArgs& A, const ScaleArgs&
   float dm2 = 0.f, dm1 = 0.f, d0 = 0.f, dp1 = 0.f, dp2 = 0.f;
   const bool vx2 = xin && (x <= w - 3);
   const bool vx1 = xin && (x <= w - 2);
+  // rows are loaded three steps ahead of their use (a plain load-then-use loop is latency bound)
+  const unsigned xc = (unsigned)min(max(x, 0), w - 1);
+  auto ldrow = [&](int r) -> float { return (r >= 0 && r < h && r < y1 + 2) ? dplane[(unsigned)r * (unsigned)w + xc] : 0.f; };
+  float q1 = ldrow(y0 - 2), q2 = ldrow(y0 - 1), q3 = ldrow(y0);
   for (int r = y0 - 2; r < y1 + 2; ++r) {
     dm2 = dm1; dm1 = d0; d0 = dp1; dp1 = dp2;
-    dp2 = 0.f;
-    if (r >= 0 && r < h && xin) dp2 = dplane[r * w + x];
+    dp2 = xin ? q1 : 0.f;
+    q1 = q2; q2 = q3; q3 = ldrow(r + 3);
     const int q = r - 2;
     if (q < y0) continue;
     const float dxr0 = from_right(d0) - d0;        // dx(q,x)
@@ -152,15 +156,26 @@ __device__ __forceinline__ void smooth_edge_pass(const LossArgs& A, const ScaleA
   float im1[3] = {0.f, 0.f, 0.f}, i0[3] = {0.f, 0.f, 0.f}, ip1[3] = {0.f, 0.f, 0.f};
   const bool vx1 = xin && (x <= w - 2);
   const float third = 1.0f / 3.0f;
-  for (int r = y0 - 1; r < y1 + 1; ++r) {
-    dm1 = d0; d0 = dp1; dp1 = 0.f;
+  // rows are loaded two steps ahead of their use
+  const unsigned xc = (unsigned)min(max(x, 0), w - 1);
+  float qd1 = 0.f, qd2 = 0.f, qi1[3] = {0.f, 0.f, 0.f}, qi2[3] = {0.f, 0.f, 0.f};
+  auto ldrow = [&](int r, float& d, float* im) {
+    d = 0.f; im[0] = im[1] = im[2] = 0.f;
+    if (r >= 0 && r < h && r < y1 + 1) {
+      const unsigned o = (unsigned)r * (unsigned)w + xc;
+      d = dplane[o];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { im1[c] = i0[c]; i0[c] = ip1[c]; ip1[c] = 0.f; }
-    if (r >= 0 && r < h && xin) {
-      dp1 = dplane[r * w + x];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) ip1[c] = tplane[c * P + r * w + x];
+      for (int c = 0; c < 3; ++c) im[c] = tplane[c * P + o];
     }
+  };
+  ldrow(y0 - 1, qd1, qi1);
+  ldrow(y0, qd2, qi2);
+  for (int r = y0 - 1; r < y1 + 1; ++r) {
+    dm1 = d0; d0 = dp1; dp1 = xin ? qd1 : 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { im1[c] = i0[c]; i0[c] = ip1[c]; ip1[c] = xin ? qi1[c] : 0.f; qi1[c] = qi2[c]; }
+    qd1 = qd2;
+    ldrow(r + 2, qd2, qi2);
     const int q = r - 1;
     if (q < y0) continue;
     // x term anchored at (q,x)
@@ -499,24 +514,45 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
   const int wave = threadIdx.x >> 6;
   float* gacc = gacc_all + (GRAD ? wave * MAX_CHUNK_ROWS * 64 : 0);
 
-  // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2): give every XCD a contiguous
-  // range of items, so that neighbouring strips / chunks of one image (shared halo rows, overlapping
-  // gather footprints) meet in one L2.  Placement only affects speed, never the result.
-  const int nblk = gridDim.x, per = (nblk + 7) >> 3;
+  // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  XCD x is given the samples
+  // b = x (mod 8) at ALL scales, largest scale first: every XCD gets the same mix of work, and all planes of
+  // a sample (target, sources, disparity; shared halo rows, overlapping gather footprints) meet in one L2.
+  // With fewer than 8 samples the items are dealt out as 8 contiguous ranges instead.  Placement only affects
+  // speed, never the result (the partial sums are indexed by the item id, not by the block).
+  static_assert(WAVES_PER_BLOCK == 1, "item mapping assumes one wavefront per workgroup");
   const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
-  const int blk = xcd * per + loc;
-  const int item = blk * WAVES_PER_BLOCK + __builtin_amdgcn_readfirstlane(wave);
-  if (loc >= per || item >= A.items) return;   // whole wavefront leaves; no block-level synchronisation anywhere in this kernel
+  int s = 0, b, t;
+  if (A.B >= 8) {
+    const int nb = (A.B - xcd + 7) >> 3;          // samples owned by this XCD
+    int rem = loc;
+    bool found = false;
+#pragma unroll
+    for (int k = 0; k < SFM_MAX_SCALES; ++k) {
+      if (k < A.n_scales && !found) {
+        const int cnt = nb * A.sc[k].tiles;
+        if (rem < cnt) { s = k; found = true; }
+        else rem -= cnt;
+      }
+    }
+    if (!found) return;   // whole wavefront leaves; no block-level synchronisation anywhere in this kernel
+    const int bl = rem / A.sc[s].tiles;
+    t = rem - bl * A.sc[s].tiles;
+    b = xcd + 8 * bl;
+  } else {
+    const int per = (int)(gridDim.x >> 3);
+    const int it = xcd * per + loc;
+    if (it >= A.items) return;
+#pragma unroll
+    for (int k = 1; k < SFM_MAX_SCALES; ++k)
+      if (k < A.n_scales && it >= A.sc[k].item_begin) s = k;
+    const int idx = it - A.sc[s].item_begin;
+    b = idx / A.sc[s].tiles;
+    t = idx - b * A.sc[s].tiles;
+  }
+  const ScaleArgs& S = A.sc[s];
+  const int item = S.item_begin + b * S.tiles + t;
   unsigned long long t_start = 0;
   if (A.trace) t_start = __builtin_amdgcn_s_memrealtime();
-  int s = 0;
-#pragma unroll
-  for (int k = 1; k < SFM_MAX_SCALES; ++k)
-    if (k < A.n_scales && item >= A.sc[k].item_begin) s = k;
-  const ScaleArgs& S = A.sc[s];
-  const int idx = item - S.item_begin;
-  const int b = idx / S.tiles;
-  const int t = idx - b * S.tiles;
   const int chunk = t / S.strips;
   const int strip = t - chunk * S.strips;
   const int h = S.h, w = S.w;
@@ -531,6 +567,11 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
 
   float acc_pix = 0.f, acc_ssim = 0.f, acc_sm = 0.f, acc_exp = 0.f;
   bool first = true;
+#ifdef SFM_STAMPS
+  Stamps st = {0, 0, 0, 0, 0};
+  unsigned long long ts0 = 0, ts1 = 0;
+  SFM_STAMP(ts0);
+#endif
   if (SMODE == 1) {
     smooth2_pass<GRAD, LOSS>(A, S, S.disp + (size_t)b * P, lane, x, xin, outl, y0, y1, gacc, acc_sm);
     first = false;
@@ -538,18 +579,25 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
     smooth_edge_pass<GRAD, LOSS>(A, S, S.disp + (size_t)b * P, S.tgt + (size_t)b * 3 * P, lane, x, xin, outl, y0, y1, gacc, acc_sm);
     first = false;
   }
+#ifdef SFM_STAMPS
+  SFM_STAMP(ts1);
+#endif
   for (int i = 0; i < A.n_src; ++i) {
     if constexpr (SSIM) {
       SsimCtx C;
-      const Geom* __restrict__ gp = A.geom + ((size_t)(b * A.n_scales + s) * A.n_src + i);
+      // the geometry table was written by geom_kernel before this launch and is read-only here: reading it
+      // through the constant address space lets the wave fetch the 32 floats with a few scalar loads
+      // (s_load_dwordx8/x16 into SGPRs, one wait) instead of 21 dependent vector loads + v_readfirstlane
+      typedef const __attribute__((address_space(4))) Geom* GeomConstPtr;
+      GeomConstPtr gp = (GeomConstPtr)(uintptr_t)(A.geom + ((size_t)(b * A.n_scales + s) * A.n_src + i));
       const float xf = (float)x;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        C.M1[k] = uniform(gp->M[k * 3 + 1]);
-        C.P3[k] = uniform(gp->P[k * 4 + 3]);
-        C.K1[k] = uniform(gp->Kinv[k * 3 + 1]);
-        C.mx[k] = fmaf(uniform(gp->M[k * 3 + 0]), xf, uniform(gp->M[k * 3 + 2]));
-        C.kx[k] = fmaf(uniform(gp->Kinv[k * 3 + 0]), xf, uniform(gp->Kinv[k * 3 + 2]));
+        C.M1[k] = gp->M[k * 3 + 1];
+        C.P3[k] = gp->P[k * 4 + 3];
+        C.K1[k] = gp->Kinv[k * 3 + 1];
+        C.mx[k] = fmaf(gp->M[k * 3 + 0], xf, gp->M[k * 3 + 2]);
+        C.kx[k] = fmaf(gp->Kinv[k * 3 + 0], xf, gp->Kinv[k * 3 + 2]);
         C.tp[k] = S.tgt + ((size_t)b * 3 + k) * P;
         C.sp[k] = S.src + (((size_t)b * A.n_src + i) * 3 + k) * P;
       }
@@ -564,7 +612,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
       C.xin = xin;
       C.outf = outl ? 1.f : 0.f;
       C.lane = lane;
-      ssim_source_pass<GRAD, LOSS>(C, gacc, first, acc_pix, acc_ssim, GRAD ? A.part_gpm + ((size_t)item * A.n_src + i) * 12 : nullptr);
+      ssim_source_pass<GRAD, LOSS>(C, gacc, first, acc_pix, acc_ssim, GRAD ? A.part_gpm + ((size_t)item * A.n_src + i) * 12 : nullptr SFM_STAMPS_PASS);
     } else {
       source_pass<false, GRAD, LOSS, EXPL>(A, S, sc, b, i, s, lane, x, xin, outl, y0, y1, gacc, first, acc_pix, acc_ssim, acc_exp, item);
     }
@@ -582,6 +630,12 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
     o[1] = __builtin_amdgcn_s_memrealtime();
     o[2] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
     o[3] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+#ifdef SFM_STAMPS
+    if constexpr (SSIM) {
+      unsigned long long* q = A.trace + (size_t)A.items * 4 + (size_t)item * 8;
+      q[0] = st.a_fin; q[1] = st.a_iss; q[2] = st.b; q[3] = st.c; q[4] = st.steps; q[5] = ts1 - ts0;
+    }
+#endif
   }
   if (LOSS) {
     const float v0 = wave_sum(acc_pix) * S.inv_cnt;
@@ -857,8 +911,11 @@ template <bool GRAD, bool LOSS>
 static void launch_main(const Plan& p, hipStream_t st) {
   LossArgs args = p.args;
   void* kargs[] = {&args};
-  (void)hipLaunchKernel(kernel_ptr<GRAD, LOSS>(p.ssim, p.expl, p.smode), dim3(((p.args.items + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK + 7) / 8 * 8),
-                        dim3(64 * WAVES_PER_BLOCK), kargs, 0, st);
+  // 8 x (items of the busiest XCD): see the item mapping at the top of loss_kernel
+  int tiles_per_sample = 0;
+  for (int s = 0; s < p.args.n_scales; ++s) tiles_per_sample += p.args.sc[s].tiles;
+  const int per_xcd = p.args.B >= 8 ? ((p.args.B + 7) / 8) * tiles_per_sample : (p.args.items + 7) / 8;
+  (void)hipLaunchKernel(kernel_ptr<GRAD, LOSS>(p.ssim, p.expl, p.smode), dim3(8 * per_xcd), dim3(64 * WAVES_PER_BLOCK), kargs, 0, st);
 }
 
 static int run(const SfmLossDesc* d, bool grad, bool loss, float gy, float* loss5, void* ws, size_t ws_bytes, void* stream,

@@ -20,6 +20,18 @@
 
 namespace sfm {
 
+#ifdef SFM_STAMPS   // diagnostic build only: cycle stamps around the stages of a row step (never in the product build)
+#define SFM_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+struct Stamps { unsigned long long a_fin, a_iss, b, c, steps; };
+__device__ Stamps g_dummy_stamps;
+#define SFM_STAMPS_ARG , Stamps& st
+#define SFM_STAMPS_PASS , st
+#else
+#define SFM_STAMP(var) do { } while (0)
+#define SFM_STAMPS_ARG
+#define SFM_STAMPS_PASS
+#endif
+
 struct SsimCtx {
   // uniform (SGPR)
   float M1[3], P3[3], K1[3];
@@ -113,14 +125,31 @@ template <bool GRAD, bool LOSS>
 __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const int r, const int rend, Pipe& ps, float& disp_next,
                                               RowS& s0, const RowS& s1, const RowS& s2,
                                               RowG& g0, const RowG& g1, const RowG& g2, float* gacc, const bool first,
-                                              float& acc_pix, float& acc_ssim, float* gpm) {
+                                              float& acc_pix, float& acc_ssim, float* gpm SFM_STAMPS_ARG) {
   const int h = C.h, w = C.w;
+#ifndef SFM_NO_PRIO_ROTATION
+  // The SIMD's issue arbiter prefers the oldest wave, so co-resident waves finish one after the other and
+  // the SIMD ends its launch with one lone wave at a fraction of its issue rate.  Rotating a raised
+  // priority among the waves of a SIMD by wall-clock time lets them advance evenly and finish together.
+  {
+    const unsigned slot = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (3 << 11));   // HW_ID.WAVE_ID: slot on this SIMD
+    const unsigned phase = (unsigned)(__builtin_amdgcn_s_memtime() >> 12);
+    if ((phase + slot) % 3u == 0u) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+  }
+#endif
+#ifdef SFM_STAMPS
+  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+#endif
+  SFM_STAMP(t0);
   // ---------------- A: finish row r, put row r+1 in flight ----------------
   if (r >= 0 && r < h) finish_row(C, ps, s0);
   else zero(s0);
+  SFM_STAMP(t1);
   const int rn = r + 1, rnn = r + 2;
   if (rn < rend && rn >= 0 && rn < h) issue_row(C, rn, disp_next, ps);
   if (rnn < rend && rnn >= 0 && rnn < h) disp_next = C.dp[(unsigned)rnn * (unsigned)w + C.xc];
+  SFM_STAMP(t2);
 
   // ---------------- B: SSIM at row r-1 ----------------
   const int rb = r - 1;
@@ -162,6 +191,7 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const int r, con
     }
   }
 
+  SFM_STAMP(t3);
   // ---------------- C: gradients at row r-2 ----------------
   if (GRAD) {
     const int rc = r - 2;
@@ -213,12 +243,16 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const int r, con
       }
     }
   }
+  SFM_STAMP(t4);
+#ifdef SFM_STAMPS
+  st.a_fin += t1 - t0; st.a_iss += t2 - t1; st.b += t3 - t2; st.c += t4 - t3; st.steps += 1;
+#endif
 }
 
 // One source of one wave.  HS = halo of this pass (2 with gradients, 1 forward only).
 template <bool GRAD, bool LOSS>
 __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, const bool first, float& acc_pix, float& acc_ssim,
-                                                 float* gpm_out /* 12 floats in global memory, or nullptr */) {
+                                                 float* gpm_out /* 12 floats in global memory, or nullptr */ SFM_STAMPS_ARG) {
   constexpr int HS = GRAD ? 2 : 1;
   const int rbeg = C.y0 - HS, rend = C.y1 + HS;
   float gpm[12];
@@ -234,11 +268,11 @@ __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, 
   if (rbeg >= 0 && rbeg < C.h) issue_row(C, rbeg, C.dp[(unsigned)rbeg * (unsigned)C.w + C.xc], ps);
   if (rbeg + 1 >= 0 && rbeg + 1 < C.h) disp_next = C.dp[(unsigned)(rbeg + 1) * (unsigned)C.w + C.xc];
   for (int r = rbeg; r < rend; r += 3) {
-    ssim_row_step<GRAD, LOSS>(C, r, rend, ps, disp_next, S0, S2, S1, G0, G2, G1, gacc, first, acc_pix, acc_ssim, gpm);
+    ssim_row_step<GRAD, LOSS>(C, r, rend, ps, disp_next, S0, S2, S1, G0, G2, G1, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
     if (r + 1 < rend)
-      ssim_row_step<GRAD, LOSS>(C, r + 1, rend, ps, disp_next, S1, S0, S2, G1, G0, G2, gacc, first, acc_pix, acc_ssim, gpm);
+      ssim_row_step<GRAD, LOSS>(C, r + 1, rend, ps, disp_next, S1, S0, S2, G1, G0, G2, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
     if (r + 2 < rend)
-      ssim_row_step<GRAD, LOSS>(C, r + 2, rend, ps, disp_next, S2, S1, S0, G2, G1, G0, gacc, first, acc_pix, acc_ssim, gpm);
+      ssim_row_step<GRAD, LOSS>(C, r + 2, rend, ps, disp_next, S2, S1, S0, G2, G1, G0, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
   }
   if (GRAD) {
 #pragma unroll

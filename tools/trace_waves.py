@@ -13,11 +13,14 @@ fl = ops.FusedLoss(smooth_reg=0.1, ssim_rate=0.15).bind([t(a) for a in d["tgt_py
                                                         [t(a) for a in d["disps"]], [t(a) for a in d["poses"]])
 run = {"fused": fl.forward_backward, "fwd": fl.forward, "bwd": lambda: fl.backward(1.0)}[mode]
 for _ in range(5): run()
-buf = torch.zeros((20000, 4), dtype=torch.int64, device=dev)
+buf = torch.zeros((60000, 4), dtype=torch.int64, device=dev)
 ops.lib.sfm_loss_debug_trace(C.c_void_p(buf.data_ptr()))
 run(); torch.cuda.synchronize()
-a = buf.cpu().numpy()
-a = a[a[:, 1] != 0]
+raw = buf.cpu().numpy()
+nz = int((raw != 0).any(axis=1).sum())
+stamps = os.environ.get("SFMWARP_LIB", "").endswith("stamps.so")
+n_items = nz // 3 if stamps else nz
+a = raw[:n_items]
 t0 = a[:, 0].min()
 st = (a[:, 0] - t0) / 100.0; en = (a[:, 1] - t0) / 100.0   # microseconds
 hw = a[:, 2]; xcc = a[:, 3] & 0xf
@@ -39,3 +42,22 @@ for k in u[:4096]:
 print("peak concurrent waves per SIMD histogram", np.bincount(peak))
 late = st > 5
 print("waves starting after 5us: %d ; their mean duration %.1f ; early waves mean duration %.1f" % (late.sum(), (en - st)[late].mean() if late.any() else 0, (en - st)[~late].mean()))
+if os.environ.get("SFMWARP_LIB", "").endswith("stamps.so"):
+    n = n_items
+    b = raw.reshape(-1)[n * 4: n * 4 + n * 8].reshape(n, 8).astype(np.float64)
+    steps = b[:, 4].sum()
+    print("cycles per row step (mean over all waves): A.finish %.0f  A.issue %.0f  B %.0f  C %.0f   total %.0f ; smooth pass per wave %.0f cycles" % (
+        b[:, 0].sum() / steps, b[:, 1].sum() / steps, b[:, 2].sum() / steps, b[:, 3].sum() / steps, b[:, :4].sum() / steps, b[:, 5].mean()))
+if stamps:
+    dur_cyc = (a[:, 1] - a[:, 0]).astype(np.float64) * 24.0     # 100 MHz ticks -> cycles at ~2.4 GHz
+    loop = b[:, :4].sum(axis=1); sm = b[:, 5]
+    order = np.zeros(n, int)
+    for kk in np.unique(key):
+        idx = np.where(key == kk)[0]
+        order[idx[np.argsort(en[idx])]] = np.arange(len(idx))
+    for rk in range(3):
+        m = order == rk
+        if m.any():
+            print("finish-rank %d: n=%d dur %.0fk cyc | loop %.0fk (%.0f/step, steps %.1f) smooth %.0fk other %.0fk | A.fin %.0f A.iss %.0f B %.0f C %.0f per step" % (
+                rk, m.sum(), dur_cyc[m].mean() / 1e3, loop[m].mean() / 1e3, (loop[m] / b[m, 4]).mean(), b[m, 4].mean(), sm[m].mean() / 1e3,
+                (dur_cyc[m] - loop[m] - sm[m]).mean() / 1e3, (b[m, 0] / b[m, 4]).mean(), (b[m, 1] / b[m, 4]).mean(), (b[m, 2] / b[m, 4]).mean(), (b[m, 3] / b[m, 4]).mean()))
