@@ -173,6 +173,26 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # secondary measurement (NOT part of the timed K steps above): the other launch mode, for the record
+    other_mode = "separate" if args.mode == "fused" else "fused"
+    other_ms = None
+    if world == 1:
+        def other_step():
+            if other_mode == "fused":
+                fl.forward_backward()
+            else:
+                fl.forward()
+                fl.backward(1.0)
+        for _ in range(5):
+            other_step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_other = max(10, args.steps // 4)
+        for _ in range(n_other):
+            other_step()
+        torch.cuda.synchronize()
+        other_ms = (time.perf_counter() - t1) / n_other * 1e3
+
     # per-launch duration of the main kernels, from the HIP events recorded inside the timed region
     k_fwd = float(np.mean([ev.elapsed_ms(e[0], e[1]) for e in events]))
     k_bwd = float(np.mean([ev.elapsed_ms(e[2], e[3]) for e in events])) if args.mode == "separate" else None
@@ -189,6 +209,18 @@ def main():
         else:
             kname, kbytes, kms = "loss_kernel<grad> (sfm_loss_bwd)", BYTES_BWD, k_bwd
         achieved = kbytes * warped_px / (kms * 1e-3) / 1e9
+        # HBM-side bytes per launch of that kernel from the rocprofv3 PMC passes (collected offline with
+        # tools/collect_profiles.sh; bench.py itself cannot read hardware counters)
+        traffic = None
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_summary.json")))
+            if prof["bench"]["config"]["mode"] == args.mode and args.workload == "cfg3" and args.batch == 0:
+                for kn, kv in prof["kernels"].items():
+                    if "loss_kernel" in kn and "hbm_bytes_raw" in kv:
+                        traffic = {"bytes_per_launch_raw": kv["hbm_bytes_raw"], "bytes_per_launch_fetch_x2": kv["hbm_bytes_fetch_x2"],
+                                   "source": "profiles/r01_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+        except Exception:
+            traffic = None
         out = {
             "metric": "warp+photo-loss fwd+bwd Mpixels/s @128x416x4scales; % HBM roofline",
             "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -198,12 +230,14 @@ def main():
                        "n_scales": n_scales, "mode": args.mode, "warped_px_per_gpu_step": warped_px,
                        "parallelism": "batch-sharded x%d, RCCL all-reduce of 5 scalars" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": kname, "kernel_ms": round(kms, 5), "bytes_per_warped_px": kbytes},
             "kernel_ms": {"fwd_main": round(k_fwd, 5) if args.mode == "separate" else None,
                           "bwd_main": round(k_bwd, 5) if k_bwd is not None else None,
                           "fused_main": round(k_fwd, 5) if args.mode == "fused" else None},
             "step_roofline_frac": round((BYTES_FWD + BYTES_BWD) * warped_px / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "other_mode": {"mode": other_mode, "ms_per_step": round(other_ms, 5) if other_ms else None,
+                           "value": round(warped_px / (other_ms * 1e-3) / 1e6, 1) if other_ms else None},
             "loss5": [round(v, 6) for v in loss],
         }
         if not args.no_cpu_baseline and world == 1:

@@ -102,8 +102,14 @@ __device__ __forceinline__ void smooth2_pass(const LossArgs& A, const ScaleArgs&
   const bool vx1 = xin && (x <= w - 2);
   // rows are loaded three steps ahead of their use (a plain load-then-use loop is latency bound)
   const unsigned xc = (unsigned)min(max(x, 0), w - 1);
-  auto ldrow = [&](int r) -> float { return (r >= 0 && r < h && r < y1 + 2) ? dplane[(unsigned)r * (unsigned)w + xc] : 0.f; };
+  // (always a load, from a row clamped into the image: a load under a branch would make the compiler drain
+  // every outstanding load at the join; rows outside the image only feed terms that are masked out below)
+  auto ldrow = [&](int r) -> float { return dplane[(unsigned)min(max(r, 0), h - 1) * (unsigned)w + xc]; };
   float q1 = ldrow(y0 - 2), q2 = ldrow(y0 - 1), q3 = ldrow(y0);
+  // loop-invariant coefficients, pinned in vector registers (the scalar file is full: they were re-loaded
+  // from the kernel arguments twice per row)
+  float c_dx2 = S.c_dx2, c_dy2 = S.c_dy2, c_dxy = S.c_dxy, gyv = A.gy;
+  asm volatile("" : "+v"(c_dx2), "+v"(c_dy2), "+v"(c_dxy), "+v"(gyv));
   for (int r = y0 - 2; r < y1 + 2; ++r) {
     dm2 = dm1; dm1 = d0; d0 = dp1; dp1 = dp2;
     dp2 = xin ? q1 : 0.f;
@@ -120,9 +126,9 @@ __device__ __forceinline__ void smooth2_pass(const LossArgs& A, const ScaleArgs&
     const bool vq2 = q <= h - 3, vq1 = q <= h - 2;
     if (LOSS) {
       float t = 0.f;
-      if (vx2) t += S.c_dx2 * fabsf(dx2);
-      if (vq2) t += S.c_dy2 * fabsf(dy2);
-      if (vx1 && vq1) t += S.c_dxy * (fabsf(dxdy0) + fabsf(dydx0));
+      if (vx2) t += c_dx2 * fabsf(dx2);
+      if (vq2) t += c_dy2 * fabsf(dy2);
+      if (vx1 && vq1) t += c_dxy * (fabsf(dxdy0) + fabsf(dydx0));
       if (outl) acc_sm += t;
     }
     if (GRAD) {
@@ -140,7 +146,7 @@ __device__ __forceinline__ void smooth2_pass(const LossArgs& A, const ScaleArgs&
       const float t1 = (vx1 && q - 1 >= 0) ? signf(dxdym1) + signf(dydxm1) : 0.f;
       const float t0 = (vx1 && vq1) ? signf(dxdy0) + signf(dydx0) : 0.f;
       const float gxy = from_left(t1) - t1 - from_left(t0) + t0;
-      gacc[(q - y0) * 64 + lane] = A.gy * (S.c_dx2 * gx2 + S.c_dy2 * gy2 + S.c_dxy * gxy);
+      gacc[(q - y0) * 64 + lane] = gyv * (c_dx2 * gx2 + c_dy2 * gy2 + c_dxy * gxy);
     }
   }
 }
@@ -159,14 +165,11 @@ __device__ __forceinline__ void smooth_edge_pass(const LossArgs& A, const ScaleA
   // rows are loaded two steps ahead of their use
   const unsigned xc = (unsigned)min(max(x, 0), w - 1);
   float qd1 = 0.f, qd2 = 0.f, qi1[3] = {0.f, 0.f, 0.f}, qi2[3] = {0.f, 0.f, 0.f};
-  auto ldrow = [&](int r, float& d, float* im) {
-    d = 0.f; im[0] = im[1] = im[2] = 0.f;
-    if (r >= 0 && r < h && r < y1 + 1) {
-      const unsigned o = (unsigned)r * (unsigned)w + xc;
-      d = dplane[o];
+  auto ldrow = [&](int r, float& d, float* im) {   // always loads, from a row clamped into the image (see smooth2_pass)
+    const unsigned o = (unsigned)min(max(r, 0), h - 1) * (unsigned)w + xc;
+    d = dplane[o];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) im[c] = tplane[c * P + o];
-    }
+    for (int c = 0; c < 3; ++c) im[c] = tplane[c * P + o];
   };
   ldrow(y0 - 1, qd1, qi1);
   ldrow(y0, qd2, qi2);
@@ -618,6 +621,10 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
     }
     first = false;
   }
+#ifdef SFM_STAMPS
+  unsigned long long ts2 = 0;
+  SFM_STAMP(ts2);
+#endif
   if (GRAD) {
     if (outl) {
       float* o = S.d_disp + (size_t)b * P;
@@ -633,7 +640,11 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
 #ifdef SFM_STAMPS
     if constexpr (SSIM) {
       unsigned long long* q = A.trace + (size_t)A.items * 4 + (size_t)item * 8;
+      unsigned long long ts3 = 0;
+      SFM_STAMP(ts3);
       q[0] = st.a_fin; q[1] = st.a_iss; q[2] = st.b; q[3] = st.c; q[4] = st.steps; q[5] = ts1 - ts0;
+      q[6] = ts2 - ts1;   // both source passes, everything included
+      q[7] = ts3 - ts2;   // epilogue: d_disp write-out, loss sums
     }
 #endif
   }

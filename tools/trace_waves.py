@@ -58,6 +58,9 @@ if stamps:
     for rk in range(3):
         m = order == rk
         if m.any():
+            print("   passes %.0fk (loop %.0fk => prologue+epilogue of the 2 source passes %.0fk), kernel epilogue %.0fk, before smooth pass %.0fk" % (
+                b[m, 6].mean() / 1e3, loop[m].mean() / 1e3, (b[m, 6] - loop[m]).mean() / 1e3, b[m, 7].mean() / 1e3,
+                (dur_cyc[m] - b[m, 5] - b[m, 6] - b[m, 7]).mean() / 1e3))
             print("finish-rank %d: n=%d dur %.0fk cyc | loop %.0fk (%.0f/step, steps %.1f) smooth %.0fk other %.0fk | A.fin %.0f A.iss %.0f B %.0f C %.0f per step" % (
                 rk, m.sum(), dur_cyc[m].mean() / 1e3, loop[m].mean() / 1e3, (loop[m] / b[m, 4]).mean(), b[m, 4].mean(), sm[m].mean() / 1e3,
                 (dur_cyc[m] - loop[m] - sm[m]).mean() / 1e3, (b[m, 0] / b[m, 4]).mean(), (b[m, 1] / b[m, 4]).mean(), (b[m, 2] / b[m, 4]).mean(), (b[m, 3] / b[m, 4]).mean()))
