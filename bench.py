@@ -215,8 +215,9 @@ def main():
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", "r01_summary.json")))
             if prof["bench"]["config"]["mode"] == args.mode and args.workload == "cfg3" and args.batch == 0:
+                want = "sfm_loss_fwd_bwd" if args.mode == "fused" else "sfm_loss_bwd"
                 for kn, kv in prof["kernels"].items():
-                    if "loss_kernel" in kn and "hbm_bytes_raw" in kv:
+                    if kv.get("entry_point") == want and "hbm_bytes_raw" in kv:
                         traffic = {"bytes_per_launch_raw": kv["hbm_bytes_raw"], "bytes_per_launch_fetch_x2": kv["hbm_bytes_fetch_x2"],
                                    "source": "profiles/r01_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
         except Exception:

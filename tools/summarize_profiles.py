@@ -54,7 +54,12 @@ for k in main:
         # loads 4-8 B per lane (uncalibrated), so both the raw and the x2-corrected figure are given.
         t["hbm_bytes_raw"] = (fetch_kb + write_kb) * 1024
         t["hbm_bytes_fetch_x2"] = (2 * fetch_kb + write_kb) * 1024
-        t["algorithmic_bytes"] = bench["roofline"]["bytes_per_warped_px"] * px
+        # template arguments <SSIM, GRAD, LOSS, EXPL, SMODE>: fused = 28 + 32 B per warped px, backward 32, forward 28
+        import re
+        m = re.search(r"loss_kernel<(\w+), (\w+), (\w+)", k)
+        grad, loss = (m.group(2) == "true", m.group(3) == "true") if m else (True, True)
+        t["entry_point"] = "sfm_loss_fwd_bwd" if (grad and loss) else ("sfm_loss_bwd" if grad else "sfm_loss_fwd")
+        t["algorithmic_bytes"] = ((28 if loss else 0) + (32 if grad else 0)) * px
     summary["kernels"].setdefault(k, {}).update(t)
 json.dump(summary, open(os.path.join(out, "%s_summary.json" % tag), "w"), indent=1, sort_keys=True)
 with open(os.path.join(out, "%s_summary.md" % tag), "w") as f:
@@ -68,7 +73,7 @@ with open(os.path.join(out, "%s_summary.md" % tag), "w") as f:
             f.write("| `%s` | %d | %.2f | %.1f |\n" % (name[:70], v["calls"], v["avg_ns"] / 1e3, v["pct"]))
     for k in main:
         v = summary["kernels"][k]
-        f.write("\n## PMC, `%s` (per launch)\n\n" % k[:70])
+        f.write("\n## PMC, `%s` = %s (per launch)\n\n" % (k[:70], v.get("entry_point", "")))
         for c, val in sorted(v.get("counters_per_launch", {}).items()):
             f.write("* %s = %.4g\n" % (c, val))
         if "hbm_bytes_raw" in v:
