@@ -158,6 +158,11 @@ int sfm_loss_debug_trace(void *buf);
  * ---------------------------------------------------------------------------------------- */
 int sfm_resize_fwd(const float *x, float *y, int N, int C, int H, int W, int oH, int oW, void *stream);
 
+/* The image pyramid of one step in ONE launch: the loop head models/base_model.py:69-72 for one
+ * tensor.  x (N,C,H,W) -> y[s] (N,C,H>>s,W>>s) for s = 1..n_scales-1, every scale resampled from
+ * the full-resolution input (as the reference does); y[0] is ignored (scale 0 is x itself). */
+int sfm_pyramid_fwd(const float *x, float *const *y, int N, int C, int H, int W, int n_scales, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -931,6 +931,14 @@ static void launch_main(const Plan& p, hipStream_t st) {
 
 static int run(const SfmLossDesc* d, bool grad, bool loss, float gy, float* loss5, void* ws, size_t ws_bytes, void* stream,
                const char* who) {
+  if (d && d->B == 0) {   // empty shard: nothing to launch (input pointers of empty arrays may be NULL)
+    if (loss) {
+      if (!loss5) return fail(SFM_ERR_NULL, "%s: loss5 is NULL", who);
+      hipError_t e = hipMemsetAsync(loss5, 0, 5 * sizeof(float), (hipStream_t)stream);
+      if (e != hipSuccess) return fail((int)e, "%s: memset: %s", who, hipGetErrorString(e));
+    }
+    return SFM_OK;
+  }
   Plan p;
   if (int e = make_plan(d, grad, loss, true, gy, p)) return e;
   if (loss && !loss5) return fail(SFM_ERR_NULL, "%s: loss5 is NULL", who);

@@ -407,6 +407,43 @@ __global__ void resize_fwd_kernel(const float* __restrict__ x, float* __restrict
   y[(size_t)nc * oH * oW + j] = top * wv0 + bot * wv1;
 }
 
+// ------------------------------------------------------------------------------------------
+// The whole image pyramid of a step in one launch (models/base_model.py:69-72): scales 1..S-1 of
+// F.resize_images(x, (H >> s, W >> s)), each resampled from the full-resolution input as the
+// reference does.  One thread per output pixel of any scale.
+// ------------------------------------------------------------------------------------------
+struct PyramidArgs {
+  const float* x;
+  float* y[SFM_MAX_SCALES];      // y[s] for s = 1..n_scales-1 (y[0] unused: scale 0 is the input itself)
+  int oH[SFM_MAX_SCALES], oW[SFM_MAX_SCALES];
+  int begin[SFM_MAX_SCALES + 1]; // prefix sums of oH*oW over scales 1..
+  int H, W, n_scales;
+};
+
+__global__ void pyramid_fwd_kernel(const PyramidArgs A) {
+#pragma clang fp contract(off)
+  const int nc = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= A.begin[A.n_scales]) return;
+  int s = 1;
+#pragma unroll
+  for (int k = 2; k < SFM_MAX_SCALES; ++k)
+    if (k < A.n_scales && j >= A.begin[k]) s = k;
+  const int jj = j - A.begin[s];
+  const int oW = A.oW[s], oH = A.oH[s], H = A.H, W = A.W;
+  const int oy = jj / oW, ox = jj - oy * oW;
+  const float u = oW > 1 ? (float)((double)ox * ((double)(W - 1) / (double)(oW - 1))) : 0.f;
+  const float v = oH > 1 ? (float)((double)oy * ((double)(H - 1) / (double)(oH - 1))) : 0.f;
+  const int u0 = min(max((int)floorf(u), 0), max(W - 2, 0)), v0 = min(max((int)floorf(v), 0), max(H - 2, 0));
+  const int u1 = min(u0 + 1, W - 1), v1 = min(v0 + 1, H - 1);
+  const float wu1 = u - (float)u0, wv1 = v - (float)v0;
+  const float wu0 = 1.0f - wu1, wv0 = 1.0f - wv1;
+  const float* img = A.x + (size_t)nc * H * W;
+  const float top = img[v0 * W + u0] * wu0 + img[v0 * W + u1] * wu1;
+  const float bot = img[v1 * W + u0] * wu0 + img[v1 * W + u1] * wu1;
+  A.y[s][(size_t)nc * oH * oW + jj] = top * wv0 + bot * wv1;
+}
+
 }  // namespace sfm
 
 using namespace sfm;
@@ -534,6 +571,28 @@ int sfm_sampler_interp_bwd(const float* x, const float* grid, const float* gy, f
   hipLaunchKernelGGL(interp_bwd_kernel, dim3((oH * oW + 255) / 256, N), dim3(256), 0, (hipStream_t)stream, x, grid, gy, ggrid, C,
                      H, W, oH * oW);
   return check_launch("sfm_sampler_interp_bwd");
+}
+
+int sfm_pyramid_fwd(const float* x, float* const* y, int N, int C, int H, int W, int n_scales, void* stream) {
+  if (N == 0) return SFM_OK;   // empty batch: nothing to do, pointers may be NULL
+  SFM_REQUIRE(x && y, SFM_ERR_NULL, "sfm_pyramid_fwd: NULL pointer");
+  SFM_REQUIRE(n_scales >= 1 && n_scales <= SFM_MAX_SCALES, SFM_ERR_SHAPE, "sfm_pyramid_fwd: n_scales=%d", n_scales);
+  SFM_REQUIRE(N >= 0 && C >= 1 && H >= 1 && W >= 1 && (long long)N * C <= 65535, SFM_ERR_SHAPE, "sfm_pyramid_fwd: bad shape");
+  if (n_scales == 1) return SFM_OK;
+  PyramidArgs A;
+  A.x = x; A.H = H; A.W = W; A.n_scales = n_scales;
+  A.begin[0] = A.begin[1] = 0;
+  for (int s = 1; s < n_scales; ++s) {
+    SFM_REQUIRE(y[s], SFM_ERR_NULL, "sfm_pyramid_fwd: y[%d] is NULL", s);
+    A.y[s] = y[s];
+    A.oH[s] = H >> s;                                                   // H // 2**s, base_model.py:70
+    A.oW[s] = W >> s;
+    SFM_REQUIRE(A.oH[s] >= 1 && A.oW[s] >= 1, SFM_ERR_SHAPE, "sfm_pyramid_fwd: scale %d is empty", s);
+    A.begin[s + 1] = A.begin[s] + A.oH[s] * A.oW[s];
+  }
+  const int total = A.begin[n_scales];
+  hipLaunchKernelGGL(pyramid_fwd_kernel, dim3((total + 255) / 256, N * C), dim3(256), 0, (hipStream_t)stream, A);
+  return check_launch("sfm_pyramid_fwd");
 }
 
 int sfm_resize_fwd(const float* x, float* y, int N, int C, int H, int W, int oH, int oW, void* stream) {

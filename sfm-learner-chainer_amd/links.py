@@ -77,11 +77,9 @@ class SFMLearnerLoss:
         do_exp = self.exp_reg is not None and self.exp_reg > 0                 # :61
         if n_sources != len(pred_poses):
             raise TypeError("src_imgs has %d sources but %d poses were given" % (n_sources, len(pred_poses)))
-        tgt_pyr, src_pyr = [], []
-        for ns in range(n_scales):                                             # :69-72
-            curr_img_size = (H // (2 ** ns), W // (2 ** ns))
-            tgt_pyr.append(ops.resize(tgt, curr_img_size) if ns else tgt.contiguous())
-            src_pyr.append(ops.resize(stacked_src_imgs, curr_img_size) if ns else stacked_src_imgs.contiguous())
+        # :69-72 -- curr_tgt_img / curr_src_imgs of every scale, one launch per tensor
+        tgt_pyr = ops.pyramid(tgt, n_scales)
+        src_pyr = ops.pyramid(stacked_src_imgs, n_scales)
         fused = ops.FusedLoss(smooth_reg=self.smooth_reg or 0.0, exp_reg=self.exp_reg or 0.0,
                               ssim_rate=self.ssim_rate or 0.0, smooth_mode=self.smooth_mode)
         fused.bind(tgt_pyr, src_pyr, as_array(intrinsics), [as_array(d) for d in pred_disps],

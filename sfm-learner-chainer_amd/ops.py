@@ -12,7 +12,7 @@ from . import _lib
 from ._lib import SfmLossDesc, check, lib
 
 __all__ = ["pose_proj_fwd", "pose_proj_bwd", "warp_fwd", "warp_bwd", "sampler_fwd", "sampler_bwd",
-           "interp_fwd", "interp_bwd", "resize", "FusedLoss"]
+           "interp_fwd", "interp_bwd", "resize", "pyramid", "FusedLoss"]
 
 
 def _dev(t, name, ndim=None):
@@ -155,6 +155,19 @@ def resize(x, out_hw):
     return y
 
 
+def pyramid(x, n_scales):
+    """[x, resize(x, (H>>1, W>>1)), ...]: all scales of models/base_model.py:69-72 in one launch."""
+    x = _dev(x, "x", 4)
+    N, Cc, H, W = x.shape
+    if not 1 <= n_scales <= _lib.SFM_MAX_SCALES:
+        raise TypeError("n_scales must be in [1, %d]" % _lib.SFM_MAX_SCALES)
+    outs = [x] + [torch.empty((N, Cc, H >> s, W >> s), dtype=torch.float32, device=x.device) for s in range(1, n_scales)]
+    ptrs = (C.c_void_p * n_scales)(*[t.data_ptr() for t in outs])
+    with torch.cuda.device(x.device):
+        check(lib.sfm_pyramid_fwd(_p(x), ptrs, N, Cc, H, W, n_scales, _stream()))
+    return outs
+
+
 class FusedLoss:
     """One bound instance of the fused multi-scale loss (sfm_loss_fwd / _bwd / _fwd_bwd):
     descriptor + caller-owned workspace and outputs.  Re-usable across steps as long as the
@@ -221,7 +234,7 @@ class FusedLoss:
             d.pose[i] = poses[i].data_ptr()
             d_poses.append(torch.empty_like(poses[i]))
             d.d_pose[i] = d_poses[-1].data_ptr()
-        nbytes = lib.sfm_loss_workspace_bytes(C.byref(d))
+        nbytes = lib.sfm_loss_workspace_bytes(C.byref(d)) if B > 0 else 256
         if nbytes == 0:
             check(lib.sfm_loss_fwd(C.byref(d), None, None, 0, None))   # re-run the validation for its message
             raise ValueError(_lib.last_error() or "invalid loss descriptor")

@@ -1,0 +1,106 @@
+"""Edge cases of the fused loss on the GPU, against the oracle: strip / chunk / XCD-mapping
+boundaries, extreme batch and source counts, degenerate geometry."""
+import numpy as np
+import pytest
+
+from oracle import sfm_oracle as O
+from test_loss_gpu import CONFIGS, KEYS, _bind, _check_grads, _check_losses, _oracle
+from util import to_np
+
+pytestmark = pytest.mark.gpu
+CFG = CONFIGS["ssim_smooth"]
+
+
+@pytest.mark.parametrize("B,H,W,n_src,n_scales", [
+    (1, 3, 3, 1, 1),        # smallest legal image
+    (1, 5, 60, 2, 1),       # exactly one gradient strip (64 lanes - 2x2 halo)
+    (1, 5, 61, 2, 1),       # one column into the second strip
+    (1, 16, 120, 1, 1),     # two full strips
+    (9, 16, 24, 2, 2),      # B >= 8: samples striped over the XCDs, one XCD owns two samples
+    (8, 16, 24, 3, 1),      # exactly one sample per XCD
+    (3, 33, 40, 8, 1),      # the maximum number of sources
+    (1, 48, 64, 1, 5),      # five scales (48x64 ... 3x4)
+    (2, 70, 36, 2, 2),      # several row chunks, narrow image
+])
+def test_shapes_at_the_boundaries(ops, synth, dev, B, H, W, n_src, n_scales):
+    d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=n_scales, seed=21)
+    ref = _oracle(d, CFG)
+    fl = _bind(ops, dev, d, CFG)
+    _check_losses(fl.forward(), ref)
+    _check_losses(fl.forward_backward(), ref)
+    _check_grads(fl, ref, n_src)
+
+
+def test_eight_scales_are_accepted(ops, synth, dev):
+    d = synth.make_inputs(B=1, H=384, W=512, n_src=1, n_scales=8, seed=2)     # 384x512 ... 3x4
+    cfg = CONFIGS["l1_smooth"]
+    ref = _oracle(d, cfg)
+    fl = _bind(ops, dev, d, cfg)
+    _check_losses(fl.forward_backward(), ref)
+
+
+def test_empty_batch(ops, synth, dev):
+    import torch
+    d = synth.make_inputs(B=1, H=16, W=24, n_src=2, n_scales=1, seed=2)
+    z = lambda a: torch.zeros((0,) + a.shape[1:], dtype=torch.float32, device=dev)
+    fl = ops.FusedLoss(**CFG).bind([z(a) for a in d["tgt_pyr"]], [z(a) for a in d["src_pyr"]], z(d["intrinsics"]),
+                                   [z(a) for a in d["disps"]], [z(a) for a in d["poses"]], norm_B=4)
+    assert to_np(fl.forward_backward()).tolist() == [0.0] * 5
+
+
+def test_everything_out_of_view_is_masked_not_nan(ops, synth, dev):
+    """a translation that moves every pixel out of the source: I^ == 0 everywhere -> masked
+    (models/base_model.py:96-100), zero photometric loss and gradients, nothing non-finite"""
+    d = synth.make_inputs(B=2, H=16, W=52, n_src=2, n_scales=2, seed=5)
+    for p in d["poses"]:
+        p[:, 3] = 50.0
+    ref = _oracle(d, CFG)
+    fl = _bind(ops, dev, d, CFG)
+    loss = to_np(fl.forward_backward())
+    assert ref["pixel_loss"] == 0.0 and loss[1] == 0.0 and loss[4] == 0.0
+    assert abs(loss[2] - ref["smooth_loss"]) <= 1e-4 * ref["smooth_loss"]
+    for g, w in zip(fl.d_disps, ref["d_disps"]):         # only the smoothness term is left
+        np.testing.assert_allclose(to_np(g), w, rtol=0, atol=2e-5 * np.abs(w).max())
+    for g in fl.d_poses:
+        assert not to_np(g).any()
+
+
+def test_rotation_angles_are_clipped_at_pi(ops, synth, dev):
+    """F.clip(r, -pi, pi) (models/transform.py:23): angles beyond +-pi behave like +-pi and get no gradient"""
+    d = synth.make_inputs(B=2, H=16, W=52, n_src=1, n_scales=1, seed=5)
+    d["poses"][0][0, 2] = 4.0          # rz > pi for sample 0
+    ref = _oracle(d, CFG)
+    fl = _bind(ops, dev, d, CFG)
+    _check_losses(fl.forward_backward(), ref)
+    g = to_np(fl.d_poses[0])
+    assert g[0, 2] == 0.0 and ref["d_poses"][0][0, 2] == 0.0
+
+
+def test_extreme_disparities(ops, synth, dev):
+    """DispNet's output range is (0.01, 10.01) (models/disp_net.py:7-8): depth from 0.1 to 100"""
+    d = synth.make_inputs(B=2, H=16, W=52, n_src=2, n_scales=1, seed=7)
+    rng = np.random.RandomState(0)
+    d["disps"][0][:] = np.where(rng.rand(*d["disps"][0].shape) < 0.5, 0.0101, 10.0).astype(np.float32)
+    cfg = CONFIGS["l1"]
+    ref = _oracle(d, cfg)
+    fl = _bind(ops, dev, d, cfg)
+    _check_losses(fl.forward_backward(), ref)
+    for x in fl.d_disps + fl.d_poses:
+        assert np.isfinite(to_np(x)).all()
+
+
+def test_high_resolution_config5_shape(ops, synth, dev):
+    """BASELINE.json configs[4]: 256x832, 4 scales, 5-frame snippet (4 sources), at B=1"""
+    d = synth.make_inputs(B=1, H=256, W=832, n_src=4, n_scales=4, seed=1)
+    ref = _oracle(d, CFG)
+    fl = _bind(ops, dev, d, CFG)
+    _check_losses(fl.forward_backward(), ref)
+    _check_grads(fl, ref, 4, check_pose=False)
+    # d_pose sums 283k signed per-pixel terms whose magnitudes exceed the sum by orders of magnitude, so fp32
+    # evaluations of the SAME formula differ at the 1e-3 level (the fp32 oracle included): judge the kernel
+    # against the fp64 oracle, allowing twice the fp32 oracle's own error
+    ref64 = O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], backward=True, dtype=np.float64, **CFG)
+    for i in range(4):
+        got, w32, w64 = to_np(fl.d_poses[i]).astype(np.float64), ref["d_poses"][i], ref64["d_poses"][i]
+        tol = np.maximum(2e-3 * np.abs(w64).max(), 2 * np.abs(w32 - w64))
+        assert (np.abs(got - w64) <= tol).all(), (i, got, w64, w32)

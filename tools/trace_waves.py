@@ -64,3 +64,12 @@ if stamps:
             print("finish-rank %d: n=%d dur %.0fk cyc | loop %.0fk (%.0f/step, steps %.1f) smooth %.0fk other %.0fk | A.fin %.0f A.iss %.0f B %.0f C %.0f per step" % (
                 rk, m.sum(), dur_cyc[m].mean() / 1e3, loop[m].mean() / 1e3, (loop[m] / b[m, 4]).mean(), b[m, 4].mean(), sm[m].mean() / 1e3,
                 (dur_cyc[m] - loop[m] - sm[m]).mean() / 1e3, (b[m, 0] / b[m, 4]).mean(), (b[m, 1] / b[m, 4]).mean(), (b[m, 2] / b[m, 4]).mean(), (b[m, 3] / b[m, 4]).mean()))
+# per-SIMD completion times: is the launch limited by throughput (all SIMDs end together) or by imbalance?
+simd_end = np.array([en[key == kk].max() for kk in u])
+simd_work = np.array([(en - st)[key == kk].sum() for kk in u])
+print("SIMD completion time: min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f us" % tuple(np.percentile(simd_end, [0, 10, 50, 90, 100])))
+xk = (u // 100000)
+for x in range(8):
+    m = xk == x
+    if m.any():
+        print("  XCD %d: SIMDs %d, completion p50 %.1f max %.1f us, waves %d" % (x, m.sum(), np.percentile(simd_end[m], 50), simd_end[m].max(), cnt[m].sum()))
