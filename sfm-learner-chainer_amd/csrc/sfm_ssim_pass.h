@@ -160,35 +160,34 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const int r, con
     // separable 3x3 sums around (r-1, x): vertical over the ring rows r-2..r (in-lane), then horizontal (DPP)
     const float Sx = hsum3(s2.ih[c] + s1.ih[c] + s0.ih[c]);
     const float Sy = hsum3(s2.it[c] + s1.it[c] + s0.it[c]);
-    const float Sxx = hsum3(fmaf(s2.ih[c], s2.ih[c], fmaf(s1.ih[c], s1.ih[c], s0.ih[c] * s0.ih[c])));
-    const float Syy = hsum3(fmaf(s2.it[c], s2.it[c], fmaf(s1.it[c], s1.it[c], s0.it[c] * s0.it[c])));
+    // sigma_x + sigma_y only ever appear together (base_model.py:138), so E[xx] and E[yy] are pooled as one field
+    const float Sqq = hsum3(fmaf(s2.ih[c], s2.ih[c], fmaf(s1.ih[c], s1.ih[c], fmaf(s0.ih[c], s0.ih[c],
+                            fmaf(s2.it[c], s2.it[c], fmaf(s1.it[c], s1.it[c], s0.it[c] * s0.it[c]))))));
     const float Sxy = hsum3(fmaf(s2.ih[c], s2.it[c], fmaf(s1.ih[c], s1.it[c], s0.ih[c] * s0.it[c])));
     const float pxy = Sx * Sy;
     const float sq = fmaf(Sx, Sx, Sy * Sy);
     const float N1 = fmaf(2.f, pxy, C1);
     const float N2 = fmaf(-2.f, pxy, fmaf(18.f, Sxy, C2));
     const float D1 = sq + C1;
-    const float D2 = fmaf(9.f, Sxx + Syy, C2) - sq;
+    const float D2 = fmaf(9.f, Sqq, C2) - sq;
     const float rD = rcp(D1 * D2);
     const float Sv = N1 * N2 * rD;                                  // base_model.py:140
     const float e = fmaf(-0.5f, Sv, 0.5f);                          // (1 - SSIM) / 2, base_model.py:142
     if (LOSS) ssum += fminf(fmaxf(e, 0.f), 1.f);
     if (GRAD) {
       // kappa = dL/dS at this pixel; s1.nm is 0 outside the image and on masked pixels (base_model.py:114)
-      const float kap = (e > 0.f && e < 1.f) ? C.kq * s1.nm * rD : 0.f;      // F.clip backward
+      const float kap = (e * (1.f - e) > 0.f) ? C.kq * s1.nm * rD : 0.f;     // F.clip backward: 0 < e < 1
       const float u3 = fmaf(-(Sv * Sx), D2 - D1, Sy * (N2 - N1));
       g0.a[c] = hsum3(2.f * kap * u3);              // (1/9) kappa dS/dmu_x
       g0.b[c] = hsum3(-9.f * kap * Sv * D1);        // (1/9) kappa dS/dE[xx]
       g0.e[c] = hsum3(18.f * kap * N1);             // (1/9) kappa dS/dE[xy]
     }
   }
-  if (LOSS) {
-    if (rb >= C.y0 && rb < C.y1) {
-      const float wgt = s1.nm * C.outf;
-      acc_ssim = fmaf(ssum, wgt, acc_ssim);                          // base_model.py:114-115
-      const float e1 = fabsf(s1.ih[0] - s1.it[0]) + fabsf(s1.ih[1] - s1.it[1]) + fabsf(s1.ih[2] - s1.it[2]);   // :95
-      acc_pix = fmaf(e1, wgt, acc_pix);                              // :98-100,:111
-    }
+  if (LOSS) {   // branch-free: a halo row simply gets weight 0 (a branch here would split the block and un-fold the DPP adds)
+    const float wgt = (rb >= C.y0 && rb < C.y1) ? s1.nm * C.outf : 0.f;
+    acc_ssim = fmaf(ssum, wgt, acc_ssim);                            // base_model.py:114-115
+    const float e1 = fabsf(s1.ih[0] - s1.it[0]) + fabsf(s1.ih[1] - s1.it[1]) + fabsf(s1.ih[2] - s1.it[2]);   // :95
+    acc_pix = fmaf(e1, wgt, acc_pix);                                // :98-100,:111
   }
 
   SFM_STAMP(t3);
