@@ -674,35 +674,34 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 __global__ void __launch_bounds__(64) finalize_kernel(const LossArgs A, float* __restrict__ loss5, const int n_pose_blocks) {
   const int lane = threadIdx.x;
   if ((int)blockIdx.x < n_pose_blocks) {
-    // d_pose of (b, i): every lane folds its tiles of every scale into K_s^T . gPm (linear), ONE wave reduction at the end
+    // d_pose of (b, i): every lane folds its tiles of every scale into K_s^T . gPm (linear), ONE in-register
+    // wave reduction at the end (DPP; a shuffle butterfly on doubles costs ~150 LDS-crossbar round trips)
     const int b = blockIdx.x / A.n_src, i = blockIdx.x - b * A.n_src;
-    double gT3[12];
+    float gT3[12];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) gT3[k] = 0.0;
-    for (int s = 0; s < A.n_scales; ++s) {
-      const ScaleArgs& S = A.sc[s];
-      const int beg = S.item_begin + b * S.tiles;
-      float g[12];
+    for (int k = 0; k < 12; ++k) gT3[k] = 0.f;
+    // all (scale, tile) pairs of this sample as one index space: independent loads, no per-scale round trips
+    int total = 0;
+    for (int s = 0; s < A.n_scales; ++s) total += A.sc[s].tiles;
+    for (int idx = lane; idx < total; idx += 64) {
+      int s = 0, off = 0;
 #pragma unroll
-      for (int k = 0; k < 12; ++k) g[k] = 0.f;
-      for (int t = lane; t < S.tiles; t += 64) {
-        const float4* p = reinterpret_cast<const float4*>(A.part_gpm + ((size_t)(beg + t) * A.n_src + i) * 12);
-        const float4 v0 = p[0], v1 = p[1], v2 = p[2];
-        g[0] += v0.x; g[1] += v0.y; g[2] += v0.z; g[3] += v0.w;
-        g[4] += v1.x; g[5] += v1.y; g[6] += v1.z; g[7] += v1.w;
-        g[8] += v2.x; g[9] += v2.y; g[10] += v2.z; g[11] += v2.w;
-      }
+      for (int k = 0; k < SFM_MAX_SCALES - 1; ++k)
+        if (k + 1 < A.n_scales && idx >= off + A.sc[k].tiles && s == k) { off += A.sc[k].tiles; s = k + 1; }
+      const int t = idx - off;
+      const float4* p = reinterpret_cast<const float4*>(A.part_gpm + ((size_t)(A.sc[s].item_begin + b * A.sc[s].tiles + t) * A.n_src + i) * 12);
+      const float4 v0 = p[0], v1 = p[1], v2 = p[2];
+      const float g[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
       const float* K = A.intrinsics + ((size_t)b * A.n_scales + s) * 9;
       // gT3 += K^T . gPm   (K4^T . gPm of the rows that reach R and t)
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-          gT3[r * 4 + c] += (double)K[0 * 3 + r] * g[0 * 4 + c] + (double)K[1 * 3 + r] * g[1 * 4 + c] + (double)K[2 * 3 + r] * g[2 * 4 + c];
+        for (int c = 0; c < 4; ++c) gT3[r * 4 + c] += K[0 * 3 + r] * g[0 * 4 + c] + K[1 * 3 + r] * g[1 * 4 + c] + K[2 * 3 + r] * g[2 * 4 + c];
     }
     float gT[12];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) gT[k] = (float)wave_sum_d(gT3[k]);
+    for (int k = 0; k < 12; ++k) gT[k] = wave_sum(gT3[k]);
     if (lane == 0) {
       float d[6];
       pose_backward(A.pose[i] + b * 6, gT, d);
@@ -712,6 +711,8 @@ __global__ void __launch_bounds__(64) finalize_kernel(const LossArgs A, float* _
     return;
   }
   if (loss5 == nullptr) return;
+  // the five reported scalars: per-lane fp64 partial sums over the items, then a fixed-order in-register
+  // wave reduction of (hi, lo) float pairs (DPP), recombined in fp64
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   const float4* pl = reinterpret_cast<const float4*>(A.part_loss);
 #pragma unroll 8
@@ -719,10 +720,15 @@ __global__ void __launch_bounds__(64) finalize_kernel(const LossArgs A, float* _
     const float4 v = pl[t];
     acc[0] += (double)v.x; acc[1] += (double)v.y; acc[2] += (double)v.z; acc[3] += (double)v.w;
   }
+  double red[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) acc[k] = wave_sum_d(acc[k]);
+  for (int k = 0; k < 4; ++k) {
+    const float hi = (float)acc[k];
+    const float lo = (float)(acc[k] - (double)hi);
+    red[k] = (double)wave_sum(hi) + (double)wave_sum(lo);
+  }
   if (lane == 0) {
-    const double pixel = acc[0], ssim = acc[1], smooth = acc[2], expl = acc[3];
+    const double pixel = red[0], ssim = red[1], smooth = red[2], expl = red[3];
     const double a = (double)A.alpha;
     loss5[0] = (float)((1.0 - a) * pixel + a * ssim + smooth + expl);   // base_model.py:117-118
     loss5[1] = (float)pixel;
