@@ -163,6 +163,15 @@ int sfm_resize_fwd(const float *x, float *y, int N, int C, int H, int W, int oH,
  * the full-resolution input (as the reference does); y[0] is ignored (scale 0 is x itself). */
 int sfm_pyramid_fwd(const float *x, float *const *y, int N, int C, int H, int W, int n_scales, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * DispNet's output activation for all scales in one launch, models/disp_net.py:7-8 and
+ * :104,:110,:116,:122:  disp = 10 * sigmoid(x) + 0.01.  numel[s] = elements of scale s.
+ * Backward: g_x = g_disp * 10 * s * (1 - s), s recovered from disp (overwrites g_x).
+ * ---------------------------------------------------------------------------------------- */
+int sfm_disp_act_fwd(const float *const *x, float *const *disp, const long long *numel, int n_scales, void *stream);
+int sfm_disp_act_bwd(const float *const *disp, const float *const *g_disp, float *const *g_x, const long long *numel,
+                     int n_scales, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,8 @@ SYMBOLS = {
     "sfm_loss_profile_events": (_I, [_V, _V]),
     "sfm_loss_debug_trace": (_I, [_V]),
     "sfm_resize_fwd": (_I, [_FP, _FP, _I, _I, _I, _I, _I, _I, _V]),
+    "sfm_disp_act_fwd": (_I, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_longlong), _I, _V]),
+    "sfm_disp_act_bwd": (_I, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_longlong), _I, _V]),
     "sfm_pyramid_fwd": (_I, [_FP, C.POINTER(C.c_void_p), _I, _I, _I, _I, _I, _V]),
 }
 

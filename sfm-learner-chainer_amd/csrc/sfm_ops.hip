@@ -6,6 +6,11 @@
 
 #include "sfm_common.h"
 
+#define SFM_REQUIRE(cond, code, ...) \
+  do {                               \
+    if (!(cond)) return fail(code, __VA_ARGS__); \
+  } while (0)
+
 namespace sfm {
 
 static thread_local char g_err[512] = "";
@@ -444,6 +449,59 @@ __global__ void pyramid_fwd_kernel(const PyramidArgs A) {
   A.y[s][(size_t)nc * oH * oW + jj] = top * wv0 + bot * wv1;
 }
 
+// ------------------------------------------------------------------------------------------
+// DispNet's output activation at all scales in one launch (models/disp_net.py:7-8,104,110,116,122):
+//   disp = DISP_SCALING * sigmoid(x) + MIN_DISP ;  g_x = g_disp * DISP_SCALING * s (1 - s), s = (disp - MIN_DISP) / DISP_SCALING
+// ------------------------------------------------------------------------------------------
+struct ActArgs {
+  const float* a[SFM_MAX_SCALES];   // fwd: x        bwd: disp
+  const float* g[SFM_MAX_SCALES];   //               bwd: g_disp
+  float* o[SFM_MAX_SCALES];         // fwd: disp     bwd: g_x
+  long long begin[SFM_MAX_SCALES + 1];
+  int n_scales;
+};
+constexpr float DISP_SCALING = 10.f, MIN_DISP = 0.01f;
+
+template <bool BWD>
+__global__ void disp_act_kernel(const ActArgs A) {
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= A.begin[A.n_scales]) return;
+  int s = 0;
+#pragma unroll
+  for (int k = 1; k < SFM_MAX_SCALES; ++k)
+    if (k < A.n_scales && j >= A.begin[k]) s = k;
+  const long long jj = j - A.begin[s];
+  if (!BWD) {
+    const float x = A.a[s][jj];
+    A.o[s][jj] = DISP_SCALING * (1.0f / (1.0f + expf(-x))) + MIN_DISP;
+  } else {
+    const float sg = (A.a[s][jj] - MIN_DISP) * (1.0f / DISP_SCALING);
+    A.o[s][jj] = A.g[s][jj] * DISP_SCALING * sg * (1.0f - sg);
+  }
+}
+
+static int disp_act_launch(bool bwd, const float* const* a, const float* const* g, float* const* o, const long long* numel,
+                           int n_scales, void* stream, const char* who) {
+  SFM_REQUIRE(a && o && numel && (!bwd || g), SFM_ERR_NULL, "%s: NULL pointer", who);
+  SFM_REQUIRE(n_scales >= 1 && n_scales <= SFM_MAX_SCALES, SFM_ERR_SHAPE, "%s: n_scales=%d", who, n_scales);
+  ActArgs A;
+  A.n_scales = n_scales;
+  A.begin[0] = 0;
+  for (int s = 0; s < n_scales; ++s) {
+    SFM_REQUIRE(numel[s] >= 0, SFM_ERR_SHAPE, "%s: numel[%d] < 0", who, s);
+    SFM_REQUIRE(numel[s] == 0 || (a[s] && o[s] && (!bwd || g[s])), SFM_ERR_NULL, "%s: NULL array at scale %d", who, s);
+    A.a[s] = a[s]; A.g[s] = bwd ? g[s] : nullptr; A.o[s] = o[s];
+    A.begin[s + 1] = A.begin[s] + numel[s];
+  }
+  const long long total = A.begin[n_scales];
+  if (total == 0) return SFM_OK;
+  SFM_REQUIRE(total < (1ll << 40), SFM_ERR_SHAPE, "%s: too large", who);
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (bwd) hipLaunchKernelGGL(disp_act_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, A);
+  else hipLaunchKernelGGL(disp_act_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, A);
+  return check_launch(who);
+}
+
 }  // namespace sfm
 
 using namespace sfm;
@@ -453,10 +511,6 @@ extern "C" {
 int sfm_abi_version(void) { return SFM_ABI_VERSION; }
 const char* sfm_last_error(void) { return sfm::g_err; }
 
-#define SFM_REQUIRE(cond, code, ...) \
-  do {                               \
-    if (!(cond)) return fail(code, __VA_ARGS__); \
-  } while (0)
 
 int sfm_pose_proj_fwd(const float* pose6, const float* K, float* proj, int N, void* stream) {
   if (N == 0) return SFM_OK;   // empty batch: nothing to do, pointers may be NULL
@@ -593,6 +647,15 @@ int sfm_pyramid_fwd(const float* x, float* const* y, int N, int C, int H, int W,
   const int total = A.begin[n_scales];
   hipLaunchKernelGGL(pyramid_fwd_kernel, dim3((total + 255) / 256, N * C), dim3(256), 0, (hipStream_t)stream, A);
   return check_launch("sfm_pyramid_fwd");
+}
+
+int sfm_disp_act_fwd(const float* const* x, float* const* disp, const long long* numel, int n_scales, void* stream) {
+  return disp_act_launch(false, x, nullptr, disp, numel, n_scales, stream, "sfm_disp_act_fwd");
+}
+
+int sfm_disp_act_bwd(const float* const* disp, const float* const* g_disp, float* const* g_x, const long long* numel,
+                     int n_scales, void* stream) {
+  return disp_act_launch(true, disp, g_disp, g_x, numel, n_scales, stream, "sfm_disp_act_bwd");
 }
 
 int sfm_resize_fwd(const float* x, float* y, int N, int C, int H, int W, int oH, int oW, void* stream) {

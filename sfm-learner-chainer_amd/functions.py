@@ -17,7 +17,7 @@ from .chainer_surface import Function, Variable, argument, as_array, type_check
 
 __all__ = ["SpatialTransformerSamplerInterp", "spatial_transformer_sampler_interp", "SpatialTransformerSampler",
            "spatial_transformer_sampler", "ProjTgtToSrc", "proj_tgt_to_src", "ProjectiveInverseWarp",
-           "projective_inverse_warp", "resize_images"]
+           "projective_inverse_warp", "resize_images", "DispActivation", "disp_activation"]
 
 
 def _sampler_type_check(in_types):
@@ -154,3 +154,27 @@ def resize_images(x, output_shape):
     """F.resize_images(x, (out_H, out_W)): bilinear, align-corners; returns a Variable whose
     `.data` is what the reference takes (base_model.py:71-72)."""
     return Variable(ops.resize(as_array(x), output_shape), requires_grad=False)
+
+
+class DispActivation(Function):
+    """DISP_SCALING * F.sigmoid(x) + MIN_DISP for the disparity logits of all scales at once
+    (models/disp_net.py:7-8,104,110,116,122): n inputs -> n outputs, one launch each way."""
+
+    def check_type_forward(self, in_types):
+        type_check.expect(in_types.size() >= 1)
+        for t in in_types:
+            type_check.expect(t.dtype.char == 'f')
+
+    def forward_gpu(self, inputs):
+        self._disps = ops.disp_act_fwd(list(inputs))
+        return tuple(self._disps)
+
+    def backward_gpu(self, inputs, grad_outputs):
+        gs = [g if g is not None else torch.zeros_like(d) for g, d in zip(grad_outputs, self._disps)]
+        return tuple(ops.disp_act_bwd(self._disps, gs))
+
+
+def disp_activation(xs):
+    """[10 * sigmoid(x) + 0.01 for x in xs] -> list of Variables"""
+    out = DispActivation()(*xs)
+    return list(out) if isinstance(out, tuple) else [out]

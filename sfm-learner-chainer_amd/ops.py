@@ -12,7 +12,7 @@ from . import _lib
 from ._lib import SfmLossDesc, check, lib
 
 __all__ = ["pose_proj_fwd", "pose_proj_bwd", "warp_fwd", "warp_bwd", "sampler_fwd", "sampler_bwd",
-           "interp_fwd", "interp_bwd", "resize", "pyramid", "FusedLoss"]
+           "interp_fwd", "interp_bwd", "resize", "pyramid", "disp_act_fwd", "disp_act_bwd", "FusedLoss"]
 
 
 def _dev(t, name, ndim=None):
@@ -165,6 +165,32 @@ def pyramid(x, n_scales):
     ptrs = (C.c_void_p * n_scales)(*[t.data_ptr() for t in outs])
     with torch.cuda.device(x.device):
         check(lib.sfm_pyramid_fwd(_p(x), ptrs, N, Cc, H, W, n_scales, _stream()))
+    return outs
+
+
+def _ptr_array(ts):
+    return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def disp_act_fwd(xs):
+    """[10 * sigmoid(x) + 0.01 for x in xs] in one launch (models/disp_net.py:104-122)."""
+    xs = [_dev(x, "xs[%d]" % k) for k, x in enumerate(xs)]
+    outs = [torch.empty_like(x) for x in xs]
+    n = (C.c_longlong * len(xs))(*[x.numel() for x in xs])
+    with torch.cuda.device(xs[0].device):
+        check(lib.sfm_disp_act_fwd(_ptr_array(xs), _ptr_array(outs), n, len(xs), _stream()))
+    return outs
+
+
+def disp_act_bwd(disps, g_disps):
+    disps = [_dev(x, "disps[%d]" % k) for k, x in enumerate(disps)]
+    g_disps = [_dev(x, "g_disps[%d]" % k) for k, x in enumerate(g_disps)]
+    if any(a.shape != b.shape for a, b in zip(disps, g_disps)):
+        raise TypeError("g_disps must match disps")
+    outs = [torch.empty_like(x) for x in disps]
+    n = (C.c_longlong * len(disps))(*[x.numel() for x in disps])
+    with torch.cuda.device(disps[0].device):
+        check(lib.sfm_disp_act_bwd(_ptr_array(disps), _ptr_array(g_disps), _ptr_array(outs), n, len(disps), _stream()))
     return outs
 
 

@@ -126,3 +126,43 @@ def test_loss_link_without_backprop_and_with_upstream_gradient(synth, dev):
     l2.grad = torch.full((), 3.0, device=dev)            # e.g. a loss scale
     l2.backward()
     np.testing.assert_allclose(to_np(disps2[0].grad), 3.0 * g1, rtol=1e-6, atol=1e-12)
+
+
+def test_disp_activation_all_scales_in_one_launch(dev):
+    """models/disp_net.py:104-122 and its backward; chained in front of the loss link the gradient lands
+    on the raw network outputs"""
+    rng = np.random.RandomState(0)
+    xs_np = [rng.normal(0, 2, (2, 1, 32 >> s, 52 >> s)).astype(np.float32) for s in range(3)]
+    xs = [cs.Variable(to_dev(a, dev)) for a in xs_np]
+    disps = fn.disp_activation(xs)
+    for d, x in zip(disps, xs_np):
+        np.testing.assert_allclose(to_np(d.data), 10.0 / (1.0 + np.exp(-x.astype(np.float64))) + 0.01, rtol=2e-6)
+        assert d.data.min() > 0.01 and d.data.max() < 10.01
+    g_np = [rng.normal(size=a.shape).astype(np.float32) for a in xs_np]
+    for d, g in zip(disps, g_np):
+        d.grad = to_dev(g, dev)
+    disps[0].backward()
+    for x, xn, g in zip(xs, xs_np, g_np):
+        sg = 1.0 / (1.0 + np.exp(-xn.astype(np.float64)))
+        np.testing.assert_allclose(to_np(x.grad), g * 10.0 * sg * (1 - sg), rtol=2e-4, atol=1e-6)
+
+
+def test_loss_gradient_reaches_the_disparity_logits(synth, dev):
+    d = synth.make_inputs(B=2, H=32, W=52, n_src=2, n_scales=2, seed=3)
+    logits_np = [np.log((a - 0.01) / (10.01 - a)).astype(np.float32) for a in d["disps"]]     # inverse of the activation
+    logits = [cs.Variable(to_dev(a, dev)) for a in logits_np]
+    disps = fn.disp_activation(logits)
+    poses = [cs.Variable(to_dev(a, dev)) for a in d["poses"]]
+    link = links.SFMLearnerLoss({"smooth_reg": 0.1, "exp_reg": 0, "seq_len": 3, "ssim_rate": 0.15})
+    K = to_dev(d["intrinsics"], dev)
+    loss = link(to_dev(d["tgt"], dev), to_dev(d["src"], dev), K, K, disps, poses)
+    loss.backward()
+    disp_np = [10.0 / (1.0 + np.exp(-a.astype(np.float64))) + 0.01 for a in logits_np]
+    ref = O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], [a.astype(np.float32) for a in disp_np], d["poses"],
+                     backward=True, smooth_reg=0.1, ssim_rate=0.15)
+    assert abs(float(loss.data) - ref.total_loss) <= 2e-4 * abs(ref.total_loss)
+    for s in range(2):
+        sg = (disp_np[s] - 0.01) / 10.0
+        want = ref.d_disps[s] * 10.0 * sg * (1 - sg)
+        err = np.abs(to_np(logits[s].grad) - want)
+        assert (err > 3e-3 * np.abs(want).max()).mean() < 0.02
