@@ -172,6 +172,16 @@ int sfm_disp_act_fwd(const float *const *x, float *const *disp, const long long 
 int sfm_disp_act_bwd(const float *const *disp, const float *const *g_disp, float *const *g_x, const long long *numel,
                      int n_scales, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * data_augmentation(), datasets/kitti/kitti_raw_transformed.py:23-74, image side: random scaling
+ * (:32-45, F.resize_images to (scaled_h, scaled_w)), random crop back to (H,W) at (offset_y,
+ * offset_x) (:48-59) and horizontal flip (:62-67) as ONE gather per output pixel.
+ *   imgs (B,F,C,H,W): target + sources of each sample ; out the same shape ;
+ *   params (B,5) float: scaled_h, scaled_w, offset_y, offset_x, flip (0/1), drawn on the host in the
+ *   reference's order (the intrinsics update :41-44,:54-57,:66 is 4 scalars per sample, host side).
+ * ---------------------------------------------------------------------------------------- */
+int sfm_augment_fwd(const float *imgs, const float *params, float *out, int B, int F, int C, int H, int W, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

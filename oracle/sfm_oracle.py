@@ -43,7 +43,7 @@ __all__ = [
     "interp_sampler_forward", "interp_sampler_backward", "projective_inverse_warp",
     "projective_inverse_warp_backward", "resize_images", "average_pooling_3x3",
     "compute_ssim", "compute_smooth_loss", "compute_disp_smooth", "compute_exp_reg_loss",
-    "get_multi_scale_intrinsics", "sfm_loss", "SfmLossResult",
+    "get_multi_scale_intrinsics", "sfm_loss", "SfmLossResult", "data_augmentation",
 ]
 
 
@@ -705,3 +705,25 @@ def sfm_loss(tgt_pyr, src_pyr, intrinsics, disps, poses, masks=None, *,
     if keep_warped:
         res.update(warped=warped_all, margin=margin_all, cell_margin=cell_all, abs_margin=abs_all, clip_margin=clip_all)
     return res
+
+
+# --------------------------------------------------------------------------------------
+# data augmentation (datasets/kitti/kitti_raw_transformed.py:23-74), one sample, explicit parameters
+# --------------------------------------------------------------------------------------
+def data_augmentation(tgt_img, src_imgs, intrinsics, x_scaling, y_scaling, offset_y, offset_x, flip, dtype=np.float32):
+    """tgt (3,H,W), src (S,3,H,W), K (3,3) with the random draws of :34,:50-51,:64 passed in.
+    -> (tgt, src, K) exactly as the reference composes them: resize -> crop -> flip."""
+    _, out_h, out_w = tgt_img.shape
+    imgs = np.concatenate((tgt_img[np.newaxis, :], src_imgs)).astype(dtype)        # :70
+    K = np.asarray(intrinsics, dtype='f')
+    in_h, in_w = imgs.shape[2:]
+    sh, sw = int(in_h * y_scaling), int(in_w * x_scaling)                           # :37-38
+    imgs = resize_images(imgs, (sh, sw), dtype)                                     # :39
+    K = np.array([[K[0, 0] * x_scaling, 0., K[0, 2] * x_scaling],
+                  [0., K[1, 1] * y_scaling, K[1, 2] * y_scaling], [0., 0., 1.]], dtype='f')   # :40-44
+    imgs = imgs[:, :, offset_y:offset_y + out_h, offset_x:offset_x + out_w]         # :52
+    K = np.array([[K[0, 0], 0., K[0, 2] - offset_x], [0., K[1, 1], K[1, 2] - offset_y], [0., 0., 1.]], dtype='f')   # :53-58
+    if flip:                                                                         # :64-66
+        imgs = imgs[:, :, :, ::-1]
+        K[0, 2] = imgs.shape[3] - K[0, 2]
+    return imgs[0], imgs[1:], K

@@ -66,6 +66,7 @@ SYMBOLS = {
     "sfm_resize_fwd": (_I, [_FP, _FP, _I, _I, _I, _I, _I, _I, _V]),
     "sfm_disp_act_fwd": (_I, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_longlong), _I, _V]),
     "sfm_disp_act_bwd": (_I, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_longlong), _I, _V]),
+    "sfm_augment_fwd": (_I, [_FP, _FP, _FP, _I, _I, _I, _I, _I, _V]),
     "sfm_pyramid_fwd": (_I, [_FP, C.POINTER(C.c_void_p), _I, _I, _I, _I, _I, _V]),
 }
 

@@ -450,6 +450,35 @@ __global__ void pyramid_fwd_kernel(const PyramidArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------
+// data_augmentation (datasets/kitti/kitti_raw_transformed.py:23-74) as one gather: random scaling
+// (F.resize_images to (int(H*ys), int(W*xs)), :32-45), random crop back to (H, W) at (oy, ox) (:48-59)
+// and horizontal flip (:62-67), for all frames of a sample with the sample's parameters.
+//   params (B,5): scaled_h, scaled_w, offset_y, offset_x, flip   (integers stored as float)
+// ------------------------------------------------------------------------------------------
+__global__ void augment_fwd_kernel(const float* __restrict__ x, const float* __restrict__ params, float* __restrict__ y,
+                                   int planes_per_sample, int H, int W) {
+#pragma clang fp contract(off)
+  const int plane = blockIdx.y;                       // (sample, frame, channel)
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= H * W) return;
+  const float* p = params + (plane / planes_per_sample) * 5;
+  const int H2 = (int)p[0], W2 = (int)p[1], oy = (int)p[2], ox = (int)p[3];
+  const bool flip = p[4] != 0.f;
+  const int yo = j / W, xo = j - yo * W;
+  const int Y = yo + oy, X = (flip ? (W - 1 - xo) : xo) + ox;          // position in the scaled image
+  const float u = W2 > 1 ? (float)((double)X * ((double)(W - 1) / (double)(W2 - 1))) : 0.f;
+  const float v = H2 > 1 ? (float)((double)Y * ((double)(H - 1) / (double)(H2 - 1))) : 0.f;
+  const int u0 = min(max((int)floorf(u), 0), max(W - 2, 0)), v0 = min(max((int)floorf(v), 0), max(H - 2, 0));
+  const int u1 = min(u0 + 1, W - 1), v1 = min(v0 + 1, H - 1);
+  const float wu1 = u - (float)u0, wv1 = v - (float)v0;
+  const float wu0 = 1.0f - wu1, wv0 = 1.0f - wv1;
+  const float* img = x + (size_t)plane * H * W;
+  const float top = img[v0 * W + u0] * wu0 + img[v0 * W + u1] * wu1;
+  const float bot = img[v1 * W + u0] * wu0 + img[v1 * W + u1] * wu1;
+  y[(size_t)plane * H * W + j] = top * wv0 + bot * wv1;
+}
+
+// ------------------------------------------------------------------------------------------
 // DispNet's output activation at all scales in one launch (models/disp_net.py:7-8,104,110,116,122):
 //   disp = DISP_SCALING * sigmoid(x) + MIN_DISP ;  g_x = g_disp * DISP_SCALING * s (1 - s), s = (disp - MIN_DISP) / DISP_SCALING
 // ------------------------------------------------------------------------------------------
@@ -647,6 +676,16 @@ int sfm_pyramid_fwd(const float* x, float* const* y, int N, int C, int H, int W,
   const int total = A.begin[n_scales];
   hipLaunchKernelGGL(pyramid_fwd_kernel, dim3((total + 255) / 256, N * C), dim3(256), 0, (hipStream_t)stream, A);
   return check_launch("sfm_pyramid_fwd");
+}
+
+int sfm_augment_fwd(const float* imgs, const float* params, float* out, int B, int F, int C, int H, int W, void* stream) {
+  if (B == 0) return SFM_OK;
+  SFM_REQUIRE(imgs && params && out, SFM_ERR_NULL, "sfm_augment_fwd: NULL pointer");
+  SFM_REQUIRE(B >= 0 && F >= 1 && C >= 1 && H >= 1 && W >= 1 && (long long)B * F * C <= 65535, SFM_ERR_SHAPE,
+              "sfm_augment_fwd: bad shape B=%d F=%d C=%d H=%d W=%d", B, F, C, H, W);
+  hipLaunchKernelGGL(augment_fwd_kernel, dim3((H * W + 255) / 256, B * F * C), dim3(256), 0, (hipStream_t)stream, imgs, params,
+                     out, F * C, H, W);
+  return check_launch("sfm_augment_fwd");
 }
 
 int sfm_disp_act_fwd(const float* const* x, float* const* disp, const long long* numel, int n_scales, void* stream) {
