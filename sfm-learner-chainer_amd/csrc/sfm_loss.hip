@@ -208,306 +208,6 @@ __device__ __forceinline__ void smooth_edge_pass(const LossArgs& A, const ScaleA
 }
 
 // ------------------------------------------------------------------------------------------
-// photometric pass for one source
-// ------------------------------------------------------------------------------------------
-struct RowA {        // what stage A leaves behind for a row (per lane = per pixel)
-  float ih[3];       // warped source I^
-  float it[3];       // target I
-  float du[3], dv[3];// dI^/du, dI^/dv
-  float U, V, rz, D; // projection (for the geometry backward)
-  float inv;         // 1 if the pixel is in view, else 0
-  float sg;          // sigmoid(explainability logit)   (EXPL only)
-};
-
-__device__ __forceinline__ void zero_row(RowA& r) {
-#pragma unroll
-  for (int c = 0; c < 3; ++c) r.ih[c] = r.it[c] = r.du[c] = r.dv[c] = 0.f;
-  r.U = r.V = r.rz = r.D = r.inv = r.sg = 0.f;
-}
-
-struct SrcConst {    // per (wave, source): uniform geometry in SGPRs + per-lane hoisted x terms
-  float M1[3], P3[3], K1[3];   // uniform: M[k][1], P[k][3], Kinv[j][1]
-  float mx[3], kx[3];          // per lane: M[k][0]*x + M[k][2],  Kinv[j][0]*x + Kinv[j][2]
-};
-
-template <bool SSIM, bool GRAD, bool LOSS, bool EXPL>
-__device__ __forceinline__ void source_pass(const LossArgs& A, const ScaleArgs& S, const ScaleConst& sc, const int b, const int i,
-                                            const int s, const int lane, const int x, const bool xin, const bool outl,
-                                            const int y0, const int y1, float* gacc, const bool first, float& acc_pix,
-                                            float& acc_ssim, float& acc_exp, const int item) {
-  constexpr int HS = SSIM ? (GRAD ? 2 : 1) : 0;
-  const int h = S.h, w = S.w;
-  const size_t P = (size_t)h * w;
-  const float xf = (float)x;
-
-  // --- geometry of (b, s, i): uniform -> SGPRs
-  const Geom* __restrict__ gp = A.geom + ((size_t)(b * A.n_scales + s) * A.n_src + i);
-  SrcConst G;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float m0 = uniform(gp->M[k * 3 + 0]), m2 = uniform(gp->M[k * 3 + 2]);
-    G.M1[k] = uniform(gp->M[k * 3 + 1]);
-    G.P3[k] = uniform(gp->P[k * 4 + 3]);
-    G.mx[k] = fmaf(m0, xf, m2);
-    if (GRAD) {
-      const float k0 = uniform(gp->Kinv[k * 3 + 0]), k2 = uniform(gp->Kinv[k * 3 + 2]);
-      G.K1[k] = uniform(gp->Kinv[k * 3 + 1]);
-      G.kx[k] = fmaf(k0, xf, k2);
-    }
-  }
-  const float* __restrict__ tplane = S.tgt + (size_t)b * 3 * P;
-  const float* __restrict__ splane = S.src + ((size_t)b * A.n_src + i) * 3 * P;
-  const float* __restrict__ dplane = S.disp + (size_t)b * P;
-  const float* __restrict__ mplane = EXPL ? S.mlog + ((size_t)b * A.n_src + i) * P : nullptr;
-  float* __restrict__ dmplane = (EXPL && GRAD) ? S.d_mask + ((size_t)b * A.n_src + i) * P : nullptr;
-  float* __restrict__ dsplane = (GRAD && S.d_src) ? S.d_src + ((size_t)b * A.n_src + i) * 3 * P : nullptr;
-
-  const float one_m_alpha = 1.0f - A.alpha;
-  const float k_pix = A.gy * one_m_alpha * S.inv_cnt;   // dL/d(sum |e|)      base_model.py:111,117
-  const float k_ssim = A.gy * A.alpha * S.inv_cnt;      // dL/d(sum ssim_err) base_model.py:115,117
-  const float c1 = 0.0001f, c2 = 0.0009f;               // base_model.py:127-128
-  const float ninth = 1.0f / 9.0f;
-
-  float gpm[12];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) gpm[k] = 0.f;
-
-  // rings
-  RowA p1, p2;  // rows r-1, r-2
-  zero_row(p1);
-  zero_row(p2);
-  float hx1[3] = {0, 0, 0}, hx2[3] = {0, 0, 0}, hxx1[3] = {0, 0, 0}, hxx2[3] = {0, 0, 0}, hxy1[3] = {0, 0, 0}, hxy2[3] = {0, 0, 0};
-  float hy1[3] = {0, 0, 0}, hy2[3] = {0, 0, 0}, hyy1[3] = {0, 0, 0}, hyy2[3] = {0, 0, 0};
-  float ga1[3] = {0, 0, 0}, ga2[3] = {0, 0, 0}, gb1[3] = {0, 0, 0}, gb2[3] = {0, 0, 0}, ge1[3] = {0, 0, 0}, ge2[3] = {0, 0, 0};
-
-  for (int r = y0 - HS; r < y1 + HS; ++r) {
-    // ------------------------------ stage A: warp row r ------------------------------
-    RowA cur;
-    zero_row(cur);
-    const bool rin = (r >= 0) && (r < h);
-    if (rin && xin) {
-      const int off = r * w + x;
-      const float yf = (float)r;
-      const float disp = dplane[off];
-      cur.D = rcp_refined(disp);                                     // base_model.py:60
-#pragma unroll
-      for (int c = 0; c < 3; ++c) cur.it[c] = tplane[c * P + off];
-      if (EXPL) {
-        const float lg = mplane[off];
-        cur.sg = rcp(1.0f + __expf(-lg));                            // F.sigmoid, base_model.py:107
-        if (LOSS && outl && r >= y0 && r < y1) {
-          // softplus(-x) = max(-x,0) + log(1 + exp(-|x|))            base_model.py:165-167
-          acc_exp += fmaxf(-lg, 0.f) + __logf(1.0f + __expf(-fabsf(lg)));
-        }
-      }
-      const float a0 = fmaf(G.M1[0], yf, G.mx[0]), a1 = fmaf(G.M1[1], yf, G.mx[1]), a2 = fmaf(G.M1[2], yf, G.mx[2]);
-      const Proj p = project(a0, a1, a2, G.P3[0], G.P3[1], G.P3[2], cur.D, sc, h, w);
-      cur.U = p.U; cur.V = p.V; cur.rz = p.rz;
-      if (p.inview) {
-        cur.inv = 1.f;
-        const float* sp = splane + p.v0 * w + p.u0;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const Tap2 t = load_tap2(sp + c * P);
-          const Tap2 bt = load_tap2(sp + c * P + w);
-          const float dxt = t.b - t.a, dxb = bt.b - bt.a;
-          const float top = fmaf(p.fu, dxt, t.a);
-          const float bot = fmaf(p.fu, dxb, bt.a);
-          const float dvv = bot - top;
-          cur.ih[c] = fmaf(p.fv, dvv, top);
-          cur.dv[c] = dvv;
-          cur.du[c] = fmaf(p.fv, dxb - dxt, dxt);
-        }
-      }
-    }
-
-    if (SSIM) {
-      // horizontal 3-sums of row r
-      float hx0[3], hxx0[3], hxy0[3], hy0[3], hyy0[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        hx0[c] = hsum3(cur.ih[c]);
-        hxx0[c] = hsum3(cur.ih[c] * cur.ih[c]);
-        hxy0[c] = hsum3(cur.ih[c] * cur.it[c]);
-        hy0[c] = hsum3(cur.it[c]);
-        hyy0[c] = hsum3(cur.it[c] * cur.it[c]);
-      }
-      // ------------------------------ stage B: SSIM at row r-1 ------------------------------
-      const int rb = r - 1;
-      const bool rb_in = (rb >= 0) && (rb < h);
-      const float m1 = (p1.ih[0] == 0.f && p1.ih[1] == 0.f && p1.ih[2] == 0.f) ? 1.f : 0.f;   // base_model.py:96
-      float ga0[3], gb0[3], ge0[3];
-      float ssum = 0.f;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float mux = (hx2[c] + hx1[c] + hx0[c]) * ninth;        // :130
-        const float muy = (hy2[c] + hy1[c] + hy0[c]) * ninth;        // :131
-        const float exx = (hxx2[c] + hxx1[c] + hxx0[c]) * ninth;
-        const float eyy = (hyy2[c] + hyy1[c] + hyy0[c]) * ninth;
-        const float exy = (hxy2[c] + hxy1[c] + hxy0[c]) * ninth;
-        const float sx = exx - mux * mux;                            // :133
-        const float sy = eyy - muy * muy;                            // :134
-        const float sxy = exy - mux * muy;                           // :135
-        const float n1 = 2.f * mux * muy + c1, n2 = 2.f * sxy + c2;  // :137
-        const float d1 = mux * mux + muy * muy + c1, d2 = sx + sy + c2;   // :138
-        const float rd = rcp(d1 * d2);
-        const float Sv = n1 * n2 * rd;                               // :140
-        const float e = (1.f - Sv) * 0.5f;                           // :142
-        ssum += fminf(fmaxf(e, 0.f), 1.f);
-        if (GRAD) {
-          float kap = (e > 0.f && e < 1.f) ? -0.5f * k_ssim * (1.f - m1) : 0.f;
-          if (!(rb_in && xin)) kap = 0.f;
-          const float rd2 = rcp(d2);
-          const float dS_dmux = (2.f * muy * (n2 - n1) - Sv * 2.f * mux * (d2 - d1)) * rd;
-          ga0[c] = hsum3(kap * dS_dmux);
-          gb0[c] = hsum3(kap * (-Sv * rd2));
-          ge0[c] = hsum3(kap * (2.f * n1 * rd));
-        }
-      }
-      if (LOSS) {
-        if (outl && rb >= y0 && rb < y1) {
-          acc_ssim += ssum * (1.f - m1);                             // :114-115
-          float e1 = 0.f;
-#pragma unroll
-          for (int c = 0; c < 3; ++c) e1 += fabsf(p1.ih[c] - p1.it[c]);   // :95
-          acc_pix += e1 * (1.f - m1);                                // :98-100,:111
-        }
-      }
-      if (GRAD) {
-        // ------------------------------ stage C: gradients at row r-2 ------------------------------
-        const int rc = r - 2;
-        if (rc >= y0 && rc < y1) {
-          const float m2 = (p2.ih[0] == 0.f && p2.ih[1] == 0.f && p2.ih[2] == 0.f) ? 1.f : 0.f;
-          float gU = 0.f, gV = 0.f;
-          float gI[3];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const float Aq = (ga2[c] + ga1[c] + ga0[c]) * ninth;
-            const float Bq = (gb2[c] + gb1[c] + gb0[c]) * ninth;
-            const float Eq = (ge2[c] + ge1[c] + ge0[c]) * ninth;
-            float g = Aq + 2.f * p2.ih[c] * Bq + p2.it[c] * Eq;
-            g += k_pix * (1.f - m2) * signf(p2.ih[c] - p2.it[c]);
-            gI[c] = g;
-            gU = fmaf(g, p2.du[c], gU);
-            gV = fmaf(g, p2.dv[c], gV);
-          }
-          gU *= p2.inv;
-          gV *= p2.inv;
-          const float yf = (float)rc;
-          const float gq0 = gU * p2.rz, gq1 = gV * p2.rz;
-          const float gq2 = -(gU * p2.U + gV * p2.V) * p2.rz;
-          const float a0 = fmaf(G.M1[0], yf, G.mx[0]), a1 = fmaf(G.M1[1], yf, G.mx[1]), a2 = fmaf(G.M1[2], yf, G.mx[2]);
-          const float gD = gq0 * a0 + gq1 * a1 + gq2 * a2;
-          const float gdisp = outl ? -gD * p2.D * p2.D : 0.f;       // d(1/d) = -1/d^2
-          float* ga = gacc + (rc - y0) * 64 + lane;
-          *ga = first ? gdisp : (*ga + gdisp);
-          if (outl) {
-            const float cc0 = p2.D * fmaf(G.K1[0], yf, G.kx[0]);
-            const float cc1 = p2.D * fmaf(G.K1[1], yf, G.kx[1]);
-            const float cc2 = p2.D * fmaf(G.K1[2], yf, G.kx[2]);
-            gpm[0] = fmaf(gq0, cc0, gpm[0]); gpm[1] = fmaf(gq0, cc1, gpm[1]); gpm[2] = fmaf(gq0, cc2, gpm[2]); gpm[3] += gq0;
-            gpm[4] = fmaf(gq1, cc0, gpm[4]); gpm[5] = fmaf(gq1, cc1, gpm[5]); gpm[6] = fmaf(gq1, cc2, gpm[6]); gpm[7] += gq1;
-            gpm[8] = fmaf(gq2, cc0, gpm[8]); gpm[9] = fmaf(gq2, cc1, gpm[9]); gpm[10] = fmaf(gq2, cc2, gpm[10]); gpm[11] += gq2;
-            if (dsplane && p2.inv != 0.f) {
-              const Proj p = project(a0, a1, a2, G.P3[0], G.P3[1], G.P3[2], p2.D, sc, h, w);
-              float* ds = dsplane + p.v0 * w + p.u0;
-              const float w00 = (1.f - p.fu) * (1.f - p.fv), w01 = p.fu * (1.f - p.fv), w10 = (1.f - p.fu) * p.fv, w11 = p.fu * p.fv;
-#pragma unroll
-              for (int c = 0; c < 3; ++c) {
-                atomicAdd(ds + c * P, gI[c] * w00);
-                atomicAdd(ds + c * P + 1, gI[c] * w01);
-                atomicAdd(ds + c * P + w, gI[c] * w10);
-                atomicAdd(ds + c * P + w + 1, gI[c] * w11);
-              }
-            }
-          }
-        }
-      }
-      // rotate rings
-      p2 = p1;
-      p1 = cur;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        hx2[c] = hx1[c]; hx1[c] = hx0[c];
-        hxx2[c] = hxx1[c]; hxx1[c] = hxx0[c];
-        hxy2[c] = hxy1[c]; hxy1[c] = hxy0[c];
-        hy2[c] = hy1[c]; hy1[c] = hy0[c];
-        hyy2[c] = hyy1[c]; hyy1[c] = hyy0[c];
-        if (GRAD) {
-          ga2[c] = ga1[c]; ga1[c] = ga0[c];
-          gb2[c] = gb1[c]; gb1[c] = gb0[c];
-          ge2[c] = ge1[c]; ge1[c] = ge0[c];
-        }
-      }
-    } else {
-      // ------------------------------ no SSIM: everything is per pixel ------------------------------
-      const float m = (cur.ih[0] == 0.f && cur.ih[1] == 0.f && cur.ih[2] == 0.f) ? 1.f : 0.f;
-      float e1 = 0.f;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) e1 += fabsf(cur.ih[c] - cur.it[c]);
-      e1 *= (1.f - m);
-      const float wgt = EXPL ? cur.sg : 1.f;                         // base_model.py:107-109
-      if (LOSS && outl) acc_pix += e1 * wgt;
-      if (GRAD) {
-        float gU = 0.f, gV = 0.f;
-        float gI[3];
-        const float kk = k_pix * (1.f - m) * wgt;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float g = kk * signf(cur.ih[c] - cur.it[c]);
-          gI[c] = g;
-          gU = fmaf(g, cur.du[c], gU);
-          gV = fmaf(g, cur.dv[c], gV);
-        }
-        gU *= cur.inv;
-        gV *= cur.inv;
-        const float yf = (float)r;
-        const float gq0 = gU * cur.rz, gq1 = gV * cur.rz;
-        const float gq2 = -(gU * cur.U + gV * cur.V) * cur.rz;
-        const float a0 = fmaf(G.M1[0], yf, G.mx[0]), a1 = fmaf(G.M1[1], yf, G.mx[1]), a2 = fmaf(G.M1[2], yf, G.mx[2]);
-        const float gD = gq0 * a0 + gq1 * a1 + gq2 * a2;
-        const float gdisp = outl ? -gD * cur.D * cur.D : 0.f;
-        float* ga = gacc + (r - y0) * 64 + lane;
-        *ga = first ? gdisp : (*ga + gdisp);
-        if (outl) {
-          if (EXPL) {
-            // d/dlogit of  (1-a) * mean(err * sigmoid)  +  exp_reg * mean(softplus(-logit))
-            dmplane[r * w + x] = k_pix * e1 * cur.sg * (1.f - cur.sg) + A.gy * S.c_exp * (cur.sg - 1.f);
-          }
-          const float cc0 = cur.D * fmaf(G.K1[0], yf, G.kx[0]);
-          const float cc1 = cur.D * fmaf(G.K1[1], yf, G.kx[1]);
-          const float cc2 = cur.D * fmaf(G.K1[2], yf, G.kx[2]);
-          gpm[0] = fmaf(gq0, cc0, gpm[0]); gpm[1] = fmaf(gq0, cc1, gpm[1]); gpm[2] = fmaf(gq0, cc2, gpm[2]); gpm[3] += gq0;
-          gpm[4] = fmaf(gq1, cc0, gpm[4]); gpm[5] = fmaf(gq1, cc1, gpm[5]); gpm[6] = fmaf(gq1, cc2, gpm[6]); gpm[7] += gq1;
-          gpm[8] = fmaf(gq2, cc0, gpm[8]); gpm[9] = fmaf(gq2, cc1, gpm[9]); gpm[10] = fmaf(gq2, cc2, gpm[10]); gpm[11] += gq2;
-          if (dsplane && cur.inv != 0.f) {
-            const Proj p = project(a0, a1, a2, G.P3[0], G.P3[1], G.P3[2], cur.D, sc, h, w);
-            float* ds = dsplane + p.v0 * w + p.u0;
-            const float w00 = (1.f - p.fu) * (1.f - p.fv), w01 = p.fu * (1.f - p.fv), w10 = (1.f - p.fu) * p.fv, w11 = p.fu * p.fv;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              atomicAdd(ds + c * P, gI[c] * w00);
-              atomicAdd(ds + c * P + 1, gI[c] * w01);
-              atomicAdd(ds + c * P + w, gI[c] * w10);
-              atomicAdd(ds + c * P + w + 1, gI[c] * w11);
-            }
-          }
-        }
-      }
-    }
-  }
-
-  if (GRAD) {
-    float* out = A.part_gpm + ((size_t)item * A.n_src + i) * 12;
-#pragma unroll
-    for (int k = 0; k < 12; ++k) {
-      const float v = wave_sum(gpm[k]);
-      if (lane == 0) out[k] = v;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
 // the main kernel: one wavefront per (scale, sample, strip, chunk)
 // ------------------------------------------------------------------------------------------
 template <bool SSIM, bool GRAD, bool LOSS, bool EXPL, int SMODE>
@@ -586,38 +286,42 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
   SFM_STAMP(ts1);
 #endif
   for (int i = 0; i < A.n_src; ++i) {
-    if constexpr (SSIM) {
-      SsimCtx C;
-      // the geometry table was written by geom_kernel before this launch and is read-only here: reading it
-      // through the constant address space lets the wave fetch the 32 floats with a few scalar loads
-      // (s_load_dwordx8/x16 into SGPRs, one wait) instead of 21 dependent vector loads + v_readfirstlane
-      typedef const __attribute__((address_space(4))) Geom* GeomConstPtr;
-      GeomConstPtr gp = (GeomConstPtr)(uintptr_t)(A.geom + ((size_t)(b * A.n_scales + s) * A.n_src + i));
-      const float xf = (float)x;
+    SsimCtx C;
+    // the geometry table was written by geom_kernel before this launch and is read-only here: reading it
+    // through the constant address space lets the wave fetch the 32 floats with a few scalar loads
+    // (s_load_dwordx8/x16 into SGPRs, one wait) instead of 21 dependent vector loads + v_readfirstlane
+    typedef const __attribute__((address_space(4))) Geom* GeomConstPtr;
+    GeomConstPtr gp = (GeomConstPtr)(uintptr_t)(A.geom + ((size_t)(b * A.n_scales + s) * A.n_src + i));
+    const float xf = (float)x;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        C.M1[k] = gp->M[k * 3 + 1];
-        C.P3[k] = gp->P[k * 4 + 3];
-        C.K1[k] = gp->Kinv[k * 3 + 1];
-        C.mx[k] = fmaf(gp->M[k * 3 + 0], xf, gp->M[k * 3 + 2]);
-        C.kx[k] = fmaf(gp->Kinv[k * 3 + 0], xf, gp->Kinv[k * 3 + 2]);
-        C.tp[k] = S.tgt + ((size_t)b * 3 + k) * P;
-        C.sp[k] = S.src + (((size_t)b * A.n_src + i) * 3 + k) * P;
-      }
-      C.k_pix = A.gy * (1.0f - A.alpha) * S.inv_cnt;
-      C.kq = -0.5f * A.gy * A.alpha * S.inv_cnt;
-      C.h = h; C.w = w; C.y0 = y0; C.y1 = y1;
-      C.dp = S.disp + (size_t)b * P;
-      C.dsp = (GRAD && S.d_src) ? S.d_src + ((size_t)b * A.n_src + i) * 3 * P : nullptr;
-      C.P = P;
-      C.sc = sc;
-      C.xc = (unsigned)min(max(x, 0), w - 1);
-      C.xin = xin;
-      C.outf = outl ? 1.f : 0.f;
-      C.lane = lane;
-      ssim_source_pass<GRAD, LOSS>(C, gacc, first, acc_pix, acc_ssim, GRAD ? A.part_gpm + ((size_t)item * A.n_src + i) * 12 : nullptr SFM_STAMPS_PASS);
+    for (int k = 0; k < 3; ++k) {
+      C.M1[k] = gp->M[k * 3 + 1];
+      C.P3[k] = gp->P[k * 4 + 3];
+      C.K1[k] = gp->Kinv[k * 3 + 1];
+      C.mx[k] = fmaf(gp->M[k * 3 + 0], xf, gp->M[k * 3 + 2]);
+      C.kx[k] = fmaf(gp->Kinv[k * 3 + 0], xf, gp->Kinv[k * 3 + 2]);
+      C.tp[k] = S.tgt + ((size_t)b * 3 + k) * P;
+      C.sp[k] = S.src + (((size_t)b * A.n_src + i) * 3 + k) * P;
+    }
+    C.k_pix = A.gy * (1.0f - A.alpha) * S.inv_cnt;
+    C.kq = -0.5f * A.gy * A.alpha * S.inv_cnt;
+    C.k_exp = A.gy * S.c_exp;
+    C.h = h; C.w = w; C.y0 = y0; C.y1 = y1;
+    C.dp = S.disp + (size_t)b * P;
+    C.dsp = (GRAD && S.d_src) ? S.d_src + ((size_t)b * A.n_src + i) * 3 * P : nullptr;
+    C.mp = EXPL ? S.mlog + ((size_t)b * A.n_src + i) * P : nullptr;
+    C.dmp = (EXPL && GRAD) ? S.d_mask + ((size_t)b * A.n_src + i) * P : nullptr;
+    C.P = P;
+    C.sc = sc;
+    C.xc = (unsigned)min(max(x, 0), w - 1);
+    C.xin = xin;
+    C.outf = outl ? 1.f : 0.f;
+    C.lane = lane;
+    float* gpm_out = GRAD ? A.part_gpm + ((size_t)item * A.n_src + i) * 12 : nullptr;
+    if constexpr (SSIM) {
+      ssim_source_pass<GRAD, LOSS>(C, gacc, first, acc_pix, acc_ssim, gpm_out SFM_STAMPS_PASS);
     } else {
-      source_pass<false, GRAD, LOSS, EXPL>(A, S, sc, b, i, s, lane, x, xin, outl, y0, y1, gacc, first, acc_pix, acc_ssim, acc_exp, item);
+      l1_source_pass<GRAD, LOSS, EXPL>(C, gacc, first, acc_pix, acc_exp, gpm_out);
     }
     first = false;
   }

@@ -42,6 +42,9 @@ struct SsimCtx {
   const float* sp[3];   // source planes of this (sample, source)
   const float* dp;      // disparity plane
   float* dsp;           // d_src planes of this (sample, source) or nullptr
+  const float* mp;      // explainability logits of this (sample, source) or nullptr     base_model.py:104
+  float* dmp;           // their gradient plane or nullptr
+  float k_exp;          // gy * exp_reg / (norm_B h w)                                  base_model.py:105,167
   size_t P;
   ScaleConst sc;
   // per lane
@@ -64,6 +67,7 @@ struct Pipe {            // a row whose gathers are in flight
   Tap2 t[3], b[3];
   float it[3];
   float fu, fv, U, V, rz, D;
+  float lg;              // explainability logit (only loaded when C.mp != nullptr)
   bool inview;
 };
 
@@ -98,6 +102,7 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
     ps.b[c] = load_tap2(C.sp[c] + off + (unsigned)C.w);
     ps.it[c] = C.tp[c][offt];
   }
+  if (C.mp != nullptr) ps.lg = C.mp[offt];
 }
 
 // stage A, second half: bilinear value and derivatives from the gathered taps
@@ -119,6 +124,42 @@ __device__ __forceinline__ void finish_row(const SsimCtx& C, const Pipe& ps, Row
   }
   s.U = ps.U; s.V = ps.V; s.D = ps.D;
   s.nm = ((nz << 1) != 0u) ? 1.f : 0.f;                             // base_model.py:96 (+-0 both count as 0)
+}
+
+// From dL/dI^ of one pixel (already contracted with dI^/du, dI^/dv and 1/z into gq0, gq1) to its
+// share of d_depth (LDS tile), of the 12 sums of dL/dPm and, optionally, of dL/d(src).
+__device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& s2, const int rc, float gq0, float gq1,
+                                                  const float* gI, float* gacc, const bool first, float* gpm) {
+  const int h = C.h, w = C.w;
+  gq0 *= C.outf;
+  gq1 *= C.outf;
+  const float gq2 = -fmaf(gq0, s2.U, gq1 * s2.V);
+  const float yf = (float)rc;
+  const float a0 = fmaf(C.M1[0], yf, C.mx[0]), a1 = fmaf(C.M1[1], yf, C.mx[1]), a2 = fmaf(C.M1[2], yf, C.mx[2]);
+  const float gD = fmaf(gq0, a0, fmaf(gq1, a1, gq2 * a2));
+  const float gdisp = -gD * s2.D * s2.D;                         // d(1/d) = -1/d^2, base_model.py:60
+  float* ga = gacc + (rc - C.y0) * 64 + C.lane;
+  *ga = first ? gdisp : (*ga + gdisp);
+  const float cc0 = s2.D * fmaf(C.K1[0], yf, C.kx[0]);
+  const float cc1 = s2.D * fmaf(C.K1[1], yf, C.kx[1]);
+  const float cc2 = s2.D * fmaf(C.K1[2], yf, C.kx[2]);
+  gpm[0] = fmaf(gq0, cc0, gpm[0]); gpm[1] = fmaf(gq0, cc1, gpm[1]); gpm[2] = fmaf(gq0, cc2, gpm[2]); gpm[3] += gq0;
+  gpm[4] = fmaf(gq1, cc0, gpm[4]); gpm[5] = fmaf(gq1, cc1, gpm[5]); gpm[6] = fmaf(gq1, cc2, gpm[6]); gpm[7] += gq1;
+  gpm[8] = fmaf(gq2, cc0, gpm[8]); gpm[9] = fmaf(gq2, cc1, gpm[9]); gpm[10] = fmaf(gq2, cc2, gpm[10]); gpm[11] += gq2;
+  if (C.dsp != nullptr) {   // optional dL/d(src): scatter of dL/dI^ over the four taps (uniform branch)
+    const Proj p = project(a0, a1, a2, C.P3[0], C.P3[1], C.P3[2], s2.D, C.sc, h, w);
+    if (p.inview && C.outf != 0.f) {
+      float* ds = C.dsp + (unsigned)(p.v0 * w + p.u0);
+      const float w00 = (1.f - p.fu) * (1.f - p.fv), w01 = p.fu * (1.f - p.fv), w10 = (1.f - p.fu) * p.fv, w11 = p.fu * p.fv;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        atomicAdd(ds + c * C.P, gI[c] * w00);
+        atomicAdd(ds + c * C.P + 1, gI[c] * w01);
+        atomicAdd(ds + c * C.P + w, gI[c] * w10);
+        atomicAdd(ds + c * C.P + w + 1, gI[c] * w11);
+      }
+    }
+  }
 }
 
 template <bool GRAD, bool LOSS>
@@ -211,35 +252,7 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const int r, con
         gq0 = fmaf(g, s2.du[c], gq0);
         gq1 = fmaf(g, s2.dv[c], gq1);
       }
-      gq0 *= C.outf;
-      gq1 *= C.outf;
-      const float gq2 = -fmaf(gq0, s2.U, gq1 * s2.V);
-      const float yf = (float)rc;
-      const float a0 = fmaf(C.M1[0], yf, C.mx[0]), a1 = fmaf(C.M1[1], yf, C.mx[1]), a2 = fmaf(C.M1[2], yf, C.mx[2]);
-      const float gD = fmaf(gq0, a0, fmaf(gq1, a1, gq2 * a2));
-      const float gdisp = -gD * s2.D * s2.D;                         // d(1/d) = -1/d^2, base_model.py:60
-      float* ga = gacc + (rc - C.y0) * 64 + C.lane;
-      *ga = first ? gdisp : (*ga + gdisp);
-      const float cc0 = s2.D * fmaf(C.K1[0], yf, C.kx[0]);
-      const float cc1 = s2.D * fmaf(C.K1[1], yf, C.kx[1]);
-      const float cc2 = s2.D * fmaf(C.K1[2], yf, C.kx[2]);
-      gpm[0] = fmaf(gq0, cc0, gpm[0]); gpm[1] = fmaf(gq0, cc1, gpm[1]); gpm[2] = fmaf(gq0, cc2, gpm[2]); gpm[3] += gq0;
-      gpm[4] = fmaf(gq1, cc0, gpm[4]); gpm[5] = fmaf(gq1, cc1, gpm[5]); gpm[6] = fmaf(gq1, cc2, gpm[6]); gpm[7] += gq1;
-      gpm[8] = fmaf(gq2, cc0, gpm[8]); gpm[9] = fmaf(gq2, cc1, gpm[9]); gpm[10] = fmaf(gq2, cc2, gpm[10]); gpm[11] += gq2;
-      if (C.dsp != nullptr) {   // optional dL/d(src): scatter of dL/dI^ over the four taps (uniform branch)
-        const Proj p = project(a0, a1, a2, C.P3[0], C.P3[1], C.P3[2], s2.D, C.sc, h, w);
-        if (p.inview && C.outf != 0.f) {
-          float* ds = C.dsp + (unsigned)(p.v0 * w + p.u0);
-          const float w00 = (1.f - p.fu) * (1.f - p.fv), w01 = p.fu * (1.f - p.fv), w10 = (1.f - p.fu) * p.fv, w11 = p.fu * p.fv;
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            atomicAdd(ds + c * C.P, gI[c] * w00);
-            atomicAdd(ds + c * C.P + 1, gI[c] * w01);
-            atomicAdd(ds + c * C.P + w, gI[c] * w10);
-            atomicAdd(ds + c * C.P + w + 1, gI[c] * w11);
-          }
-        }
-      }
+      geometry_backward(C, s2, rc, gq0, gq1, gI, gacc, first, gpm);
     }
   }
   SFM_STAMP(t4);
@@ -272,6 +285,61 @@ __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, 
       ssim_row_step<GRAD, LOSS>(C, r + 1, rend, ps, disp_next, S1, S0, S2, G1, G0, G2, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
     if (r + 2 < rend)
       ssim_row_step<GRAD, LOSS>(C, r + 2, rend, ps, disp_next, S2, S1, S0, G2, G1, G0, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
+  }
+  if (GRAD) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      const float v = wave_sum(gpm[k]);
+      if (C.lane == 0) gpm_out[k] = v;
+    }
+  }
+}
+
+// Photometric pass WITHOUT SSIM for one (wave, source): L1 (+ explainability weighting, base_model.py:103-109).
+// Everything is per pixel, so there is no ring; the loads of row r+1 are in flight while row r is finished.
+template <bool GRAD, bool LOSS, bool EXPL>
+__device__ __forceinline__ void l1_source_pass(const SsimCtx& C, float* gacc, const bool first, float& acc_pix, float& acc_exp,
+                                               float* gpm_out) {
+  float gpm[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) gpm[k] = 0.f;
+  Pipe ps;
+  ps.lg = 0.f;
+  float disp_next = 1.f;
+  const int rbeg = C.y0, rend = C.y1;    // rows of a chunk are always inside the image
+  issue_row(C, rbeg, C.dp[(unsigned)rbeg * (unsigned)C.w + C.xc], ps);
+  if (rbeg + 1 < rend) disp_next = C.dp[(unsigned)(rbeg + 1) * (unsigned)C.w + C.xc];
+  for (int r = rbeg; r < rend; ++r) {
+    RowS s0;
+    finish_row(C, ps, s0);
+    const float lg = ps.lg;
+    if (r + 1 < rend) issue_row(C, r + 1, disp_next, ps);
+    disp_next = C.dp[(unsigned)min(r + 2, C.h - 1) * (unsigned)C.w + C.xc];
+    float sgm = 1.f;
+    if (EXPL) {
+      sgm = rcp(1.0f + __expf(-lg));                                  // F.sigmoid, base_model.py:107
+      if (LOSS) acc_exp += C.outf * (fmaxf(-lg, 0.f) + __logf(1.0f + __expf(-fabsf(lg))));   // softplus(-x), :165-167
+    }
+    const float e1 = (fabsf(s0.ih[0] - s0.it[0]) + fabsf(s0.ih[1] - s0.it[1]) + fabsf(s0.ih[2] - s0.it[2])) * s0.nm;   // :95-100
+    if (LOSS) acc_pix = fmaf(e1 * sgm, C.outf, acc_pix);              // :109 / :111
+    if (GRAD) {
+      const float kpn = C.k_pix * s0.nm * sgm;
+      float gq0 = 0.f, gq1 = 0.f;
+      float gI[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float d = s0.ih[c] - s0.it[c];
+        const float g = (d != 0.f) ? __uint_as_float(__float_as_uint(kpn) ^ (__float_as_uint(d) & 0x80000000u)) : 0.f;
+        gI[c] = g;
+        gq0 = fmaf(g, s0.du[c], gq0);
+        gq1 = fmaf(g, s0.dv[c], gq1);
+      }
+      if (EXPL) {
+        // d/dlogit of (1-alpha) mean(err sigmoid) + exp_reg mean(softplus(-logit))
+        if (C.outf != 0.f) C.dmp[(unsigned)r * (unsigned)C.w + C.xc] = C.k_pix * e1 * sgm * (1.f - sgm) + C.k_exp * (sgm - 1.f);
+      }
+      geometry_backward(C, s0, r, gq0, gq1, gI, gacc, first, gpm);
+    }
   }
   if (GRAD) {
 #pragma unroll
