@@ -211,17 +211,21 @@ def main():
         achieved = kbytes * warped_px / (kms * 1e-3) / 1e9
         # HBM-side bytes per launch of that kernel from the rocprofv3 PMC passes (collected offline with
         # tools/collect_profiles.sh; bench.py itself cannot read hardware counters)
-        traffic = None
+        traffic = traffic_detail = None
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", "r01_summary.json")))
             if prof["bench"]["config"]["mode"] == args.mode and args.workload == "cfg3" and args.batch == 0:
                 want = "sfm_loss_fwd_bwd" if args.mode == "fused" else "sfm_loss_bwd"
                 for kn, kv in prof["kernels"].items():
                     if kv.get("entry_point") == want and "hbm_bytes_raw" in kv:
-                        traffic = {"bytes_per_launch_raw": kv["hbm_bytes_raw"], "bytes_per_launch_fetch_x2": kv["hbm_bytes_fetch_x2"],
-                                   "source": "profiles/r01_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+                        # bytes per launch with the guide's gfx950 correction (FETCH_SIZE x 2); raw value alongside
+                        traffic = round(kv["hbm_bytes_fetch_x2"])
+                        traffic_detail = {"bytes_per_launch_raw": round(kv["hbm_bytes_raw"]),
+                                          "bytes_per_launch_fetch_x2": round(kv["hbm_bytes_fetch_x2"]),
+                                          "source": "profiles/r01_summary.json (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes; "
+                                                    "KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md, uncalibrated for 4-8 B/lane loads)"}
         except Exception:
-            traffic = None
+            traffic = traffic_detail = None
         out = {
             "metric": "warp+photo-loss fwd+bwd Mpixels/s @128x416x4scales; % HBM roofline",
             "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -232,7 +236,7 @@ def main():
                        "parallelism": "batch-sharded x%d, RCCL all-reduce of 5 scalars" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": kname, "kernel_ms": round(kms, 5), "bytes_per_warped_px": kbytes},
+                         "traffic_detail": traffic_detail, "kernel": kname, "kernel_ms": round(kms, 5), "bytes_per_warped_px": kbytes},
             "kernel_ms": {"fwd_main": round(k_fwd, 5) if args.mode == "separate" else None,
                           "bwd_main": round(k_bwd, 5) if k_bwd is not None else None,
                           "fused_main": round(k_fwd, 5) if args.mode == "fused" else None},
