@@ -210,7 +210,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 __device__ __forceinline__ float uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 
-__device__ __forceinline__ float signf(float t) { return (t > 0.f) ? 1.f : ((t < 0.f) ? -1.f : 0.f); }
+// sign(t) with sign(0) = 0 (F.absolute backward): copysign(1, t) unless t == 0   (v_bfi + v_cmp + v_cndmask)
+__device__ __forceinline__ float signf(float t) { return (t != 0.f) ? __builtin_copysignf(1.0f, t) : 0.f; }
 
 // two horizontally adjacent taps with one 8-byte load; only 4-byte alignment is guaranteed
 struct __attribute__((packed, aligned(4))) Tap2 {

@@ -96,58 +96,62 @@ __global__ void geom_kernel(const LossArgs A) {
 template <bool GRAD, bool LOSS>
 __device__ __forceinline__ void smooth2_pass(const LossArgs& A, const ScaleArgs& S, const float* __restrict__ dplane, int lane,
                                              int x, bool xin, bool outl, int y0, int y1, float* gacc, float& acc_sm) {
+  // Every term of compute_smooth_loss is a forward difference anchored at one pixel (a, x):
+  //   dx2(a,x)  = d(a,x+2) - 2 d(a,x+1) + d(a,x)                      valid x <= w-3
+  //   dy2(a,x)  = d(a+2,x) - 2 d(a+1,x) + d(a,x)                      valid a <= h-3
+  //   dxdy, dydx(a,x): the two evaluation orders of the mixed difference  valid a <= h-2, x <= w-2
+  // The walk computes the anchored SIGNS of a row once (rows a, a+1, a+2 in registers) and keeps the two
+  // previous rows' signs in a ring; the gradient at (q,x) gathers them with the transposed stencil:
+  //   c_dx2 [s2x(q,x-2) - 2 s2x(q,x-1) + s2x(q,x)] + c_dy2 [s2y(q-2,x) - 2 s2y(q-1,x) + s2y(q,x)]
+  //   + c_dxy [txy(q-1,x-1) - txy(q-1,x) - txy(q,x-1) + txy(q,x)]
   const int h = S.h, w = S.w;
-  float dm2 = 0.f, dm1 = 0.f, d0 = 0.f, dp1 = 0.f, dp2 = 0.f;
   const bool vx2 = xin && (x <= w - 3);
   const bool vx1 = xin && (x <= w - 2);
-  // rows are loaded three steps ahead of their use (a plain load-then-use loop is latency bound)
   const unsigned xc = (unsigned)min(max(x, 0), w - 1);
-  // (always a load, from a row clamped into the image: a load under a branch would make the compiler drain
-  // every outstanding load at the join; rows outside the image only feed terms that are masked out below)
+  // always a load, from a row clamped into the image (a load under a branch would make the compiler drain every
+  // outstanding load at the join); values of rows outside the image only feed terms that are masked out
   auto ldrow = [&](int r) -> float { return dplane[(unsigned)min(max(r, 0), h - 1) * (unsigned)w + xc]; };
-  float q1 = ldrow(y0 - 2), q2 = ldrow(y0 - 1), q3 = ldrow(y0);
-  // loop-invariant coefficients, pinned in vector registers (the scalar file is full: they were re-loaded
-  // from the kernel arguments twice per row)
+  // loop-invariant coefficients pinned in vector registers (the scalar file is full)
   float c_dx2 = S.c_dx2, c_dy2 = S.c_dy2, c_dxy = S.c_dxy, gyv = A.gy;
   asm volatile("" : "+v"(c_dx2), "+v"(c_dy2), "+v"(c_dxy), "+v"(gyv));
-  for (int r = y0 - 2; r < y1 + 2; ++r) {
-    dm2 = dm1; dm1 = d0; d0 = dp1; dp1 = dp2;
-    dp2 = xin ? q1 : 0.f;
-    q1 = q2; q2 = q3; q3 = ldrow(r + 3);
-    const int q = r - 2;
-    if (q < y0) continue;
-    const float dxr0 = from_right(d0) - d0;        // dx(q,x)
-    const float dx2 = from_right(dxr0) - dxr0;     // dx2(q,x)
-    const float dy0 = dp1 - d0, dy1 = dp2 - dp1;   // dy(q,x), dy(q+1,x)
-    const float dy2 = dy1 - dy0;                   // dy2(q,x)
-    const float dxrp = from_right(dp1) - dp1;      // dx(q+1,x)
-    const float dxdy0 = dxrp - dxr0;               // dxdy(q,x) = dx(q+1,x) - dx(q,x)
-    const float dydx0 = from_right(dy0) - dy0;     // dydx(q,x) = dy(q,x+1) - dy(q,x)
-    const bool vq2 = q <= h - 3, vq1 = q <= h - 2;
+  // rows a, a+1 in registers, a+2 arriving; loads run three rows ahead of their use
+  float d0 = xin ? ldrow(y0 - 2) : 0.f, dp1 = xin ? ldrow(y0 - 1) : 0.f;
+  float q1 = ldrow(y0), q2 = ldrow(y0 + 1), q3 = ldrow(y0 + 2);
+  float s2y_m1 = 0.f, s2y_m2 = 0.f, txy_m1 = 0.f;   // anchored signs of rows a-1, a-2
+  for (int a = y0 - 2; a < y1; ++a) {
+    const float dp2 = xin ? q1 : 0.f;
+    q1 = q2; q2 = q3; q3 = ldrow(a + 5);
+    const float dxr0 = from_right(d0) - d0;        // dx(a,x)
+    const float dx2 = from_right(dxr0) - dxr0;     // dx2(a,x)
+    const float dy0 = dp1 - d0, dy1 = dp2 - dp1;   // dy(a,x), dy(a+1,x)
+    const float dy2 = dy1 - dy0;                   // dy2(a,x)
+    const float dxrp = from_right(dp1) - dp1;      // dx(a+1,x)
+    const float dxdy0 = dxrp - dxr0;               // dxdy(a,x) = dx(a+1,x) - dx(a,x)
+    const float dydx0 = from_right(dy0) - dy0;     // dydx(a,x) = dy(a,x+1) - dy(a,x)
+    const bool va = a >= 0, va2 = va && a <= h - 3, va1 = va && a <= h - 2;   // uniform
     if (LOSS) {
-      float t = 0.f;
-      if (vx2) t += c_dx2 * fabsf(dx2);
-      if (vq2) t += c_dy2 * fabsf(dy2);
-      if (vx1 && vq1) t += c_dxy * (fabsf(dxdy0) + fabsf(dydx0));
-      if (outl) acc_sm += t;
+      if (a >= y0) {
+        float t = 0.f;
+        if (vx2) t += c_dx2 * fabsf(dx2);
+        if (va2) t += c_dy2 * fabsf(dy2);
+        if (vx1 && va1) t += c_dxy * (fabsf(dxdy0) + fabsf(dydx0));
+        if (outl) acc_sm += t;
+      }
     }
     if (GRAD) {
-      const float s2x = vx2 ? signf(dx2) : 0.f;
-      const float s2x1 = from_left(s2x);
-      const float gx2 = from_left(s2x1) - 2.f * s2x1 + s2x;
-      const float dym2 = dm1 - dm2, dym1 = d0 - dm1;   // dy(q-2,x), dy(q-1,x)
-      const float s2ym2 = (q - 2 >= 0) ? signf(dym1 - dym2) : 0.f;
-      const float s2ym1 = (q - 1 >= 0 && vq1) ? signf(dy0 - dym1) : 0.f;
-      const float s2y0 = vq2 ? signf(dy2) : 0.f;
-      const float gy2 = s2ym2 - 2.f * s2ym1 + s2y0;
-      const float dxrm = from_right(dm1) - dm1;        // dx(q-1,x)
-      const float dxdym1 = dxr0 - dxrm;                // dxdy(q-1,x)
-      const float dydxm1 = from_right(dym1) - dym1;    // dydx(q-1,x)
-      const float t1 = (vx1 && q - 1 >= 0) ? signf(dxdym1) + signf(dydxm1) : 0.f;
-      const float t0 = (vx1 && vq1) ? signf(dxdy0) + signf(dydx0) : 0.f;
-      const float gxy = from_left(t1) - t1 - from_left(t0) + t0;
-      gacc[(q - y0) * 64 + lane] = gyv * (c_dx2 * gx2 + c_dy2 * gy2 + c_dxy * gxy);
+      const float s2y = va2 ? signf(dy2) : 0.f;
+      const float txy = (vx1 && va1) ? signf(dxdy0) + signf(dydx0) : 0.f;
+      if (a >= y0) {
+        const float s2x = (vx2 && va) ? signf(dx2) : 0.f;
+        const float s2x1 = from_left(s2x);
+        const float gx2 = from_left(s2x1) - 2.f * s2x1 + s2x;
+        const float gy2 = s2y_m2 - 2.f * s2y_m1 + s2y;
+        const float gxy = from_left(txy_m1) - txy_m1 - from_left(txy) + txy;
+        gacc[(a - y0) * 64 + lane] = gyv * (c_dx2 * gx2 + c_dy2 * gy2 + c_dxy * gxy);
+      }
+      s2y_m2 = s2y_m1; s2y_m1 = s2y; txy_m1 = txy;
     }
+    d0 = dp1; dp1 = dp2;
   }
 }
 
