@@ -120,9 +120,11 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ     # under torch.distributed.run, also at N = 1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     ops = importlib.import_module(PKG + ".ops")
     synth = importlib.import_module(PKG + ".synth")
@@ -150,25 +152,28 @@ def main():
             if evs:
                 lib.sfm_loss_profile_events(evs[2], evs[3])
             fl.backward(1.0)
-        if world > 1:
-            dist.all_reduce(fl.loss5)       # the five reported scalars, summed over shards (RCCL)
+        if use_dist:
+            # the only collective of the path: the five reported scalars summed over the shards (RCCL).  Issued
+            # synchronously in stream order: an async_op=True variant with rotating buffers measured SLOWER
+            # (111 vs 95 us per step at N=1, tools/allreduce_overhead.py)
+            dist.all_reduce(fl.loss5)
 
     for _ in range(args.warmup):
         step()
     events = [[ev.create() for _ in range(4)] for _ in range(args.steps)]
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(events[k])
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -248,7 +253,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -291,8 +291,11 @@ class FusedLoss:
             check(lib.sfm_loss_bwd(C.byref(self.desc), float(gy), C.c_void_p(self._ws_ptr), self._ws_bytes, _stream()))
         return self.d_disps, self.d_poses, self.d_masks, self.d_srcs
 
-    def forward_backward(self):
+    def forward_backward(self, out=None):
+        """`out`: optional (5,) float32 device tensor to receive the five scalars instead of `self.loss5`
+        (lets a caller rotate output slots, e.g. to all-reduce them asynchronously)."""
         self._zero_d_src()
+        loss5 = self.loss5 if out is None else out
         with torch.cuda.device(self.device):
-            check(lib.sfm_loss_fwd_bwd(C.byref(self.desc), _p(self.loss5), C.c_void_p(self._ws_ptr), self._ws_bytes, _stream()))
-        return self.loss5
+            check(lib.sfm_loss_fwd_bwd(C.byref(self.desc), _p(loss5), C.c_void_p(self._ws_ptr), self._ws_bytes, _stream()))
+        return loss5
