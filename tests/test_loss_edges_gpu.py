@@ -104,3 +104,28 @@ def test_high_resolution_config5_shape(ops, synth, dev):
         got, w32, w64 = to_np(fl.d_poses[i]).astype(np.float64), ref["d_poses"][i], ref64["d_poses"][i]
         tol = np.maximum(2e-3 * np.abs(w64).max(), 2 * np.abs(w32 - w64))
         assert (np.abs(got - w64) <= tol).all(), (i, got, w64, w32)
+
+
+def _random_cases(n, seed=2024):
+    rng = np.random.RandomState(seed)
+    cases = []
+    names = sorted(CONFIGS)
+    for k in range(n):
+        n_scales = int(rng.randint(1, 4))
+        H = int(rng.randint(3 << (n_scales - 1), 80))
+        W = int(rng.randint(3 << (n_scales - 1), 200))
+        cases.append((int(rng.randint(1, 11)), H, W, int(rng.randint(1, 5)), n_scales, names[int(rng.randint(len(names)))], int(rng.randint(1 << 30))))
+    return cases
+
+
+@pytest.mark.parametrize("B,H,W,n_src,n_scales,cfg_name,seed", _random_cases(16))
+def test_random_shapes_and_modes(ops, synth, dev, B, H, W, n_src, n_scales, cfg_name, seed):
+    """a seeded sweep over ragged shapes (odd sizes, partial strips and chunks), batch sizes on both sides of the
+    XCD-striping threshold, source counts and every loss mode"""
+    cfg = CONFIGS[cfg_name]
+    d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=n_scales, seed=seed % 10000, with_masks=True)
+    ref = _oracle(d, cfg)
+    fl = _bind(ops, dev, d, cfg)
+    _check_losses(fl.forward(), ref)
+    _check_losses(fl.forward_backward(), ref)
+    _check_grads(fl, ref, n_src, check_mask=bool(cfg.get("exp_reg")))
