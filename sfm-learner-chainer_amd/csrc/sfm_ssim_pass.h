@@ -55,13 +55,49 @@ struct SsimCtx {
   int lane;
 };
 
+// The three colour channels of a pixel: channels 0 and 1 as one 64-bit register pair, channel 2 alone.  The
+// per-channel arithmetic of SSIM and of the gradient is written once, generic over the element type, and
+// instantiated for the pair (v_pk_fma/mul/add_f32: two channels per issued instruction) and for the scalar.
+// At the 3 waves per SIMD this kernel runs at, instruction ISSUE is the limit, and a packed op costs less than
+// two scalar ones (tools/mix_pk.hip: 449 vs 524 cycles per SSIM row step per SIMD).
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct Ch3 {
+  f2 p;      // channels 0, 1
+  float s;   // channel 2
+};
+__device__ __forceinline__ Ch3 ch3(float c0, float c1, float c2) { Ch3 r; r.p.x = c0; r.p.y = c1; r.s = c2; return r; }
+__device__ __forceinline__ Ch3 ch3_zero() { return ch3(0.f, 0.f, 0.f); }
+
+__device__ __forceinline__ f2 vfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float vfma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ f2 vrcp(f2 a) { f2 r; r.x = rcp(a.x); r.y = rcp(a.y); return r; }
+__device__ __forceinline__ float vrcp(float a) { return rcp(a); }
+__device__ __forceinline__ f2 hsum3(f2 v) { f2 r; r.x = hsum3(v.x); r.y = hsum3(v.y); return r; }
+__device__ __forceinline__ float vclamp01_sum(f2 e) { return fminf(fmaxf(e.x, 0.f), 1.f) + fminf(fmaxf(e.y, 0.f), 1.f); }
+__device__ __forceinline__ float vclamp01_sum(float e) { return fminf(fmaxf(e, 0.f), 1.f); }
+// v where 0 < e < 1, else 0   (F.clip backward)
+__device__ __forceinline__ f2 vsel_open01(f2 e, f2 v) {
+  const f2 t = e * (1.f - e);
+  f2 r; r.x = t.x > 0.f ? v.x : 0.f; r.y = t.y > 0.f ? v.y : 0.f; return r;
+}
+__device__ __forceinline__ float vsel_open01(float e, float v) { return (e * (1.f - e) > 0.f) ? v : 0.f; }
+// k * sign(d), sign(0) = 0   (F.absolute backward; k carries the sign of the upstream gradient)
+__device__ __forceinline__ float ksign(float k, float d) {
+  return (d != 0.f) ? __uint_as_float(__float_as_uint(k) ^ (__float_as_uint(d) & 0x80000000u)) : 0.f;
+}
+__device__ __forceinline__ f2 ksign(float k, f2 d) { f2 r; r.x = ksign(k, d.x); r.y = ksign(k, d.y); return r; }
+__device__ __forceinline__ float vabs_sum(f2 d) { return fabsf(d.x) + fabsf(d.y); }
+__device__ __forceinline__ float vabs_sum(float d) { return fabsf(d); }
+__device__ __forceinline__ float vhadd(f2 v) { return v.x + v.y; }
+__device__ __forceinline__ float vhadd(float v) { return v; }
+
 struct RowS {            // a warped row as the later stages need it (per lane = per pixel)
-  float ih[3], it[3];    // I^ (0 where not in view / outside the image), I (0 outside the image)
-  float du[3], dv[3];    // dI^/du, dI^/dv, pre-multiplied by 1/z (0 where not in view)
+  Ch3 ih, it;            // I^ (0 where not in view / outside the image), I (0 outside the image)
+  Ch3 du, dv;            // dI^/du, dI^/dv, pre-multiplied by 1/z (0 where not in view)
   float U, V, D;         // q0/z, q1/z, depth
   float nm;              // 1 - mask, mask = all three channels of I^ exactly 0   base_model.py:96
 };
-struct RowG { float a[3], b[3], e[3]; };                  // horizontal 3-sums of the SSIM partials
+struct RowG { Ch3 a, b, e; };                             // horizontal 3-sums of the SSIM partials
 
 struct Pipe {            // a row whose gathers are in flight
   Tap2 t[3], b[3];
@@ -72,14 +108,10 @@ struct Pipe {            // a row whose gathers are in flight
 };
 
 __device__ __forceinline__ void zero(RowS& s) {
-#pragma unroll
-  for (int c = 0; c < 3; ++c) s.ih[c] = s.it[c] = s.du[c] = s.dv[c] = 0.f;
+  s.ih = s.it = s.du = s.dv = ch3_zero();
   s.U = s.V = s.D = s.nm = 0.f;
 }
-__device__ __forceinline__ void zero(RowG& s) {
-#pragma unroll
-  for (int c = 0; c < 3; ++c) s.a[c] = s.b[c] = s.e[c] = 0.f;
-}
+__device__ __forceinline__ void zero(RowG& s) { s.a = s.b = s.e = ch3_zero(); }
 
 // stage A, first half: project row r and issue its loads (row r is inside the image)
 __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const float disp, Pipe& ps) {
@@ -109,6 +141,7 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
 __device__ __forceinline__ void finish_row(const SsimCtx& C, const Pipe& ps, RowS& s) {
   const float rzi = ps.inview ? ps.rz : 0.f;
   unsigned nz = 0;
+  float ih[3], it[3], du[3], dv[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float dxt = ps.t[c].b - ps.t[c].a, dxb = ps.b[c].b - ps.b[c].a;
@@ -116,12 +149,16 @@ __device__ __forceinline__ void finish_row(const SsimCtx& C, const Pipe& ps, Row
     const float bot = fmaf(ps.fu, dxb, ps.b[c].a);
     const float dvv = bot - top;
     const float val = ps.inview ? fmaf(ps.fv, dvv, top) : 0.f;
-    s.ih[c] = val;
-    s.dv[c] = dvv * rzi;
-    s.du[c] = fmaf(ps.fv, dxb - dxt, dxt) * rzi;
-    s.it[c] = C.xin ? ps.it[c] : 0.f;
+    ih[c] = val;
+    dv[c] = dvv * rzi;
+    du[c] = fmaf(ps.fv, dxb - dxt, dxt) * rzi;
+    it[c] = C.xin ? ps.it[c] : 0.f;
     nz |= __float_as_uint(val);
   }
+  s.ih = ch3(ih[0], ih[1], ih[2]);
+  s.it = ch3(it[0], it[1], it[2]);
+  s.du = ch3(du[0], du[1], du[2]);
+  s.dv = ch3(dv[0], dv[1], dv[2]);
   s.U = ps.U; s.V = ps.V; s.D = ps.D;
   s.nm = ((nz << 1) != 0u) ? 1.f : 0.f;                             // base_model.py:96 (+-0 both count as 0)
 }
@@ -162,6 +199,50 @@ __device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& 
   }
 }
 
+// Stage B for one channel group (T = f2: channels 0,1; T = float: channel 2).
+//   x2,x1,x0 / y2,y1,y0: I^ and I of rows r-2, r-1, r;  out: horizontal 3-sums of the three SSIM partials of row r-1
+// SSIM in scaled sums (Sx = 9 mu_x ...), see the header of this file; models/base_model.py:130-142.
+template <bool GRAD, bool LOSS, typename T>
+__device__ __forceinline__ void ssim_stage_b(const T x2, const T x1, const T x0, const T y2, const T y1, const T y0,
+                                             const float kq_nm, T& ga, T& gb, T& ge, float& ssum) {
+  const float C1 = 81.f * 0.0001f, C2 = 81.f * 0.0009f;             // 81 c1, 81 c2   base_model.py:127-128
+  // separable 3x3 sums around (r-1, x): vertical over the ring rows r-2..r (in-lane), then horizontal (DPP)
+  const T Sx = hsum3(x2 + x1 + x0);
+  const T Sy = hsum3(y2 + y1 + y0);
+  // sigma_x + sigma_y only ever appear together (base_model.py:138), so E[xx] and E[yy] are pooled as one field
+  const T Sqq = hsum3(vfma(x2, x2, vfma(x1, x1, vfma(x0, x0, vfma(y2, y2, vfma(y1, y1, y0 * y0))))));
+  const T Sxy = hsum3(vfma(x2, y2, vfma(x1, y1, x0 * y0)));
+  const T pxy = Sx * Sy;
+  const T sq = vfma(Sx, Sx, Sy * Sy);
+  const T N1 = pxy * 2.f + C1;
+  const T N2 = pxy * -2.f + (Sxy * 18.f + C2);
+  const T D1 = sq + C1;
+  const T D2 = (Sqq * 9.f + C2) - sq;
+  const T rD = vrcp(D1 * D2);
+  const T Sv = N1 * N2 * rD;                                        // base_model.py:140
+  const T e = Sv * -0.5f + 0.5f;                                    // (1 - SSIM) / 2, base_model.py:142
+  if (LOSS) ssum += vclamp01_sum(e);
+  if (GRAD) {
+    const T kap = vsel_open01(e, rD * kq_nm);                       // kappa / (D1 D2); F.clip backward: 0 < e < 1
+    const T u3 = vfma(-(Sv * Sx), D2 - D1, Sy * (N2 - N1));
+    ga = hsum3(kap * u3 * 2.f);               // (1/9) kappa dS/dmu_x
+    gb = hsum3(kap * Sv * D1 * -9.f);         // (1/9) kappa dS/dE[xx]
+    ge = hsum3(kap * N1 * 18.f);              // (1/9) kappa dS/dE[xy]
+  }
+}
+
+// Stage C for one channel group: dL/dI^ of row r-2 from the transposed 3x3 pool of the SSIM partials plus the L1
+// term, contracted with dI^/du, dI^/dv (already divided by z)
+template <typename T>
+__device__ __forceinline__ void ssim_stage_c(const T a2, const T a1, const T a0, const T b2, const T b1, const T b0, const T e2,
+                                             const T e1, const T e0, const T ih, const T it, const T du, const T dv,
+                                             const float kpn, T& g, T& q0, T& q1) {
+  const T Aq = a2 + a1 + a0, Bq = b2 + b1 + b0, Eq = e2 + e1 + e0;
+  g = vfma(it, Eq, vfma(ih * 2.f, Bq, Aq)) + ksign(kpn, ih - it);
+  q0 = g * du;
+  q1 = g * dv;
+}
+
 template <bool GRAD, bool LOSS>
 __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const int r, const int rend, Pipe& ps, float& disp_next,
                                               RowS& s0, const RowS& s1, const RowS& s2,
@@ -194,40 +275,14 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const int r, con
 
   // ---------------- B: SSIM at row r-1 ----------------
   const int rb = r - 1;
-  const float C1 = 81.f * 0.0001f, C2 = 81.f * 0.0009f;             // 81 c1, 81 c2   base_model.py:127-128
   float ssum = 0.f;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    // separable 3x3 sums around (r-1, x): vertical over the ring rows r-2..r (in-lane), then horizontal (DPP)
-    const float Sx = hsum3(s2.ih[c] + s1.ih[c] + s0.ih[c]);
-    const float Sy = hsum3(s2.it[c] + s1.it[c] + s0.it[c]);
-    // sigma_x + sigma_y only ever appear together (base_model.py:138), so E[xx] and E[yy] are pooled as one field
-    const float Sqq = hsum3(fmaf(s2.ih[c], s2.ih[c], fmaf(s1.ih[c], s1.ih[c], fmaf(s0.ih[c], s0.ih[c],
-                            fmaf(s2.it[c], s2.it[c], fmaf(s1.it[c], s1.it[c], s0.it[c] * s0.it[c]))))));
-    const float Sxy = hsum3(fmaf(s2.ih[c], s2.it[c], fmaf(s1.ih[c], s1.it[c], s0.ih[c] * s0.it[c])));
-    const float pxy = Sx * Sy;
-    const float sq = fmaf(Sx, Sx, Sy * Sy);
-    const float N1 = fmaf(2.f, pxy, C1);
-    const float N2 = fmaf(-2.f, pxy, fmaf(18.f, Sxy, C2));
-    const float D1 = sq + C1;
-    const float D2 = fmaf(9.f, Sqq, C2) - sq;
-    const float rD = rcp(D1 * D2);
-    const float Sv = N1 * N2 * rD;                                  // base_model.py:140
-    const float e = fmaf(-0.5f, Sv, 0.5f);                          // (1 - SSIM) / 2, base_model.py:142
-    if (LOSS) ssum += fminf(fmaxf(e, 0.f), 1.f);
-    if (GRAD) {
-      // kappa = dL/dS at this pixel; s1.nm is 0 outside the image and on masked pixels (base_model.py:114)
-      const float kap = (e * (1.f - e) > 0.f) ? C.kq * s1.nm * rD : 0.f;     // F.clip backward: 0 < e < 1
-      const float u3 = fmaf(-(Sv * Sx), D2 - D1, Sy * (N2 - N1));
-      g0.a[c] = hsum3(2.f * kap * u3);              // (1/9) kappa dS/dmu_x
-      g0.b[c] = hsum3(-9.f * kap * Sv * D1);        // (1/9) kappa dS/dE[xx]
-      g0.e[c] = hsum3(18.f * kap * N1);             // (1/9) kappa dS/dE[xy]
-    }
-  }
+  const float kq_nm = C.kq * s1.nm;   // kappa before the clip test; s1.nm is 0 outside the image and on masked pixels (:114)
+  ssim_stage_b<GRAD, LOSS>(s2.ih.p, s1.ih.p, s0.ih.p, s2.it.p, s1.it.p, s0.it.p, kq_nm, g0.a.p, g0.b.p, g0.e.p, ssum);
+  ssim_stage_b<GRAD, LOSS>(s2.ih.s, s1.ih.s, s0.ih.s, s2.it.s, s1.it.s, s0.it.s, kq_nm, g0.a.s, g0.b.s, g0.e.s, ssum);
   if (LOSS) {   // branch-free: a halo row simply gets weight 0 (a branch here would split the block and un-fold the DPP adds)
     const float wgt = (rb >= C.y0 && rb < C.y1) ? s1.nm * C.outf : 0.f;
     acc_ssim = fmaf(ssum, wgt, acc_ssim);                            // base_model.py:114-115
-    const float e1 = fabsf(s1.ih[0] - s1.it[0]) + fabsf(s1.ih[1] - s1.it[1]) + fabsf(s1.ih[2] - s1.it[2]);   // :95
+    const float e1 = vabs_sum(s1.ih.p - s1.it.p) + vabs_sum(s1.ih.s - s1.it.s);   // :95
     acc_pix = fmaf(e1, wgt, acc_pix);                                // :98-100,:111
   }
 
@@ -237,22 +292,12 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const int r, con
     const int rc = r - 2;
     if (rc >= C.y0 && rc < C.y1) {
       const float kpn = C.k_pix * s2.nm;
-      float gq0 = 0.f, gq1 = 0.f;
-      float gI[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float Aq = g2.a[c] + g1.a[c] + g0.a[c];
-        const float Bq = g2.b[c] + g1.b[c] + g0.b[c];
-        const float Eq = g2.e[c] + g1.e[c] + g0.e[c];
-        const float d = s2.ih[c] - s2.it[c];
-        // F.absolute backward: kpn * sign(d), sign(0) = 0 (kpn carries the sign of the upstream gradient)
-        const float sg = (d != 0.f) ? __uint_as_float(__float_as_uint(kpn) ^ (__float_as_uint(d) & 0x80000000u)) : 0.f;
-        const float g = fmaf(s2.it[c], Eq, fmaf(2.f * s2.ih[c], Bq, Aq)) + sg;
-        gI[c] = g;
-        gq0 = fmaf(g, s2.du[c], gq0);
-        gq1 = fmaf(g, s2.dv[c], gq1);
-      }
-      geometry_backward(C, s2, rc, gq0, gq1, gI, gacc, first, gpm);
+      f2 gp, q0p, q1p;
+      float gs, q0s, q1s;
+      ssim_stage_c(g2.a.p, g1.a.p, g0.a.p, g2.b.p, g1.b.p, g0.b.p, g2.e.p, g1.e.p, g0.e.p, s2.ih.p, s2.it.p, s2.du.p, s2.dv.p, kpn, gp, q0p, q1p);
+      ssim_stage_c(g2.a.s, g1.a.s, g0.a.s, g2.b.s, g1.b.s, g0.b.s, g2.e.s, g1.e.s, g0.e.s, s2.ih.s, s2.it.s, s2.du.s, s2.dv.s, kpn, gs, q0s, q1s);
+      const float gI[3] = {gp.x, gp.y, gs};
+      geometry_backward(C, s2, rc, vhadd(q0p) + q0s, vhadd(q1p) + q1s, gI, gacc, first, gpm);
     }
   }
   SFM_STAMP(t4);
@@ -320,20 +365,15 @@ __device__ __forceinline__ void l1_source_pass(const SsimCtx& C, float* gacc, co
       sgm = rcp(1.0f + __expf(-lg));                                  // F.sigmoid, base_model.py:107
       if (LOSS) acc_exp += C.outf * (fmaxf(-lg, 0.f) + __logf(1.0f + __expf(-fabsf(lg))));   // softplus(-x), :165-167
     }
-    const float e1 = (fabsf(s0.ih[0] - s0.it[0]) + fabsf(s0.ih[1] - s0.it[1]) + fabsf(s0.ih[2] - s0.it[2])) * s0.nm;   // :95-100
+    const float e1 = (vabs_sum(s0.ih.p - s0.it.p) + vabs_sum(s0.ih.s - s0.it.s)) * s0.nm;   // :95-100
     if (LOSS) acc_pix = fmaf(e1 * sgm, C.outf, acc_pix);              // :109 / :111
     if (GRAD) {
       const float kpn = C.k_pix * s0.nm * sgm;
-      float gq0 = 0.f, gq1 = 0.f;
-      float gI[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float d = s0.ih[c] - s0.it[c];
-        const float g = (d != 0.f) ? __uint_as_float(__float_as_uint(kpn) ^ (__float_as_uint(d) & 0x80000000u)) : 0.f;
-        gI[c] = g;
-        gq0 = fmaf(g, s0.du[c], gq0);
-        gq1 = fmaf(g, s0.dv[c], gq1);
-      }
+      const f2 gp = ksign(kpn, s0.ih.p - s0.it.p);
+      const float gs = ksign(kpn, s0.ih.s - s0.it.s);
+      const float gI[3] = {gp.x, gp.y, gs};
+      const float gq0 = vhadd(gp * s0.du.p) + gs * s0.du.s;
+      const float gq1 = vhadd(gp * s0.dv.p) + gs * s0.dv.s;
       if (EXPL) {
         // d/dlogit of (1-alpha) mean(err sigmoid) + exp_reg mean(softplus(-logit))
         if (C.outf != 0.f) C.dmp[(unsigned)r * (unsigned)C.w + C.xc] = C.k_pix * e1 * sgm * (1.f - sgm) + C.k_exp * (sgm - 1.f);
