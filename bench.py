@@ -89,10 +89,65 @@ def cpu_baseline(budget_s=15.0):
         times.append(time.perf_counter() - t0)
     med = float(np.median(times))
     px = 1 * 2 * 128 * 416
-    return {"value": round(px / med / 1e6, 4), "unit": "Mpix/s", "cores": 1, "kind": "port",
-            "sample": "cfg1 (B=1, 128x416, 1 scale, 2 src, L1 only) fwd+bwd, median of %d runs, %.3f s/step; "
-                      "single-threaded NumPy oracle, host has %d cores (%d usable)" % (
-                          len(times), med, os.cpu_count(), len(os.sched_getaffinity(0)))}
+    out = {"value": round(px / med / 1e6, 4), "unit": "Mpix/s", "cores": 1, "kind": "port",
+           "sample": "cfg1 (B=1, 128x416, 1 scale, 2 src, L1 only) fwd+bwd, median of %d runs, %.3f s/step; "
+                     "single-threaded NumPy oracle, host has %d cores (%d usable)" % (
+                         len(times), med, os.cpu_count(), len(os.sched_getaffinity(0)))}
+    try:
+        out["all_cores"] = cpu_baseline_all_cores(px)
+    except Exception as e:   # the one-core figure above is the baseline; this one is a courtesy
+        out["all_cores"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
+_CPU_WORKER = r"""
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+import importlib
+import numpy as np
+from oracle import sfm_oracle as O
+synth = importlib.import_module(sys.argv[2] + ".synth")
+d = synth.make_inputs(B=1, H=128, W=416, n_src=2, n_scales=1, seed=int(sys.argv[3]))
+step = lambda: O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], backward=True)
+step()
+sys.stdout.write("ready\n"); sys.stdout.flush()
+sys.stdin.readline()                      # start gun: every worker is warm before any of them is timed
+n = 0; t0 = time.perf_counter(); budget = float(sys.argv[4])
+while time.perf_counter() - t0 < budget:
+    step(); n += 1
+sys.stdout.write("%d %.6f\n" % (n, time.perf_counter() - t0)); sys.stdout.flush()
+"""
+
+
+def cpu_baseline_all_cores(px_per_step, budget_s=8.0):
+    """the same cfg1 step as independent samples, one single-threaded process per usable
+    core (the path shards by sample), all started together; value = samples finished / wall time."""
+    import subprocess
+    n = len(os.sched_getaffinity(0))
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    procs = [subprocess.Popen([sys.executable, "-c", _CPU_WORKER, here, PKG, str(k + 1), str(budget_s)], env=env,
+                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for k in range(n)]
+    try:
+        for p in procs:
+            assert p.stdout.readline().strip() == "ready"
+        for p in procs:
+            p.stdin.write("go\n"); p.stdin.flush()
+        rate = 0.0
+        steps = 0
+        for p in procs:
+            k, dt = p.stdout.readline().split()
+            rate += int(k) * px_per_step / float(dt)
+            steps += int(k)
+    finally:
+        for p in procs:
+            try:
+                p.stdin.close()
+            except Exception:
+                pass
+            p.wait(timeout=60)
+    return {"value": round(rate / 1e6, 4), "unit": "Mpix/s", "cores": n,
+            "sample": "%d independent cfg1 samples in %d single-threaded processes, %.0f s each" % (steps, n, budget_s)}
 
 
 def main():

@@ -186,7 +186,7 @@ __device__ __forceinline__ float from_right(float x) {
 #undef from_right
 #endif
 __device__ __forceinline__ float hsum3(float x) {
-  asm volatile("" : "+v"(x));   // keep x a materialised value: an FMA contraction of its producer into the adds would block the DPP operand folding
+  asm("" : "+v"(x));   // keep x a materialised value: an FMA contraction of its producer into the adds would block the DPP operand folding
   return (x + from_left(x)) + from_right(x);
 }
 
@@ -217,7 +217,11 @@ __device__ __forceinline__ float signf(float t) { return (t != 0.f) ? __builtin_
 struct __attribute__((packed, aligned(4))) Tap2 {
   float a, b;
 };
+#ifdef SFM_TAP_DWORDS   // timing experiment only: two 4-byte loads per tap pair (the laundered pointer keeps them from being re-merged)
+__device__ __forceinline__ Tap2 load_tap2(const float* p) { Tap2 t; t.a = p[0]; const float* q = p + 1; asm("" : "+v"(q)); t.b = *q; return t; }
+#else
 __device__ __forceinline__ Tap2 load_tap2(const float* p) { return *reinterpret_cast<const Tap2*>(p); }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // The per-pixel projection + sampling coordinates shared by every kernel.

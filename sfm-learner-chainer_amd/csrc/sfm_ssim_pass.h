@@ -73,6 +73,32 @@ __device__ __forceinline__ float vfma(float a, float b, float c) { return fmaf(a
 __device__ __forceinline__ f2 vrcp(f2 a) { f2 r; r.x = rcp(a.x); r.y = rcp(a.y); return r; }
 __device__ __forceinline__ float vrcp(float a) { return rcp(a); }
 __device__ __forceinline__ f2 hsum3(f2 v) { f2 r; r.x = hsum3(v.x); r.y = hsum3(v.y); return r; }
+// a + (its left neighbour), b + (the right neighbour of a): per component, so that each is ONE v_add_f32_dpp
+__device__ __forceinline__ float add_left(float a) { return a + from_left(a); }
+__device__ __forceinline__ float add_right(float b, float a) { return b + from_right(a); }
+__device__ __forceinline__ f2 add_left(f2 a) { f2 r; r.x = add_left(a.x); r.y = add_left(a.y); return r; }
+__device__ __forceinline__ f2 add_right(f2 b, f2 a) { f2 r; r.x = add_right(b.x, a.x); r.y = add_right(b.y, a.y); return r; }
+__device__ __forceinline__ void pin(float& x) { asm("" : "+v"(x)); }   // see hsum3(float)
+__device__ __forceinline__ void pin(f2& v) { asm("" : "+v"(v)); }
+// Horizontal 3-sums of several fields at once, the DPP adds of the fields interleaved: a DPP operand written by the
+// instruction just before costs an s_nop (2 wait states), and left to itself the scheduler puts each field's two DPP
+// adds right behind its producer (tools/nop_cost.hip: 3.15 -> 2.83 cycles per instruction at 3 waves per SIMD).
+template <typename T>
+__device__ __forceinline__ void hsum3_group(T& a, T& b, T& c, T& d) {
+  pin(a); pin(b); pin(c); pin(d);
+  __builtin_amdgcn_sched_barrier(0);
+  const T la = add_left(a), lb = add_left(b), lc = add_left(c), ld = add_left(d);
+  a = add_right(la, a); b = add_right(lb, b); c = add_right(lc, c); d = add_right(ld, d);
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <typename T>
+__device__ __forceinline__ void hsum3_group(T& a, T& b, T& c) {
+  pin(a); pin(b); pin(c);
+  __builtin_amdgcn_sched_barrier(0);
+  const T la = add_left(a), lb = add_left(b), lc = add_left(c);
+  a = add_right(la, a); b = add_right(lb, b); c = add_right(lc, c);
+  __builtin_amdgcn_sched_barrier(0);
+}
 __device__ __forceinline__ float vclamp01_sum(f2 e) { return fminf(fmaxf(e.x, 0.f), 1.f) + fminf(fmaxf(e.y, 0.f), 1.f); }
 __device__ __forceinline__ float vclamp01_sum(float e) { return fminf(fmaxf(e, 0.f), 1.f); }
 // v where 0 < e < 1, else 0   (F.clip backward)
@@ -124,16 +150,39 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
 #ifdef SFM_ABLATE_MEM   // timing experiment only: every access hits the same few cache lines
   const unsigned off = (unsigned)((p.v0 * C.w + p.u0) & 63);
   const unsigned offt = (unsigned)((r * C.w + C.xc) & 63);
+#elif defined(SFM_ABLATE_ALIGN)   // timing experiment only: 8-byte aligned taps
+  const unsigned off = (unsigned)(p.v0 * C.w + p.u0) & ~1u;
+  const unsigned offt = (unsigned)r * (unsigned)C.w + C.xc;
 #else
   const unsigned off = (unsigned)(p.v0 * C.w + p.u0);
   const unsigned offt = (unsigned)r * (unsigned)C.w + C.xc;
 #endif
+#ifdef SFM_ABLATE_NOLOAD   // timing experiment only (wrong values): no vector memory loads in the row loop at all
+  {
+    const float f = __uint_as_float(0x3f800000u | (off & 0xffffu)), g = __uint_as_float(0x3f800000u | (offt & 0xffffu));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { ps.t[c].a = f; ps.t[c].b = f + 0.25f * c; ps.b[c].a = f * 0.5f; ps.b[c].b = f - 0.125f * c; ps.it[c] = g + c; }
+  }
+#elif defined(SFM_EXP_TEXEL)   // timing experiment only (wrong values): the access pattern of an RGBX texel layout
+  {
+    const unsigned lim = (unsigned)(C.h * C.w) * 3u / 4u - (unsigned)C.w - 2u;
+    unsigned i4 = off - (off >> 2); i4 = i4 < lim ? i4 : lim;
+    unsigned j4 = offt - (offt >> 2); j4 = j4 < lim ? j4 : lim;
+    const float4* s4 = reinterpret_cast<const float4*>(C.sp[0]);
+    const float4* t4 = reinterpret_cast<const float4*>(C.tp[0]);
+    const float4 T0 = s4[i4], T1 = s4[i4 + 1], B0 = s4[i4 + (unsigned)C.w], B1 = s4[i4 + (unsigned)C.w + 1], I4 = t4[j4];
+    ps.t[0].a = T0.x; ps.t[1].a = T0.y; ps.t[2].a = T0.z; ps.t[0].b = T1.x; ps.t[1].b = T1.y; ps.t[2].b = T1.z;
+    ps.b[0].a = B0.x; ps.b[1].a = B0.y; ps.b[2].a = B0.z; ps.b[0].b = B1.x; ps.b[1].b = B1.y; ps.b[2].b = B1.z;
+    ps.it[0] = I4.x; ps.it[1] = I4.y; ps.it[2] = I4.z;
+  }
+#else
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     ps.t[c] = load_tap2(C.sp[c] + off);
     ps.b[c] = load_tap2(C.sp[c] + off + (unsigned)C.w);
     ps.it[c] = C.tp[c][offt];
   }
+#endif
   if (C.mp != nullptr) ps.lg = C.mp[offt];
 }
 
@@ -207,11 +256,12 @@ __device__ __forceinline__ void ssim_stage_b(const T x2, const T x1, const T x0,
                                              const float kq_nm, T& ga, T& gb, T& ge, float& ssum) {
   const float C1 = 81.f * 0.0001f, C2 = 81.f * 0.0009f;             // 81 c1, 81 c2   base_model.py:127-128
   // separable 3x3 sums around (r-1, x): vertical over the ring rows r-2..r (in-lane), then horizontal (DPP)
-  const T Sx = hsum3(x2 + x1 + x0);
-  const T Sy = hsum3(y2 + y1 + y0);
+  T Sx = x2 + x1 + x0;
+  T Sy = y2 + y1 + y0;
   // sigma_x + sigma_y only ever appear together (base_model.py:138), so E[xx] and E[yy] are pooled as one field
-  const T Sqq = hsum3(vfma(x2, x2, vfma(x1, x1, vfma(x0, x0, vfma(y2, y2, vfma(y1, y1, y0 * y0))))));
-  const T Sxy = hsum3(vfma(x2, y2, vfma(x1, y1, x0 * y0)));
+  T Sqq = vfma(x2, x2, vfma(x1, x1, vfma(x0, x0, vfma(y2, y2, vfma(y1, y1, y0 * y0)))));
+  T Sxy = vfma(x2, y2, vfma(x1, y1, x0 * y0));
+  hsum3_group(Sx, Sy, Sqq, Sxy);
   const T pxy = Sx * Sy;
   const T sq = vfma(Sx, Sx, Sy * Sy);
   const T N1 = pxy * 2.f + C1;
@@ -225,9 +275,10 @@ __device__ __forceinline__ void ssim_stage_b(const T x2, const T x1, const T x0,
   if (GRAD) {
     const T kap = vsel_open01(e, rD * kq_nm);                       // kappa / (D1 D2); F.clip backward: 0 < e < 1
     const T u3 = vfma(-(Sv * Sx), D2 - D1, Sy * (N2 - N1));
-    ga = hsum3(kap * u3 * 2.f);               // (1/9) kappa dS/dmu_x
-    gb = hsum3(kap * Sv * D1 * -9.f);         // (1/9) kappa dS/dE[xx]
-    ge = hsum3(kap * N1 * 18.f);              // (1/9) kappa dS/dE[xy]
+    ga = kap * u3 * 2.f;                      // (1/9) kappa dS/dmu_x
+    gb = kap * Sv * D1 * -9.f;                // (1/9) kappa dS/dE[xx]
+    ge = kap * N1 * 18.f;                     // (1/9) kappa dS/dE[xy]
+    hsum3_group(ga, gb, ge);
   }
 }
 
@@ -249,17 +300,6 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const int r, con
                                               RowG& g0, const RowG& g1, const RowG& g2, float* gacc, const bool first,
                                               float& acc_pix, float& acc_ssim, float* gpm SFM_STAMPS_ARG) {
   const int h = C.h, w = C.w;
-#ifndef SFM_NO_PRIO_ROTATION
-  // The SIMD's issue arbiter prefers the oldest wave, so co-resident waves finish one after the other and
-  // the SIMD ends its launch with one lone wave at a fraction of its issue rate.  Rotating a raised
-  // priority among the waves of a SIMD by wall-clock time lets them advance evenly and finish together.
-  {
-    const unsigned slot = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (3 << 11));   // HW_ID.WAVE_ID: slot on this SIMD
-    const unsigned phase = (unsigned)(__builtin_amdgcn_s_memtime() >> 12);
-    if ((phase + slot) % 3u == 0u) __builtin_amdgcn_s_setprio(1);
-    else __builtin_amdgcn_s_setprio(0);
-  }
-#endif
 #ifdef SFM_STAMPS
   unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
 #endif
@@ -274,23 +314,36 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const int r, con
   SFM_STAMP(t2);
 
   // ---------------- B: SSIM at row r-1 ----------------
+  // The first two steps of a pass only fill the ring: their centre rows lie above every row whose SSIM value
+  // (forward) or SSIM partials (gradient, one more row) anything will read, so the whole stage is skipped
+  // (wave-uniform branch).
   const int rb = r - 1;
-  float ssum = 0.f;
-  const float kq_nm = C.kq * s1.nm;   // kappa before the clip test; s1.nm is 0 outside the image and on masked pixels (:114)
-  ssim_stage_b<GRAD, LOSS>(s2.ih.p, s1.ih.p, s0.ih.p, s2.it.p, s1.it.p, s0.it.p, kq_nm, g0.a.p, g0.b.p, g0.e.p, ssum);
-  ssim_stage_b<GRAD, LOSS>(s2.ih.s, s1.ih.s, s0.ih.s, s2.it.s, s1.it.s, s0.it.s, kq_nm, g0.a.s, g0.b.s, g0.e.s, ssum);
-  if (LOSS) {   // branch-free: a halo row simply gets weight 0 (a branch here would split the block and un-fold the DPP adds)
-    const float wgt = (rb >= C.y0 && rb < C.y1) ? s1.nm * C.outf : 0.f;
-    acc_ssim = fmaf(ssum, wgt, acc_ssim);                            // base_model.py:114-115
-    const float e1 = vabs_sum(s1.ih.p - s1.it.p) + vabs_sum(s1.ih.s - s1.it.s);   // :95
-    acc_pix = fmaf(e1, wgt, acc_pix);                                // :98-100,:111
+#ifdef SFM_ABLATE_NO_B   // timing experiment only (wrong values)
+  if (false) {
+#else
+  if (rb >= C.y0 - (GRAD ? 1 : 0)) {
+#endif
+    float ssum = 0.f;
+    const float kq_nm = C.kq * s1.nm;   // kappa before the clip test; s1.nm is 0 outside the image and on masked pixels (:114)
+    ssim_stage_b<GRAD, LOSS>(s2.ih.p, s1.ih.p, s0.ih.p, s2.it.p, s1.it.p, s0.it.p, kq_nm, g0.a.p, g0.b.p, g0.e.p, ssum);
+    ssim_stage_b<GRAD, LOSS>(s2.ih.s, s1.ih.s, s0.ih.s, s2.it.s, s1.it.s, s0.it.s, kq_nm, g0.a.s, g0.b.s, g0.e.s, ssum);
+    if (LOSS) {   // branch-free: a halo row simply gets weight 0 (a branch here would split the block and un-fold the DPP adds)
+      const float wgt = (rb >= C.y0 && rb < C.y1) ? s1.nm * C.outf : 0.f;
+      acc_ssim = fmaf(ssum, wgt, acc_ssim);                            // base_model.py:114-115
+      const float e1 = vabs_sum(s1.ih.p - s1.it.p) + vabs_sum(s1.ih.s - s1.it.s);   // :95
+      acc_pix = fmaf(e1, wgt, acc_pix);                                // :98-100,:111
+    }
   }
 
   SFM_STAMP(t3);
   // ---------------- C: gradients at row r-2 ----------------
   if (GRAD) {
     const int rc = r - 2;
+#ifdef SFM_ABLATE_NO_C   // timing experiment only (wrong values)
+    if (false) {
+#else
     if (rc >= C.y0 && rc < C.y1) {
+#endif
       const float kpn = C.k_pix * s2.nm;
       f2 gp, q0p, q1p;
       float gs, q0s, q1s;

@@ -18,6 +18,8 @@ ops.lib.sfm_loss_debug_trace(C.c_void_p(buf.data_ptr()))
 run(); torch.cuda.synchronize()
 raw = buf.cpu().numpy()
 nz = int((raw != 0).any(axis=1).sum())
+if os.environ.get("SFM_TRACE_DUMP"):
+    np.save(os.environ["SFM_TRACE_DUMP"], raw[:nz])
 stamps = os.environ.get("SFMWARP_LIB", "").endswith("stamps.so")
 n_items = nz // 3 if stamps else nz
 a = raw[:n_items]
