@@ -225,7 +225,10 @@ __device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& 
   const float gD = fmaf(gq0, a0, fmaf(gq1, a1, gq2 * a2));
   const float gdisp = -gD * s2.D * s2.D;                         // d(1/d) = -1/d^2, base_model.py:60
   float* ga = gacc + (rc - C.y0) * 64 + C.lane;
-  *ga = first ? gdisp : (*ga + gdisp);
+  // the tile is private to this wave: a plain store for the first contribution, then LDS adds without return value
+  // (ds_add_f32: nothing to wait for, unlike a read-modify-write through a register)
+  if (first) *ga = gdisp;
+  else (void)__hip_atomic_fetch_add(ga, gdisp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
   const float cc0 = s2.D * fmaf(C.K1[0], yf, C.kx[0]);
   const float cc1 = s2.D * fmaf(C.K1[1], yf, C.kx[1]);
   const float cc2 = s2.D * fmaf(C.K1[2], yf, C.kx[2]);
