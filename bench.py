@@ -123,7 +123,8 @@ def cpu_baseline_all_cores(px_per_step, budget_s=8.0):
     """the same cfg1 step as independent samples, one single-threaded process per usable
     core (the path shards by sample), all started together; value = samples finished / wall time."""
     import subprocess
-    n = len(os.sched_getaffinity(0))
+    # a 1-GPU box is given a share of 16 host cores, whatever the affinity mask says
+    n = min(len(os.sched_getaffinity(0)), int(os.environ.get("SFM_CPU_BASELINE_PROCS", "16")))
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
     here = os.path.dirname(os.path.abspath(__file__))
     procs = [subprocess.Popen([sys.executable, "-c", _CPU_WORKER, here, PKG, str(k + 1), str(budget_s)], env=env,

@@ -55,6 +55,8 @@ struct LossArgs {
   float gy;          // upstream gradient on total_loss
   float alpha;       // ssim_rate
   unsigned long long* trace;   // diagnostics: per item {t_start, t_end (100 MHz), HW_ID, XCC_ID}; normally nullptr
+  int simds_per_xcd;           // SIMDs of one XCD (dispatch rounds -> age rank, see loss_kernel)
+  int prio_top;                // resident waves per SIMD - 1, at most 3
 };
 
 template <bool SSIM, bool GRAD, int SMODE>
@@ -214,6 +216,13 @@ __device__ __forceinline__ void smooth_edge_pass(const LossArgs& A, const ScaleA
 // ------------------------------------------------------------------------------------------
 // the main kernel: one wavefront per (scale, sample, strip, chunk)
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void set_issue_prio(const int p) {   // s_setprio takes an immediate
+  if (p <= 0) __builtin_amdgcn_s_setprio(0);
+  else if (p == 1) __builtin_amdgcn_s_setprio(1);
+  else if (p == 2) __builtin_amdgcn_s_setprio(2);
+  else __builtin_amdgcn_s_setprio(3);
+}
+
 template <bool SSIM, bool GRAD, bool LOSS, bool EXPL, int SMODE>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) loss_kernel(const LossArgs A) {
   using HH = Halo<SSIM, GRAD, SMODE>;
@@ -260,6 +269,13 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
   const int item = S.item_begin + b * S.tiles + t;
   unsigned long long t_start = 0;
   if (A.trace) t_start = __builtin_amdgcn_s_memrealtime();
+  // Issue priority.  The SIMD arbiter prefers the oldest wave, so of the co-resident waves of a SIMD one runs ahead
+  // and the SIMD ends its launch with a lone wave at half its throughput (profiles/r01_wave_stage_stamps.txt).  The
+  // dispatcher places workgroups j, j + S, j + 2S ... of an XCD (S = its SIMD count) on the same SIMD in that age
+  // order, so the dispatch round is the age rank: the youngest is preferred during the first half of the sources,
+  // the oldest during the second, and the waves of a SIMD finish closer together.  Only ever affects speed.
+  const int prio_rank = min((int)(blockIdx.x >> 3) / A.simds_per_xcd, A.prio_top);
+  set_issue_prio(prio_rank);
   const int chunk = t / S.strips;
   const int strip = t - chunk * S.strips;
   const int h = S.h, w = S.w;
@@ -290,6 +306,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
   SFM_STAMP(ts1);
 #endif
   for (int i = 0; i < A.n_src; ++i) {
+    if (i * 2 >= A.n_src) set_issue_prio(A.prio_top - prio_rank);
     SsimCtx C;
     // the geometry table was written by geom_kernel before this launch and is read-only here: reading it
     // through the constant address space lets the wave fetch the 32 floats with a few scalar loads
@@ -471,13 +488,15 @@ static thread_local unsigned long long* g_trace = nullptr;   // sfm_loss_debug_t
 template <bool GRAD, bool LOSS>
 static const void* kernel_ptr(bool ssim, bool expl, int smode);
 
-static int wave_slots(const void* kernel) {
+static int wave_slots(const void* kernel, int* simds_per_xcd = nullptr, int* waves_per_simd = nullptr) {
   int dev = 0, cus = 0, per_cu = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
       hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64 * WAVES_PER_BLOCK, 0) != hipSuccess || cus <= 0 || per_cu <= 0) {
     (void)hipGetLastError();
-    return 2048;   // no device visible (workspace query on a CPU-only host): MI355X, 2 waves per SIMD
+    cus = 256; per_cu = 8;   // no device visible (workspace query on a CPU-only host): MI355X, 2 waves per SIMD
   }
+  if (simds_per_xcd) *simds_per_xcd = (cus % 8 == 0) ? cus / 8 * 4 : 128;   // gfx950: 8 XCDs, 4 SIMDs per CU
+  if (waves_per_simd) *waves_per_simd = (per_cu * WAVES_PER_BLOCK + 3) / 4;
   return cus * per_cu * WAVES_PER_BLOCK;
 }
 
@@ -560,7 +579,10 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
     if (d->H[s] < 3 || d->W[s] < 3) return fail(SFM_ERR_SHAPE, "sfm_loss: scale %d is %dx%d, need H,W >= 3", s, d->H[s], d->W[s]);
   const void* kfn = grad ? (need_loss ? kernel_ptr<true, true>(p.ssim, p.expl, p.smode) : kernel_ptr<true, false>(p.ssim, p.expl, p.smode))
                          : kernel_ptr<false, true>(p.ssim, p.expl, p.smode);
-  plan_chunks(d, sw, 2 * (hs > hm ? hs : hm), wave_slots(kfn), rows);
+  int waves_per_simd = 1;
+  const int slots = wave_slots(kfn, &A.simds_per_xcd, &waves_per_simd);
+  A.prio_top = waves_per_simd - 1 < 3 ? waves_per_simd - 1 : 3;
+  plan_chunks(d, sw, 2 * (hs > hm ? hs : hm), slots, rows);
   int items = 0;
   for (int s = 0; s < d->n_scales; ++s) {
     const int h = d->H[s], w = d->W[s];
