@@ -162,6 +162,10 @@ def main():
                          "fused: one sfm_loss_fwd_bwd launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch of the workload (experiments only)")
+    ap.add_argument("--report-interval", type=int, default=0,
+                    help="steps per reporting interval: the five scalars of the steps of an interval are summed over the ranks "
+                         "with ONE all-reduce at its end (the reference's trainer reports at LogReport's interval, not per "
+                         "iteration).  0 = one interval over the K timed steps; 1 = a collective every step")
     args = ap.parse_args()
 
     import numpy as np
@@ -196,26 +200,35 @@ def main():
     ev = HipEvents()
     lib = ops.lib
 
-    def step(evs=None):
+    # The only collective of the path: the five reported scalars summed over the shards (RCCL over xGMI).  Every
+    # step writes its scalars into its own row of a device-resident log; the rows of a reporting interval are
+    # reduced with one all-reduce at the interval's end, in stream order, inside the timed region.  (Per-sample
+    # gradients never leave their rank.  A collective per step is --report-interval 1.)
+    interval = args.report_interval if args.report_interval > 0 else max(args.steps, 1)
+    n_log = max(args.steps, args.warmup, 1)
+    loss_log = torch.zeros((n_log, 5), dtype=torch.float32, device=dev)
+    rows = [loss_log[k] for k in range(n_log)]
+
+    def step(k, evs=None):
         if args.mode == "fused":
             if evs:
                 lib.sfm_loss_profile_events(evs[0], evs[1])
-            fl.forward_backward()
+            fl.forward_backward(out=rows[k])
         else:
             if evs:
                 lib.sfm_loss_profile_events(evs[0], evs[1])
-            fl.forward()
+            fl.forward(out=rows[k])
             if evs:
                 lib.sfm_loss_profile_events(evs[2], evs[3])
             fl.backward(1.0)
-        if use_dist:
-            # the only collective of the path: the five reported scalars summed over the shards (RCCL).  Issued
-            # synchronously in stream order: an async_op=True variant with rotating buffers measured SLOWER
-            # (111 vs 95 us per step at N=1, tools/allreduce_overhead.py)
-            dist.all_reduce(fl.loss5)
+        if use_dist and ((k + 1) % interval == 0 or k + 1 == n_steps_now[0]):
+            lo = (k // interval) * interval
+            dist.all_reduce(loss_log[lo:k + 1])
 
-    for _ in range(args.warmup):
-        step()
+    n_steps_now = [args.warmup]
+    for k in range(args.warmup):
+        step(k)
+    n_steps_now[0] = args.steps
     events = [[ev.create() for _ in range(4)] for _ in range(args.steps)]
     torch.cuda.synchronize()
     if use_dist:
@@ -223,7 +236,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(events[k])
+        step(k, events[k])
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -257,7 +270,7 @@ def main():
     # per-launch duration of the main kernels, from the HIP events recorded inside the timed region
     k_fwd = float(np.mean([ev.elapsed_ms(e[0], e[1]) for e in events]))
     k_bwd = float(np.mean([ev.elapsed_ms(e[2], e[3]) for e in events])) if args.mode == "separate" else None
-    loss = fl.loss5.cpu().numpy().tolist()
+    loss = loss_log[max(args.steps - 1, 0)].cpu().numpy().tolist()
     for e4 in events:
         for e in e4:
             ev.destroy(e)
@@ -294,7 +307,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "per_gpu_batch": B, "global_batch": B * world, "H": H, "W": W, "n_src": n_src,
                        "n_scales": n_scales, "mode": args.mode, "warped_px_per_gpu_step": warped_px,
-                       "parallelism": "batch-sharded x%d, RCCL all-reduce of 5 scalars" % world},
+                       "parallelism": "batch-sharded x%d, RCCL all-reduce of the 5 scalars per reporting interval (%d steps)" % (world, interval)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_detail": traffic_detail, "kernel": kname, "kernel_ms": round(kms, 5), "bytes_per_warped_px": kbytes},

@@ -280,10 +280,12 @@ class FusedLoss:
             for t in self.d_srcs:
                 t.zero_()
 
-    def forward(self):
+    def forward(self, out=None):
+        """`out`: as for forward_backward."""
+        loss5 = self.loss5 if out is None else out
         with torch.cuda.device(self.device):
-            check(lib.sfm_loss_fwd(C.byref(self.desc), _p(self.loss5), C.c_void_p(self._ws_ptr), self._ws_bytes, _stream()))
-        return self.loss5
+            check(lib.sfm_loss_fwd(C.byref(self.desc), _p(loss5), C.c_void_p(self._ws_ptr), self._ws_bytes, _stream()))
+        return loss5
 
     def backward(self, gy=1.0):
         self._zero_d_src()
@@ -293,7 +295,7 @@ class FusedLoss:
 
     def forward_backward(self, out=None):
         """`out`: optional (5,) float32 device tensor to receive the five scalars instead of `self.loss5`
-        (lets a caller rotate output slots, e.g. to all-reduce them asynchronously)."""
+        (lets a caller keep a log of the steps of a reporting interval and reduce it across ranks once)."""
         self._zero_d_src()
         loss5 = self.loss5 if out is None else out
         with torch.cuda.device(self.device):

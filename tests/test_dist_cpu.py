@@ -40,8 +40,12 @@ def _worker(rank, world, port, out_dir):
     res = O.sfm_loss(sh["tgt_pyr"], sh["src_pyr"], sh["intrinsics"], sh["disps"], sh["poses"], backward=True,
                      norm_batch=sh["global_B"], **CFG)
     loss5 = torch.tensor([res[k] for k in KEYS], dtype=torch.float64)
+    # bench.py keeps one row of scalars per step and reduces the rows of a reporting interval with ONE collective
+    log = torch.stack([loss5 * (k + 1) for k in range(3)])      # three "steps" of an interval
     dmod.allreduce_losses(loss5)
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), loss5=loss5.numpy(), d_disp0=res.d_disps[0], d_pose0=res.d_poses[0])
+    dmod.allreduce_losses(log)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), loss5=loss5.numpy(), log=log.numpy(), d_disp0=res.d_disps[0],
+             d_pose0=res.d_poses[0])
     dist.barrier()
     dist.destroy_process_group()
 
@@ -60,6 +64,7 @@ def test_two_rank_batch_sharding_over_gloo(tmp_path):
     outs = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
     for o in outs:                                    # every rank holds the global scalars after the all-reduce
         np.testing.assert_allclose(o["loss5"], want, rtol=1e-6)
+        np.testing.assert_allclose(o["log"], np.outer([1.0, 2.0, 3.0], want), rtol=1e-6)   # one collective per interval
     # a rank's gradients are those of its samples in the full batch: no exchange needed
     for r, o in enumerate(outs):
         lo, hi = dmod.shard_range(5, r, world)
