@@ -162,6 +162,9 @@ def main():
                          "fused: one sfm_loss_fwd_bwd launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch of the workload (experiments only)")
+    ap.add_argument("--layout", default="hwc", choices=["hwc", "planar"],
+                    help="memory layout of the image pyramids resident in HBM when the timed region starts: hwc = pixel-"
+                         "interleaved, as sfm_pyramid_hwc_fwd writes them (default); planar = the reference's (B,3,h,w)")
     ap.add_argument("--report-interval", type=int, default=0,
                     help="steps per reporting interval: the five scalars of the steps of an interval are summed over the ranks "
                          "with ONE all-reduce at its end (the reference's trainer reports at LogReport's interval, not per "
@@ -193,8 +196,16 @@ def main():
         B, desc = args.batch, desc + " [per-GPU batch overridden to %d]" % args.batch
     d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=n_scales, seed=1 + rank)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    fl = ops.FusedLoss(**cfg).bind([t(a) for a in d["tgt_pyr"]], [t(a) for a in d["src_pyr"]], t(d["intrinsics"]),
-                                   [t(a) for a in d["disps"]], [t(a) for a in d["poses"]], norm_B=B * world)
+    tgt_planar, src_planar = [t(a) for a in d["tgt_pyr"]], [t(a) for a in d["src_pyr"]]
+    common = (t(d["intrinsics"]), [t(a) for a in d["disps"]], [t(a) for a in d["poses"]])
+
+    def bound(layout):
+        if layout == "hwc":     # the same values, pixel-interleaved
+            return ops.FusedLoss(**cfg).bind([ops.to_hwc(a) for a in tgt_planar], [ops.to_hwc(a) for a in src_planar], *common,
+                                             norm_B=B * world, layout="hwc")
+        return ops.FusedLoss(**cfg).bind(tgt_planar, src_planar, *common, norm_B=B * world)
+
+    fl = bound(args.layout)
     warped_px = B * n_src * sum((H >> s) * (W >> s) for s in range(n_scales))
 
     ev = HipEvents()
@@ -247,7 +258,23 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # secondary measurement (NOT part of the timed K steps above): the other launch mode, for the record
+    # secondary measurements (NOT part of the timed K steps above), for the record: the other image layout ...
+    other_layout = "planar" if args.layout == "hwc" else "hwc"
+    other_layout_ms = None
+    if world == 1:
+        fl2 = bound(other_layout)
+        run2 = fl2.forward_backward if args.mode == "fused" else (lambda: (fl2.forward(), fl2.backward(1.0)))
+        for _ in range(5):
+            run2()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_other = max(10, args.steps // 4)
+        for _ in range(n_other):
+            run2()
+        torch.cuda.synchronize()
+        other_layout_ms = (time.perf_counter() - t1) / n_other * 1e3
+        del fl2
+    # ... and the other launch mode
     other_mode = "separate" if args.mode == "fused" else "fused"
     other_ms = None
     if world == 1:
@@ -288,7 +315,8 @@ def main():
         traffic = traffic_detail = None
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", "r01_summary.json")))
-            if prof["bench"]["config"]["mode"] == args.mode and args.workload == "cfg3" and args.batch == 0:
+            if prof["bench"]["config"]["mode"] == args.mode and args.workload == "cfg3" and args.batch == 0 \
+                    and prof["bench"]["config"].get("image_layout", "planar") == args.layout:
                 want = "sfm_loss_fwd_bwd" if args.mode == "fused" else "sfm_loss_bwd"
                 for kn, kv in prof["kernels"].items():
                     if kv.get("entry_point") == want and "hbm_bytes_raw" in kv:
@@ -306,7 +334,7 @@ def main():
             "ms_per_step": round(ms_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "per_gpu_batch": B, "global_batch": B * world, "H": H, "W": W, "n_src": n_src,
-                       "n_scales": n_scales, "mode": args.mode, "warped_px_per_gpu_step": warped_px,
+                       "n_scales": n_scales, "mode": args.mode, "image_layout": args.layout, "warped_px_per_gpu_step": warped_px,
                        "parallelism": "batch-sharded x%d, RCCL all-reduce of the 5 scalars per reporting interval (%d steps)" % (world, interval)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -317,6 +345,8 @@ def main():
             "step_roofline_frac": round((BYTES_FWD + BYTES_BWD) * warped_px / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "other_mode": {"mode": other_mode, "ms_per_step": round(other_ms, 5) if other_ms else None,
                            "value": round(warped_px / (other_ms * 1e-3) / 1e6, 1) if other_ms else None},
+            "other_layout": {"image_layout": other_layout, "ms_per_step": round(other_layout_ms, 5) if other_layout_ms else None,
+                             "value": round(warped_px / (other_layout_ms * 1e-3) / 1e6, 1) if other_layout_ms else None},
             "loss5": [round(v, 6) for v in loss],
         }
         if not args.no_cpu_baseline and world == 1:

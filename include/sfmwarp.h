@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SFM_ABI_VERSION 1
+#define SFM_ABI_VERSION 2
 
 #define SFM_OK 0
 #define SFM_ERR_NULL (-1)      /* a required pointer is NULL                       */
@@ -106,6 +106,15 @@ int sfm_sampler_interp_bwd(const float *x, const float *grid, const float *gy, f
 #define SFM_SMOOTH_SECOND_ORDER 1 /* base_model.py:169-185 (the live one) */
 #define SFM_SMOOTH_EDGE_AWARE 2   /* base_model.py:144-155                */
 
+/* Memory layout of the image pyramids handed to sfm_loss_* (tgt[s], src[s]):
+ *   SFM_LAYOUT_PLANAR  the reference's: tgt (B,3,h,w), src (B,3*n_src,h,w)   (base_model.py:71-72)
+ *   SFM_LAYOUT_HWC     pixel-interleaved: tgt (B,h,w,3), src (B,n_src,h,w,3) -- what sfm_pyramid_hwc_fwd writes.
+ * Same values, same results (bit for bit); HWC lets the kernel fetch the three channels of a tap with one
+ * 12-byte load (6 instead of 10 vector loads per pixel row) and is the layout the fused loss runs fastest on.
+ * Disparities, masks and every gradient output (d_src included) are planar in both cases. */
+#define SFM_LAYOUT_PLANAR 0
+#define SFM_LAYOUT_HWC 1
+
 typedef struct SfmLossDesc {
   int32_t B;        /* samples held by this call (a batch shard)                              */
   int32_t norm_B;   /* batch size used in every mean: the GLOBAL batch when sharded, else B   */
@@ -118,8 +127,8 @@ typedef struct SfmLossDesc {
   float ssim_rate;     /* config.get('ssim_rate', 0) (:39)                                    */
   int32_t smooth_mode; /* SFM_SMOOTH_*                                                        */
   /* inputs */
-  const float *tgt[SFM_MAX_SCALES];         /* (B,3,h,w)        curr_tgt_img  (:71)           */
-  const float *src[SFM_MAX_SCALES];         /* (B,3*n_src,h,w)  curr_src_imgs (:72)           */
+  const float *tgt[SFM_MAX_SCALES];         /* (B,3,h,w)        curr_tgt_img  (:71)  [layout] */
+  const float *src[SFM_MAX_SCALES];         /* (B,3*n_src,h,w)  curr_src_imgs (:72)  [layout] */
   const float *disp[SFM_MAX_SCALES];        /* (B,1,h,w)        pred_disps    (:59)           */
   const float *mask_logits[SFM_MAX_SCALES]; /* (B,n_src,h,w)    pred_maskes (:62) or NULL     */
   const float *intrinsics;                  /* (B,n_scales,3,3) (:85)                         */
@@ -129,6 +138,7 @@ typedef struct SfmLossDesc {
   float *d_pose[SFM_MAX_SRC];    /* (B,6)         overwritten                                 */
   float *d_mask[SFM_MAX_SCALES]; /* (B,n_src,h,w) overwritten; required iff exp_reg != 0      */
   float *d_src[SFM_MAX_SCALES];  /* (B,3*n_src,h,w) or NULL; ACCUMULATED (atomics)            */
+  int32_t image_layout;          /* SFM_LAYOUT_* of tgt[] and src[]                           */
 } SfmLossDesc;
 
 /* scratch needed by the three calls below for this descriptor (0 on a bad descriptor) */
@@ -162,6 +172,10 @@ int sfm_resize_fwd(const float *x, float *y, int N, int C, int H, int W, int oH,
  * tensor.  x (N,C,H,W) -> y[s] (N,C,H>>s,W>>s) for s = 1..n_scales-1, every scale resampled from
  * the full-resolution input (as the reference does); y[0] is ignored (scale 0 is x itself). */
 int sfm_pyramid_fwd(const float *x, float *const *y, int N, int C, int H, int W, int n_scales, void *stream);
+/* The same pyramid written pixel-interleaved for SFM_LAYOUT_HWC: x (N,3*G,H,W) planar, G images per sample
+ * (1 for the target, n_src for the sources, base_model.py:50-57) -> y[s] (N,G,H>>s,W>>s,3) for s = 0..n_scales-1
+ * (scale 0 is the re-laid-out input).  Values are identical to sfm_pyramid_fwd's. */
+int sfm_pyramid_hwc_fwd(const float *x, float *const *y, int N, int G, int H, int W, int n_scales, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * DispNet's output activation for all scales in one launch, models/disp_net.py:7-8 and

@@ -158,7 +158,7 @@ __device__ __forceinline__ void smooth2_pass(const LossArgs& A, const ScaleArgs&
 }
 
 // edge-aware first-order, models/base_model.py:144-155 (commented out at :78-80 in the reference)
-template <bool GRAD, bool LOSS>
+template <bool GRAD, bool LOSS, bool HWC>
 __device__ __forceinline__ void smooth_edge_pass(const LossArgs& A, const ScaleArgs& S, const float* __restrict__ dplane,
                                                  const float* __restrict__ tplane, int lane, int x, bool xin, bool outl, int y0,
                                                  int y1, float* gacc, float& acc_sm) {
@@ -175,7 +175,7 @@ __device__ __forceinline__ void smooth_edge_pass(const LossArgs& A, const ScaleA
     const unsigned o = (unsigned)min(max(r, 0), h - 1) * (unsigned)w + xc;
     d = dplane[o];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) im[c] = tplane[c * P + o];
+    for (int c = 0; c < 3; ++c) im[c] = HWC ? tplane[3u * o + c] : tplane[c * P + o];
   };
   ldrow(y0 - 1, qd1, qi1);
   ldrow(y0, qd2, qi2);
@@ -223,7 +223,7 @@ __device__ __forceinline__ void set_issue_prio(const int p) {   // s_setprio tak
   else __builtin_amdgcn_s_setprio(3);
 }
 
-template <bool SSIM, bool GRAD, bool LOSS, bool EXPL, int SMODE>
+template <bool SSIM, bool GRAD, bool LOSS, bool EXPL, int SMODE, bool HWC>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) loss_kernel(const LossArgs A) {
   using HH = Halo<SSIM, GRAD, SMODE>;
   __shared__ float gacc_all[GRAD ? WAVES_PER_BLOCK * MAX_CHUNK_ROWS * 64 : 64];
@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
     smooth2_pass<GRAD, LOSS>(A, S, S.disp + (size_t)b * P, lane, x, xin, outl, y0, y1, gacc, acc_sm);
     first = false;
   } else if (SMODE == 2) {
-    smooth_edge_pass<GRAD, LOSS>(A, S, S.disp + (size_t)b * P, S.tgt + (size_t)b * 3 * P, lane, x, xin, outl, y0, y1, gacc, acc_sm);
+    smooth_edge_pass<GRAD, LOSS, HWC>(A, S, S.disp + (size_t)b * P, S.tgt + (size_t)b * 3 * P, lane, x, xin, outl, y0, y1, gacc, acc_sm);
     first = false;
   }
 #ifdef SFM_STAMPS
@@ -340,9 +340,9 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
     C.lane = lane;
     float* gpm_out = GRAD ? A.part_gpm + ((size_t)item * A.n_src + i) * 12 : nullptr;
     if constexpr (SSIM) {
-      ssim_source_pass<GRAD, LOSS>(C, gacc, first, acc_pix, acc_ssim, gpm_out SFM_STAMPS_PASS);
+      ssim_source_pass<GRAD, LOSS, HWC>(C, gacc, first, acc_pix, acc_ssim, gpm_out SFM_STAMPS_PASS);
     } else {
-      l1_source_pass<GRAD, LOSS, EXPL>(C, gacc, first, acc_pix, acc_exp, gpm_out);
+      l1_source_pass<GRAD, LOSS, EXPL, HWC>(C, gacc, first, acc_pix, acc_exp, gpm_out);
     }
     first = false;
   }
@@ -396,9 +396,12 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
-__global__ void __launch_bounds__(64) finalize_kernel(const LossArgs A, float* __restrict__ loss5, const int n_pose_blocks) {
-  const int lane = threadIdx.x;
+constexpr int FINALIZE_WAVES = 16;   // waves of the block that sums the loss partials (the pose blocks use one)
+
+__global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const LossArgs A, float* __restrict__ loss5, const int n_pose_blocks) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if ((int)blockIdx.x < n_pose_blocks) {
+    if (wave != 0) return;   // no block-level synchronisation in this branch
     // d_pose of (b, i): every lane folds its tiles of every scale into K_s^T . gPm (linear), ONE in-register
     // wave reduction at the end (DPP; a shuffle butterfly on doubles costs ~150 LDS-crossbar round trips)
     const int b = blockIdx.x / A.n_src, i = blockIdx.x - b * A.n_src;
@@ -438,21 +441,29 @@ __global__ void __launch_bounds__(64) finalize_kernel(const LossArgs A, float* _
   if (loss5 == nullptr) return;
   // the five reported scalars: per-lane fp64 partial sums over the items, then a fixed-order in-register
   // wave reduction of (hi, lo) float pairs (DPP), recombined in fp64
+  // (16 waves, so that the partials are fetched in one or two rounds of independent loads; the waves' sums
+  // meet in LDS and are added in wave order: the result does not depend on timing)
+  __shared__ double wave_red[FINALIZE_WAVES][4];
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   const float4* pl = reinterpret_cast<const float4*>(A.part_loss);
-#pragma unroll 8
-  for (int t = lane; t < A.items; t += 64) {
+#pragma unroll 4
+  for (int t = threadIdx.x; t < A.items; t += 64 * FINALIZE_WAVES) {
     const float4 v = pl[t];
     acc[0] += (double)v.x; acc[1] += (double)v.y; acc[2] += (double)v.z; acc[3] += (double)v.w;
   }
-  double red[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const float hi = (float)acc[k];
     const float lo = (float)(acc[k] - (double)hi);
-    red[k] = (double)wave_sum(hi) + (double)wave_sum(lo);
+    const double r = (double)wave_sum(hi) + (double)wave_sum(lo);
+    if (lane == 0) wave_red[wave][k] = r;
   }
-  if (lane == 0) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double red[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int wv = 0; wv < FINALIZE_WAVES; ++wv)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[k] += wave_red[wv][k];
     const double pixel = red[0], ssim = red[1], smooth = red[2], expl = red[3];
     const double a = (double)A.alpha;
     loss5[0] = (float)((1.0 - a) * pixel + a * ssim + smooth + expl);   // base_model.py:117-118
@@ -469,7 +480,7 @@ __global__ void __launch_bounds__(64) finalize_kernel(const LossArgs A, float* _
 struct Plan {
   LossArgs args;
   size_t off_geom, off_loss, off_gpm, total;
-  bool ssim, expl;
+  bool ssim, expl, hwc;
   int smode;
 };
 
@@ -486,7 +497,7 @@ static thread_local unsigned long long* g_trace = nullptr;   // sfm_loss_debug_t
 // whole launch, so the chunk height is chosen such that all items fit in as few full "rounds" of
 // resident waves as possible while the halo rows (recomputed per chunk) stay a small fraction.
 template <bool GRAD, bool LOSS>
-static const void* kernel_ptr(bool ssim, bool expl, int smode);
+static const void* kernel_ptr(bool ssim, bool expl, int smode, bool hwc);
 
 static int wave_slots(const void* kernel, int* simds_per_xcd = nullptr, int* waves_per_simd = nullptr) {
   int dev = 0, cus = 0, per_cu = 0;
@@ -552,6 +563,9 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
   if (d->smooth_mode < SFM_SMOOTH_NONE || d->smooth_mode > SFM_SMOOTH_EDGE_AWARE)
     return fail(SFM_ERR_CONFIG, "sfm_loss: smooth_mode=%d", d->smooth_mode);
   if (!d->intrinsics) return fail(SFM_ERR_NULL, "sfm_loss: intrinsics is NULL");
+  if (d->image_layout != SFM_LAYOUT_PLANAR && d->image_layout != SFM_LAYOUT_HWC)
+    return fail(SFM_ERR_CONFIG, "sfm_loss: image_layout=%d", d->image_layout);
+  p.hwc = d->image_layout == SFM_LAYOUT_HWC;
   p.expl = d->exp_reg > 0.f;                       // base_model.py:86,103
   p.ssim = !p.expl && d->ssim_rate > 0.f;          // base_model.py:110-112
   p.smode = d->smooth_reg > 0.f ? d->smooth_mode : SFM_SMOOTH_NONE;   // base_model.py:75
@@ -577,8 +591,8 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
   int rows[SFM_MAX_SCALES];
   for (int s = 0; s < d->n_scales; ++s)
     if (d->H[s] < 3 || d->W[s] < 3) return fail(SFM_ERR_SHAPE, "sfm_loss: scale %d is %dx%d, need H,W >= 3", s, d->H[s], d->W[s]);
-  const void* kfn = grad ? (need_loss ? kernel_ptr<true, true>(p.ssim, p.expl, p.smode) : kernel_ptr<true, false>(p.ssim, p.expl, p.smode))
-                         : kernel_ptr<false, true>(p.ssim, p.expl, p.smode);
+  const void* kfn = grad ? (need_loss ? kernel_ptr<true, true>(p.ssim, p.expl, p.smode, p.hwc) : kernel_ptr<true, false>(p.ssim, p.expl, p.smode, p.hwc))
+                         : kernel_ptr<false, true>(p.ssim, p.expl, p.smode, p.hwc);
   int waves_per_simd = 1;
   const int slots = wave_slots(kfn, &A.simds_per_xcd, &waves_per_simd);
   A.prio_top = waves_per_simd - 1 < 3 ? waves_per_simd - 1 : 3;
@@ -636,8 +650,8 @@ static void bind_workspace(Plan& p, void* ws) {
 }
 
 template <bool GRAD, bool LOSS>
-static const void* kernel_ptr(bool ssim, bool expl, int smode) {
-#define SFM_KPTR(SS, EX, SM) return (const void*)&loss_kernel<SS, GRAD, LOSS, EX, SM>
+static const void* kernel_ptr(bool ssim, bool expl, int smode, bool hwc) {
+#define SFM_KPTR(SS, EX, SM) return hwc ? (const void*)&loss_kernel<SS, GRAD, LOSS, EX, SM, true> : (const void*)&loss_kernel<SS, GRAD, LOSS, EX, SM, false>
   if (expl) {
     if (smode == 0) SFM_KPTR(false, true, 0);
     else if (smode == 1) SFM_KPTR(false, true, 1);
@@ -662,7 +676,7 @@ static void launch_main(const Plan& p, hipStream_t st) {
   int tiles_per_sample = 0;
   for (int s = 0; s < p.args.n_scales; ++s) tiles_per_sample += p.args.sc[s].tiles;
   const int per_xcd = p.args.B >= 8 ? ((p.args.B + 7) / 8) * tiles_per_sample : (p.args.items + 7) / 8;
-  (void)hipLaunchKernel(kernel_ptr<GRAD, LOSS>(p.ssim, p.expl, p.smode), dim3(8 * per_xcd), dim3(64 * WAVES_PER_BLOCK), kargs, 0, st);
+  (void)hipLaunchKernel(kernel_ptr<GRAD, LOSS>(p.ssim, p.expl, p.smode, p.hwc), dim3(8 * per_xcd), dim3(64 * WAVES_PER_BLOCK), kargs, 0, st);
 }
 
 static int run(const SfmLossDesc* d, bool grad, bool loss, float gy, float* loss5, void* ws, size_t ws_bytes, void* stream,
@@ -700,7 +714,7 @@ static int run(const SfmLossDesc* d, bool grad, bool loss, float gy, float* loss
   if (g_ev_stop) (void)hipEventRecord(g_ev_stop, st);
   g_ev_start = g_ev_stop = nullptr;
   const int n_pose_blocks = grad ? d->B * d->n_src : 0;
-  hipLaunchKernelGGL(finalize_kernel, dim3(n_pose_blocks + 1), dim3(64), 0, st, p.args, loss ? loss5 : (float*)nullptr, n_pose_blocks);
+  hipLaunchKernelGGL(finalize_kernel, dim3(n_pose_blocks + 1), dim3(64 * FINALIZE_WAVES), 0, st, p.args, loss ? loss5 : (float*)nullptr, n_pose_blocks);
   return check_launch(who);
 }
 

@@ -449,6 +449,44 @@ __global__ void pyramid_fwd_kernel(const PyramidArgs A) {
   A.y[s][(size_t)nc * oH * oW + jj] = top * wv0 + bot * wv1;
 }
 
+// The same pyramid, pixel-interleaved (SFM_LAYOUT_HWC): x (N,3G,H,W) -> y[s] (N,G,h_s,w_s,3), s = 0..S-1.  One thread
+// per output pixel computes the three channels with one set of weights; per channel the arithmetic is that of
+// pyramid_fwd_kernel, so the values agree bit for bit.  Scale 0 is a copy.
+__global__ void pyramid_hwc_fwd_kernel(const PyramidArgs A) {
+#pragma clang fp contract(off)
+  const int ng = blockIdx.y;   // n * G + g
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= A.begin[A.n_scales]) return;
+  int s = 0;
+#pragma unroll
+  for (int k = 1; k < SFM_MAX_SCALES; ++k)
+    if (k < A.n_scales && j >= A.begin[k]) s = k;
+  const int jj = j - A.begin[s];
+  const int oW = A.oW[s], oH = A.oH[s], H = A.H, W = A.W;
+  const size_t P = (size_t)H * W;
+  const float* img = A.x + (size_t)ng * 3 * P;
+  float* out = A.y[s] + ((size_t)ng * oH * oW + jj) * 3;
+  if (s == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[c] = img[c * P + jj];
+    return;
+  }
+  const int oy = jj / oW, ox = jj - oy * oW;
+  const float u = oW > 1 ? (float)((double)ox * ((double)(W - 1) / (double)(oW - 1))) : 0.f;
+  const float v = oH > 1 ? (float)((double)oy * ((double)(H - 1) / (double)(oH - 1))) : 0.f;
+  const int u0 = min(max((int)floorf(u), 0), max(W - 2, 0)), v0 = min(max((int)floorf(v), 0), max(H - 2, 0));
+  const int u1 = min(u0 + 1, W - 1), v1 = min(v0 + 1, H - 1);
+  const float wu1 = u - (float)u0, wv1 = v - (float)v0;
+  const float wu0 = 1.0f - wu1, wv0 = 1.0f - wv1;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float* pl = img + c * P;
+    const float top = pl[v0 * W + u0] * wu0 + pl[v0 * W + u1] * wu1;
+    const float bot = pl[v1 * W + u0] * wu0 + pl[v1 * W + u1] * wu1;
+    out[c] = top * wv0 + bot * wv1;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // data_augmentation (datasets/kitti/kitti_raw_transformed.py:23-74) as one gather: random scaling
 // (F.resize_images to (int(H*ys), int(W*xs)), :32-45), random crop back to (H, W) at (oy, ox) (:48-59)
@@ -676,6 +714,28 @@ int sfm_pyramid_fwd(const float* x, float* const* y, int N, int C, int H, int W,
   const int total = A.begin[n_scales];
   hipLaunchKernelGGL(pyramid_fwd_kernel, dim3((total + 255) / 256, N * C), dim3(256), 0, (hipStream_t)stream, A);
   return check_launch("sfm_pyramid_fwd");
+}
+
+int sfm_pyramid_hwc_fwd(const float* x, float* const* y, int N, int G, int H, int W, int n_scales, void* stream) {
+  if (N == 0) return SFM_OK;   // empty batch: nothing to do, pointers may be NULL
+  SFM_REQUIRE(x && y, SFM_ERR_NULL, "sfm_pyramid_hwc_fwd: NULL pointer");
+  SFM_REQUIRE(n_scales >= 1 && n_scales <= SFM_MAX_SCALES, SFM_ERR_SHAPE, "sfm_pyramid_hwc_fwd: n_scales=%d", n_scales);
+  SFM_REQUIRE(N >= 0 && G >= 1 && H >= 1 && W >= 1 && (long long)N * G <= 65535, SFM_ERR_SHAPE, "sfm_pyramid_hwc_fwd: bad shape");
+  PyramidArgs A;
+  A.x = x; A.H = H; A.W = W; A.n_scales = n_scales;
+  A.begin[0] = 0;
+  for (int s = 0; s < n_scales; ++s) {
+    SFM_REQUIRE(y[s], SFM_ERR_NULL, "sfm_pyramid_hwc_fwd: y[%d] is NULL", s);
+    A.y[s] = y[s];
+    A.oH[s] = H >> s;                                                   // H // 2**s, base_model.py:70
+    A.oW[s] = W >> s;
+    SFM_REQUIRE(A.oH[s] >= 1 && A.oW[s] >= 1, SFM_ERR_SHAPE, "sfm_pyramid_hwc_fwd: scale %d is empty", s);
+    SFM_REQUIRE((long long)A.begin[s] + (long long)A.oH[s] * A.oW[s] < (1ll << 31), SFM_ERR_SHAPE, "sfm_pyramid_hwc_fwd: image too large");
+    A.begin[s + 1] = A.begin[s] + A.oH[s] * A.oW[s];
+  }
+  const int total = A.begin[n_scales];
+  hipLaunchKernelGGL(pyramid_hwc_fwd_kernel, dim3((total + 255) / 256, N * G), dim3(256), 0, (hipStream_t)stream, A);
+  return check_launch("sfm_pyramid_hwc_fwd");
 }
 
 int sfm_augment_fwd(const float* imgs, const float* params, float* out, int B, int F, int C, int H, int W, void* stream) {

@@ -126,7 +126,8 @@ struct RowS {            // a warped row as the later stages need it (per lane =
 struct RowG { Ch3 a, b, e; };                             // horizontal 3-sums of the SSIM partials
 
 struct Pipe {            // a row whose gathers are in flight
-  Tap2 t[3], b[3];
+  float ta[3], tb[3];    // taps (u0, v0), (u0+1, v0) of the three channels
+  float ba[3], bb[3];    // taps (u0, v0+1), (u0+1, v0+1)
   float it[3];
   float fu, fv, U, V, rz, D;
   float lg;              // explainability logit (only loaded when C.mp != nullptr)
@@ -140,6 +141,15 @@ __device__ __forceinline__ void zero(RowS& s) {
 __device__ __forceinline__ void zero(RowG& s) { s.a = s.b = s.e = ch3_zero(); }
 
 // stage A, first half: project row r and issue its loads (row r is inside the image)
+// three consecutive floats with one 12-byte load; only 4-byte alignment is guaranteed
+struct __attribute__((packed, aligned(4))) Rgb {
+  float c[3];
+};
+__device__ __forceinline__ Rgb load_rgb(const float* p) { return *reinterpret_cast<const Rgb*>(p); }
+
+// HWC: the images are pixel-interleaved (SFM_LAYOUT_HWC): C.tp[0] / C.sp[0] are the (h,w,3) images of this sample /
+// (sample, source), and the three channels of a tap come with one load.
+template <bool HWC>
 __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const float disp, Pipe& ps) {
   const float yf = (float)r;
   ps.D = rcp_refined(disp);                                         // base_model.py:60
@@ -161,26 +171,23 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
   {
     const float f = __uint_as_float(0x3f800000u | (off & 0xffffu)), g = __uint_as_float(0x3f800000u | (offt & 0xffffu));
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { ps.t[c].a = f; ps.t[c].b = f + 0.25f * c; ps.b[c].a = f * 0.5f; ps.b[c].b = f - 0.125f * c; ps.it[c] = g + c; }
-  }
-#elif defined(SFM_EXP_TEXEL)   // timing experiment only (wrong values): the access pattern of an RGBX texel layout
-  {
-    const unsigned lim = (unsigned)(C.h * C.w) * 3u / 4u - (unsigned)C.w - 2u;
-    unsigned i4 = off - (off >> 2); i4 = i4 < lim ? i4 : lim;
-    unsigned j4 = offt - (offt >> 2); j4 = j4 < lim ? j4 : lim;
-    const float4* s4 = reinterpret_cast<const float4*>(C.sp[0]);
-    const float4* t4 = reinterpret_cast<const float4*>(C.tp[0]);
-    const float4 T0 = s4[i4], T1 = s4[i4 + 1], B0 = s4[i4 + (unsigned)C.w], B1 = s4[i4 + (unsigned)C.w + 1], I4 = t4[j4];
-    ps.t[0].a = T0.x; ps.t[1].a = T0.y; ps.t[2].a = T0.z; ps.t[0].b = T1.x; ps.t[1].b = T1.y; ps.t[2].b = T1.z;
-    ps.b[0].a = B0.x; ps.b[1].a = B0.y; ps.b[2].a = B0.z; ps.b[0].b = B1.x; ps.b[1].b = B1.y; ps.b[2].b = B1.z;
-    ps.it[0] = I4.x; ps.it[1] = I4.y; ps.it[2] = I4.z;
+    for (int c = 0; c < 3; ++c) { ps.ta[c] = f; ps.tb[c] = f + 0.25f * c; ps.ba[c] = f * 0.5f; ps.bb[c] = f - 0.125f * c; ps.it[c] = g + c; }
   }
 #else
+  if constexpr (HWC) {
+    const float* q = C.sp[0] + 3u * off;
+    const unsigned w3 = 3u * (unsigned)C.w;
+    const Rgb T0 = load_rgb(q), T1 = load_rgb(q + 3), B0 = load_rgb(q + w3), B1 = load_rgb(q + w3 + 3);
+    const Rgb I = load_rgb(C.tp[0] + 3u * offt);
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    ps.t[c] = load_tap2(C.sp[c] + off);
-    ps.b[c] = load_tap2(C.sp[c] + off + (unsigned)C.w);
-    ps.it[c] = C.tp[c][offt];
+    for (int c = 0; c < 3; ++c) { ps.ta[c] = T0.c[c]; ps.tb[c] = T1.c[c]; ps.ba[c] = B0.c[c]; ps.bb[c] = B1.c[c]; ps.it[c] = I.c[c]; }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const Tap2 t = load_tap2(C.sp[c] + off), b = load_tap2(C.sp[c] + off + (unsigned)C.w);
+      ps.ta[c] = t.a; ps.tb[c] = t.b; ps.ba[c] = b.a; ps.bb[c] = b.b;
+      ps.it[c] = C.tp[c][offt];
+    }
   }
 #endif
   if (C.mp != nullptr) ps.lg = C.mp[offt];
@@ -193,9 +200,9 @@ __device__ __forceinline__ void finish_row(const SsimCtx& C, const Pipe& ps, Row
   float ih[3], it[3], du[3], dv[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const float dxt = ps.t[c].b - ps.t[c].a, dxb = ps.b[c].b - ps.b[c].a;
-    const float top = fmaf(ps.fu, dxt, ps.t[c].a);
-    const float bot = fmaf(ps.fu, dxb, ps.b[c].a);
+    const float dxt = ps.tb[c] - ps.ta[c], dxb = ps.bb[c] - ps.ba[c];
+    const float top = fmaf(ps.fu, dxt, ps.ta[c]);
+    const float bot = fmaf(ps.fu, dxb, ps.ba[c]);
     const float dvv = bot - top;
     const float val = ps.inview ? fmaf(ps.fv, dvv, top) : 0.f;
     ih[c] = val;
@@ -297,7 +304,7 @@ __device__ __forceinline__ void ssim_stage_c(const T a2, const T a1, const T a0,
   q1 = g * dv;
 }
 
-template <bool GRAD, bool LOSS>
+template <bool GRAD, bool LOSS, bool HWC>
 __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const int r, const int rend, Pipe& ps, float& disp_next,
                                               RowS& s0, const RowS& s1, const RowS& s2,
                                               RowG& g0, const RowG& g1, const RowG& g2, float* gacc, const bool first,
@@ -312,7 +319,7 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const int r, con
   else zero(s0);
   SFM_STAMP(t1);
   const int rn = r + 1, rnn = r + 2;
-  if (rn < rend && rn >= 0 && rn < h) issue_row(C, rn, disp_next, ps);
+  if (rn < rend && rn >= 0 && rn < h) issue_row<HWC>(C, rn, disp_next, ps);
   if (rnn < rend && rnn >= 0 && rnn < h) disp_next = C.dp[(unsigned)rnn * (unsigned)w + C.xc];
   SFM_STAMP(t2);
 
@@ -363,7 +370,7 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const int r, con
 }
 
 // One source of one wave.  HS = halo of this pass (2 with gradients, 1 forward only).
-template <bool GRAD, bool LOSS>
+template <bool GRAD, bool LOSS, bool HWC>
 __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, const bool first, float& acc_pix, float& acc_ssim,
                                                  float* gpm_out /* 12 floats in global memory, or nullptr */ SFM_STAMPS_ARG) {
   constexpr int HS = GRAD ? 2 : 1;
@@ -378,14 +385,14 @@ __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, 
   Pipe ps;
   float disp_next = 1.f;
   // prologue: row rbeg in flight, disparity of row rbeg+1 loaded
-  if (rbeg >= 0 && rbeg < C.h) issue_row(C, rbeg, C.dp[(unsigned)rbeg * (unsigned)C.w + C.xc], ps);
+  if (rbeg >= 0 && rbeg < C.h) issue_row<HWC>(C, rbeg, C.dp[(unsigned)rbeg * (unsigned)C.w + C.xc], ps);
   if (rbeg + 1 >= 0 && rbeg + 1 < C.h) disp_next = C.dp[(unsigned)(rbeg + 1) * (unsigned)C.w + C.xc];
   for (int r = rbeg; r < rend; r += 3) {
-    ssim_row_step<GRAD, LOSS>(C, r, rend, ps, disp_next, S0, S2, S1, G0, G2, G1, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
+    ssim_row_step<GRAD, LOSS, HWC>(C, r, rend, ps, disp_next, S0, S2, S1, G0, G2, G1, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
     if (r + 1 < rend)
-      ssim_row_step<GRAD, LOSS>(C, r + 1, rend, ps, disp_next, S1, S0, S2, G1, G0, G2, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
+      ssim_row_step<GRAD, LOSS, HWC>(C, r + 1, rend, ps, disp_next, S1, S0, S2, G1, G0, G2, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
     if (r + 2 < rend)
-      ssim_row_step<GRAD, LOSS>(C, r + 2, rend, ps, disp_next, S2, S1, S0, G2, G1, G0, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
+      ssim_row_step<GRAD, LOSS, HWC>(C, r + 2, rend, ps, disp_next, S2, S1, S0, G2, G1, G0, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
   }
   if (GRAD) {
 #pragma unroll
@@ -398,7 +405,7 @@ __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, 
 
 // Photometric pass WITHOUT SSIM for one (wave, source): L1 (+ explainability weighting, base_model.py:103-109).
 // Everything is per pixel, so there is no ring; the loads of row r+1 are in flight while row r is finished.
-template <bool GRAD, bool LOSS, bool EXPL>
+template <bool GRAD, bool LOSS, bool EXPL, bool HWC>
 __device__ __forceinline__ void l1_source_pass(const SsimCtx& C, float* gacc, const bool first, float& acc_pix, float& acc_exp,
                                                float* gpm_out) {
   float gpm[12];
@@ -408,13 +415,13 @@ __device__ __forceinline__ void l1_source_pass(const SsimCtx& C, float* gacc, co
   ps.lg = 0.f;
   float disp_next = 1.f;
   const int rbeg = C.y0, rend = C.y1;    // rows of a chunk are always inside the image
-  issue_row(C, rbeg, C.dp[(unsigned)rbeg * (unsigned)C.w + C.xc], ps);
+  issue_row<HWC>(C, rbeg, C.dp[(unsigned)rbeg * (unsigned)C.w + C.xc], ps);
   if (rbeg + 1 < rend) disp_next = C.dp[(unsigned)(rbeg + 1) * (unsigned)C.w + C.xc];
   for (int r = rbeg; r < rend; ++r) {
     RowS s0;
     finish_row(C, ps, s0);
     const float lg = ps.lg;
-    if (r + 1 < rend) issue_row(C, r + 1, disp_next, ps);
+    if (r + 1 < rend) issue_row<HWC>(C, r + 1, disp_next, ps);
     disp_next = C.dp[(unsigned)min(r + 2, C.h - 1) * (unsigned)C.w + C.xc];
     float sgm = 1.f;
     if (EXPL) {

@@ -168,6 +168,29 @@ def pyramid(x, n_scales):
     return outs
 
 
+def pyramid_hwc(x, n_scales):
+    """The pyramid of `pyramid`, pixel-interleaved for the fused loss (SFM_LAYOUT_HWC): x (N,3G,H,W) planar, G images
+    per sample -> [y_s (N,G,H>>s,W>>s,3) for s in 0..n_scales-1], one launch.  Same values as `pyramid`."""
+    x = _dev(x, "x", 4)
+    N, Cc, H, W = x.shape
+    if Cc % 3 != 0:
+        raise TypeError("pyramid_hwc: the channel count must be a multiple of 3 (RGB images), got %d" % Cc)
+    if not 1 <= n_scales <= _lib.SFM_MAX_SCALES:
+        raise TypeError("n_scales must be in [1, %d]" % _lib.SFM_MAX_SCALES)
+    G = Cc // 3
+    outs = [torch.empty((N, G, H >> s, W >> s, 3), dtype=torch.float32, device=x.device) for s in range(n_scales)]
+    ptrs = (C.c_void_p * n_scales)(*[t.data_ptr() for t in outs])
+    with torch.cuda.device(x.device):
+        check(lib.sfm_pyramid_hwc_fwd(_p(x), ptrs, N, G, H, W, n_scales, _stream()))
+    return outs
+
+
+def to_hwc(x):
+    """(N,3G,h,w) planar -> (N,G,h,w,3) pixel-interleaved copy (a torch permute; for callers that hold planar pyramids)."""
+    N, Cc, h, w = x.shape
+    return x.reshape(N, Cc // 3, 3, h, w).permute(0, 1, 3, 4, 2).contiguous()
+
+
 def _ptr_array(ts):
     return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
 
@@ -209,14 +232,19 @@ class FusedLoss:
         self.desc = None
         self._keep = None
 
-    def bind(self, tgt_pyr, src_pyr, intrinsics, disps, poses, masks=None, norm_B=None, want_d_src=False):
+    def bind(self, tgt_pyr, src_pyr, intrinsics, disps, poses, masks=None, norm_B=None, want_d_src=False, layout="planar"):
+        """layout: "planar" -- tgt (B,3,h,w), src (B,3*n_src,h,w) as in the reference; "hwc" -- tgt (B,1,h,w,3),
+        src (B,n_src,h,w,3) as written by `pyramid_hwc` (the faster layout for these kernels; same results)."""
+        if layout not in ("planar", "hwc"):
+            raise ValueError("layout must be 'planar' or 'hwc', got %r" % (layout,))
+        hwc = layout == "hwc"
         S = len(disps)
         if not (len(tgt_pyr) == len(src_pyr) == S):
             raise TypeError("tgt_pyr, src_pyr and disps must have one entry per scale")
         if S > _lib.SFM_MAX_SCALES or len(poses) > _lib.SFM_MAX_SRC:
             raise TypeError("at most %d scales and %d sources" % (_lib.SFM_MAX_SCALES, _lib.SFM_MAX_SRC))
-        tgt_pyr = [_dev(t, "tgt_pyr[%d]" % s, 4) for s, t in enumerate(tgt_pyr)]
-        src_pyr = [_dev(t, "src_pyr[%d]" % s, 4) for s, t in enumerate(src_pyr)]
+        tgt_pyr = [_dev(t, "tgt_pyr[%d]" % s, 5 if hwc else 4) for s, t in enumerate(tgt_pyr)]
+        src_pyr = [_dev(t, "src_pyr[%d]" % s, 5 if hwc else 4) for s, t in enumerate(src_pyr)]
         disps = [_dev(t, "disps[%d]" % s, 4) for s, t in enumerate(disps)]
         poses = [_dev(t, "poses[%d]" % i, 2) for i, t in enumerate(poses)]
         intrinsics = _dev(intrinsics, "intrinsics", 4)
@@ -234,12 +262,17 @@ class FusedLoss:
         d.B, d.norm_B, d.n_src, d.n_scales = B, int(norm_B if norm_B is not None else B), n_src, S
         d.smooth_reg, d.exp_reg, d.ssim_rate, d.smooth_mode = self.smooth_reg, self.exp_reg, self.ssim_rate, self.smooth_mode
         d.intrinsics = intrinsics.data_ptr()
+        d.image_layout = _lib.SFM_LAYOUT_HWC if hwc else _lib.SFM_LAYOUT_PLANAR
         d_disps, d_masks, d_srcs = [], [], []
         for s in range(S):
-            h, w = tgt_pyr[s].shape[2:]
-            if tuple(tgt_pyr[s].shape) != (B, 3, h, w) or tuple(src_pyr[s].shape) != (B, 3 * n_src, h, w) \
-                    or tuple(disps[s].shape) != (B, 1, h, w):
-                raise TypeError("scale %d: expected tgt (B,3,h,w), src (B,3*n_src,h,w), disp (B,1,h,w)" % s)
+            h, w = disps[s].shape[2:]
+            if hwc:
+                ok = tuple(tgt_pyr[s].shape) == (B, 1, h, w, 3) and tuple(src_pyr[s].shape) == (B, n_src, h, w, 3)
+            else:
+                ok = tuple(tgt_pyr[s].shape) == (B, 3, h, w) and tuple(src_pyr[s].shape) == (B, 3 * n_src, h, w)
+            if not ok or tuple(disps[s].shape) != (B, 1, h, w):
+                raise TypeError("scale %d: expected tgt (B,3,h,w), src (B,3*n_src,h,w) [hwc: (B,1,h,w,3), (B,n_src,h,w,3)], "
+                                "disp (B,1,h,w)" % s)
             d.H[s], d.W[s] = h, w
             d.tgt[s], d.src[s], d.disp[s] = tgt_pyr[s].data_ptr(), src_pyr[s].data_ptr(), disps[s].data_ptr()
             d_disps.append(torch.empty_like(disps[s]))
@@ -250,8 +283,8 @@ class FusedLoss:
                 d.mask_logits[s] = masks[s].data_ptr()
                 d_masks.append(torch.empty_like(masks[s]))
                 d.d_mask[s] = d_masks[-1].data_ptr()
-            if want_d_src:
-                d_srcs.append(torch.zeros_like(src_pyr[s]))
+            if want_d_src:      # always planar
+                d_srcs.append(torch.zeros((B, 3 * n_src, h, w), dtype=torch.float32, device=dev))
                 d.d_src[s] = d_srcs[-1].data_ptr()
         d_poses = []
         for i in range(n_src):

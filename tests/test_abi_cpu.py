@@ -29,9 +29,10 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_descriptor_layout_matches_the_header():
-    # 4 + 8 + 8 int32, 3 float, 1 int32, then 4*8 + 1 + 8 + 8 + 8 + 8 + 8 pointers
-    assert C.sizeof(_lib.SfmLossDesc) == 4 * (4 + 8 + 8 + 3 + 1) + 8 * (8 * 4 + 1 + 8 + 8 * 3 + 8)
+    # 4 + 8 + 8 int32, 3 float, 1 int32, then 4*8 + 1 + 8 + 8 + 8 + 8 + 8 pointers, then image_layout (int32, padded to 8)
+    assert C.sizeof(_lib.SfmLossDesc) == 4 * (4 + 8 + 8 + 3 + 1) + 8 * (8 * 4 + 1 + 8 + 8 * 3 + 8) + 8
     assert _lib.SfmLossDesc.tgt.offset % 8 == 0
+    assert _lib.SfmLossDesc.image_layout.offset == C.sizeof(_lib.SfmLossDesc) - 8
 
 
 def _desc(**kw):
@@ -58,7 +59,7 @@ def test_workspace_query_needs_no_gpu():
 
 @pytest.mark.parametrize("bad,code", [
     (dict(n_src=0), _lib.ERR_SHAPE), (dict(n_src=9), _lib.ERR_SHAPE), (dict(n_scales=0), _lib.ERR_SHAPE),
-    (dict(norm_B=1), _lib.ERR_CONFIG), (dict(ssim_rate=1.5), _lib.ERR_CONFIG), (dict(smooth_mode=7), _lib.ERR_CONFIG),
+    (dict(norm_B=1), _lib.ERR_CONFIG), (dict(ssim_rate=1.5), _lib.ERR_CONFIG), (dict(smooth_mode=7), _lib.ERR_CONFIG), (dict(image_layout=5), _lib.ERR_CONFIG),
     (dict(intrinsics=None), _lib.ERR_NULL), (dict(exp_reg=0.2), _lib.ERR_NULL),   # exp_reg without mask logits
 ])
 def test_bad_descriptors_are_rejected_with_a_message(bad, code):

@@ -38,7 +38,7 @@ def test_loss_kernels_fit_their_register_budget(tmp_path):
         if m and name:
             kernels[name][m.group(1).strip()] = int(m.group(2))
     loss = {k: v for k, v in kernels.items() if "loss_kernel" in k}
-    assert len(loss) == 27                       # {fwd, bwd, fused} x {l1, ssim, explain} x {no, 2nd-order, edge-aware smoothness}
+    assert len(loss) == 54                       # {fwd, bwd, fused} x {l1, ssim, explain} x {no, 2nd-order, edge-aware smoothness} x {planar, hwc}
     for k, v in kernels.items():
         assert v["ScratchSize [bytes/lane]"] == 0, (k, v)
     for k, v in loss.items():

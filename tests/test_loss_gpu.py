@@ -25,13 +25,15 @@ def _oracle(d, cfg, norm_B=None, want_d_src=False):
                       backward=True, want_d_src=want_d_src, keep_warped=True, norm_batch=norm_B, **cfg)
 
 
-def _bind(ops, dev, d, cfg, norm_B=None, want_d_src=False):
+def _bind(ops, dev, d, cfg, norm_B=None, want_d_src=False, layout="planar"):
     fl = ops.FusedLoss(**cfg)
-    fl.bind([to_dev(a, dev) for a in d["tgt_pyr"]], [to_dev(a, dev) for a in d["src_pyr"]],
-            to_dev(d["intrinsics"], dev), [to_dev(a, dev) for a in d["disps"]],
+    tgt, src = [to_dev(a, dev) for a in d["tgt_pyr"]], [to_dev(a, dev) for a in d["src_pyr"]]
+    if layout == "hwc":      # the same values, pixel-interleaved (SFM_LAYOUT_HWC)
+        tgt, src = [ops.to_hwc(a) for a in tgt], [ops.to_hwc(a) for a in src]
+    fl.bind(tgt, src, to_dev(d["intrinsics"], dev), [to_dev(a, dev) for a in d["disps"]],
             [to_dev(a, dev) for a in d["poses"]],
             [to_dev(a, dev) for a in d["masks"]] if d["masks"] is not None else None,
-            norm_B=norm_B, want_d_src=want_d_src)
+            norm_B=norm_B, want_d_src=want_d_src, layout=layout)
     return fl
 
 
@@ -107,6 +109,37 @@ def test_fused_loss_matches_oracle(ops, synth, dev, name, shape):
     g_fused = [to_np(t) for t in fl.d_disps] + [to_np(t) for t in fl.d_poses]
     for a, b in zip(g_sep, g_fused):   # two instantiations of one template: same math, ulp-level differences
         np.testing.assert_allclose(a, b, rtol=0, atol=2e-5 * np.abs(a).max())
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+@pytest.mark.parametrize("shape", [(2, 32, 48, 2, 3), (1, 37, 70, 2, 1), (3, 20, 130, 4, 2)])
+def test_hwc_layout_gives_the_planar_results(ops, synth, dev, name, shape):
+    """SFM_LAYOUT_HWC only changes how the images are fetched: every entry point returns what it returns for the
+    reference's planar layout -- the loss bit for bit, the gradients to the last ulps (another instantiation of the
+    same template) -- and the oracle parity of the planar path carries over."""
+    B, H, W, n_src, n_scales = shape
+    cfg = CONFIGS[name]
+    d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=n_scales, seed=13, with_masks=True)
+    ref = _oracle(d, cfg, want_d_src=True)
+    a = _bind(ops, dev, d, cfg, want_d_src=True)
+    b = _bind(ops, dev, d, cfg, want_d_src=True, layout="hwc")
+    for run in ("separate", "fused"):
+        if run == "separate":
+            la, lb = to_np(a.forward()).copy(), to_np(b.forward()).copy()
+            a.backward(1.0); b.backward(1.0)
+        else:
+            la, lb = to_np(a.forward_backward()).copy(), to_np(b.forward_backward()).copy()
+        np.testing.assert_allclose(lb, la, rtol=2e-7, atol=0)
+        groups = [(a.d_disps, b.d_disps), (a.d_poses, b.d_poses), (a.d_srcs, b.d_srcs)]
+        if cfg.get("exp_reg"):
+            groups.append((a.d_masks, b.d_masks))
+        for ga, gb in groups:
+            for x, y in zip(ga, gb):
+                x, y = to_np(x), to_np(y)
+                assert x.shape == y.shape
+                np.testing.assert_allclose(y, x, rtol=0, atol=2e-5 * max(np.abs(x).max(), 1e-30))
+    _check_losses(b.loss5, ref)
+    _check_grads(b, ref, n_src, check_src=True, check_mask=bool(cfg.get("exp_reg")))
 
 
 def test_upstream_gradient_scales_linearly(ops, synth, dev):
@@ -212,6 +245,16 @@ def test_argument_errors(ops, synth, dev):
         ops.FusedLoss().bind([torch.from_numpy(a) for a in d["tgt_pyr"]], [torch.from_numpy(a) for a in d["src_pyr"]],
                              torch.from_numpy(d["intrinsics"]), [torch.from_numpy(a) for a in d["disps"]],
                              [torch.from_numpy(a) for a in d["poses"]])
+    with pytest.raises(ValueError):          # unknown layout name
+        _bind(ops, dev, d, dict(), layout="chw")
+    with pytest.raises(TypeError):           # planar arrays announced as pixel-interleaved
+        ops.FusedLoss().bind([to_dev(a, dev) for a in d["tgt_pyr"]], [to_dev(a, dev) for a in d["src_pyr"]],
+                             to_dev(d["intrinsics"], dev), [to_dev(a, dev) for a in d["disps"]],
+                             [to_dev(a, dev) for a in d["poses"]], layout="hwc")
+    fl = _bind(ops, dev, d, dict())
+    fl.desc.image_layout = 7                 # the C ABI rejects a layout code it does not know
+    with pytest.raises(ValueError):
+        fl.forward()
     tiny = synth.make_inputs(B=1, H=16, W=24, n_src=1, n_scales=4, seed=3)   # smallest scale 2x3 < 3
     with pytest.raises((TypeError, ValueError)):
         _bind(ops, dev, tiny, dict())

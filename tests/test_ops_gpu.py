@@ -154,6 +154,21 @@ def test_pyramid_matches_oracle_resizes(ops, dev, shape, n_scales):
         np.testing.assert_array_equal(to_np(outs[s]), to_np(ops.resize(to_dev(x, dev), (H >> s, W >> s))))
 
 
+@pytest.mark.parametrize("shape,n_scales", [((2, 3, 32, 48), 4), ((3, 6, 37, 70), 3), ((1, 12, 128, 416), 4), ((2, 3, 9, 11), 1)])
+def test_pyramid_hwc_is_the_planar_pyramid_interleaved(ops, dev, shape, n_scales):
+    """sfm_pyramid_hwc_fwd: the values of sfm_pyramid_fwd (bit for bit), laid out (N,G,h,w,3), scale 0 included"""
+    rng = np.random.RandomState(6)
+    x = to_dev(rng.uniform(-1, 1, size=shape).astype(np.float32), dev)
+    planar = ops.pyramid(x, n_scales)
+    hwc = ops.pyramid_hwc(x, n_scales)
+    assert len(hwc) == n_scales
+    for s in range(n_scales):
+        assert tuple(hwc[s].shape) == (shape[0], shape[1] // 3, shape[2] >> s, shape[3] >> s, 3)
+        np.testing.assert_array_equal(to_np(hwc[s]), to_np(ops.to_hwc(planar[s])))
+    with pytest.raises(TypeError):
+        ops.pyramid_hwc(x[:, :2], n_scales)             # not RGB triples
+
+
 def test_type_checks(ops, dev):
     """check_type_forward of the reference (spational_transformer_sampler_interp.py:11-24)."""
     import torch
