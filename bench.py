@@ -319,7 +319,8 @@ def main():
                     and prof["bench"]["config"].get("image_layout", "planar") == args.layout:
                 want = "sfm_loss_fwd_bwd" if args.mode == "fused" else "sfm_loss_bwd"
                 for kn, kv in prof["kernels"].items():
-                    if kv.get("entry_point") == want and "hbm_bytes_raw" in kv:
+                    is_hwc = kn.rstrip().endswith("true>(sfm::LossArgs)")      # last template argument: HWC
+                    if kv.get("entry_point") == want and "hbm_bytes_raw" in kv and is_hwc == (args.layout == "hwc"):
                         # bytes per launch with the guide's gfx950 correction (FETCH_SIZE x 2); raw value alongside
                         traffic = round(kv["hbm_bytes_fetch_x2"])
                         traffic_detail = {"bytes_per_launch_raw": round(kv["hbm_bytes_raw"]),

@@ -16,8 +16,8 @@ os.makedirs(out, exist_ok=True)
 
 
 def one(pattern):
-    g = glob.glob(os.path.join(raw, pattern))
-    return g[0] if g else None
+    g = glob.glob(os.path.join(raw, pattern))   # gpurun merges every run into the same directory: take the newest
+    return max(g, key=os.path.getmtime) if g else None
 
 
 stats = one("trace/*/*_kernel_stats.csv")
