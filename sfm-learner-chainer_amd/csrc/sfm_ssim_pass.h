@@ -378,10 +378,10 @@ __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, 
   float gpm[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) gpm[k] = 0.f;
+  // The rings need no initial value: stage B first runs on the third row of the pass, when all three RowS slots have
+  // been written, and stage C two rows later, when all three RowG slots have (see ssim_row_step).
   RowS S0, S1, S2;
   RowG G0, G1, G2;
-  zero(S0); zero(S1); zero(S2);
-  zero(G0); zero(G1); zero(G2);
   Pipe ps;
   float disp_next = 1.f;
   // prologue: row rbeg in flight, disparity of row rbeg+1 loaded
