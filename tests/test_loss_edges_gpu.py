@@ -22,10 +22,11 @@ CFG = CONFIGS["ssim_smooth"]
     (1, 48, 64, 1, 5),      # five scales (48x64 ... 3x4)
     (2, 70, 36, 2, 2),      # several row chunks, narrow image
 ])
-def test_shapes_at_the_boundaries(ops, synth, dev, B, H, W, n_src, n_scales):
+@pytest.mark.parametrize("layout", ["planar", "hwc"])
+def test_shapes_at_the_boundaries(ops, synth, dev, B, H, W, n_src, n_scales, layout):
     d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=n_scales, seed=21)
     ref = _oracle(d, CFG)
-    fl = _bind(ops, dev, d, CFG)
+    fl = _bind(ops, dev, d, CFG, layout=layout)
     _check_losses(fl.forward(), ref)
     _check_losses(fl.forward_backward(), ref)
     _check_grads(fl, ref, n_src)
@@ -93,7 +94,7 @@ def test_high_resolution_config5_shape(ops, synth, dev):
     """BASELINE.json configs[4]: 256x832, 4 scales, 5-frame snippet (4 sources), at B=1"""
     d = synth.make_inputs(B=1, H=256, W=832, n_src=4, n_scales=4, seed=1)
     ref = _oracle(d, CFG)
-    fl = _bind(ops, dev, d, CFG)
+    fl = _bind(ops, dev, d, CFG, layout="hwc")
     _check_losses(fl.forward_backward(), ref)
     _check_grads(fl, ref, 4, check_pose=False)
     # d_pose sums 283k signed per-pixel terms whose magnitudes exceed the sum by orders of magnitude, so fp32
@@ -125,7 +126,7 @@ def test_random_shapes_and_modes(ops, synth, dev, B, H, W, n_src, n_scales, cfg_
     cfg = CONFIGS[cfg_name]
     d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=n_scales, seed=seed % 10000, with_masks=True)
     ref = _oracle(d, cfg)
-    fl = _bind(ops, dev, d, cfg)
+    fl = _bind(ops, dev, d, cfg, layout="hwc" if seed % 2 else "planar")     # both image layouts take part in the sweep
     _check_losses(fl.forward(), ref)
     _check_losses(fl.forward_backward(), ref)
     _check_grads(fl, ref, n_src, check_mask=bool(cfg.get("exp_reg")))
