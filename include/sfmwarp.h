@@ -176,6 +176,10 @@ int sfm_pyramid_fwd(const float *x, float *const *y, int N, int C, int H, int W,
  * (1 for the target, n_src for the sources, base_model.py:50-57) -> y[s] (N,G,H>>s,W>>s,3) for s = 0..n_scales-1
  * (scale 0 is the re-laid-out input).  Values are identical to sfm_pyramid_fwd's. */
 int sfm_pyramid_hwc_fwd(const float *x, float *const *y, int N, int G, int H, int W, int n_scales, void *stream);
+/* Both pyramids of a step in ONE launch: tgt (N,3,H,W) and src (N,3*n_src,H,W) (base_model.py:50-57) ->
+ * y_tgt[s] (N,1,h,w,3), y_src[s] (N,n_src,h,w,3), s = 0..n_scales-1: the whole loop head :69-72. */
+int sfm_pyramid_pair_hwc_fwd(const float *tgt, const float *src, float *const *y_tgt, float *const *y_src, int N, int n_src,
+                             int H, int W, int n_scales, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * DispNet's output activation for all scales in one launch, models/disp_net.py:7-8 and

@@ -71,6 +71,7 @@ SYMBOLS = {
     "sfm_augment_fwd": (_I, [_FP, _FP, _FP, _I, _I, _I, _I, _I, _V]),
     "sfm_pyramid_fwd": (_I, [_FP, C.POINTER(C.c_void_p), _I, _I, _I, _I, _I, _V]),
     "sfm_pyramid_hwc_fwd": (_I, [_FP, C.POINTER(C.c_void_p), _I, _I, _I, _I, _I, _V]),
+    "sfm_pyramid_pair_hwc_fwd": (_I, [_FP, _FP, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I, _I, _I, _I, _I, _V]),
 }
 
 

@@ -419,6 +419,9 @@ __global__ void resize_fwd_kernel(const float* __restrict__ x, float* __restrict
 // ------------------------------------------------------------------------------------------
 struct PyramidArgs {
   const float* x;
+  const float* x2;               // pair form only: second input tensor (N,3*G2,H,W) and its outputs
+  float* y2[SFM_MAX_SCALES];
+  int n_first, G2;               // pair form only: blockIdx.y < n_first -> first tensor (one image per sample)
   float* y[SFM_MAX_SCALES];      // y[s] for s = 1..n_scales-1 (y[0] unused: scale 0 is the input itself)
   int oH[SFM_MAX_SCALES], oW[SFM_MAX_SCALES];
   int begin[SFM_MAX_SCALES + 1]; // prefix sums of oH*oW over scales 1..
@@ -452,9 +455,13 @@ __global__ void pyramid_fwd_kernel(const PyramidArgs A) {
 // The same pyramid, pixel-interleaved (SFM_LAYOUT_HWC): x (N,3G,H,W) -> y[s] (N,G,h_s,w_s,3), s = 0..S-1.  One thread
 // per output pixel computes the three channels with one set of weights; per channel the arithmetic is that of
 // pyramid_fwd_kernel, so the values agree bit for bit.  Scale 0 is a copy.
+template <bool PAIR>
 __global__ void pyramid_hwc_fwd_kernel(const PyramidArgs A) {
 #pragma clang fp contract(off)
-  const int ng = blockIdx.y;   // n * G + g
+  int ng = blockIdx.y;   // n * G + g
+  const float* xin = A.x;
+  float* const* yout = A.y;
+  if (PAIR && ng >= A.n_first) { ng -= A.n_first; xin = A.x2; yout = A.y2; }   // block-uniform
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= A.begin[A.n_scales]) return;
   int s = 0;
@@ -464,8 +471,8 @@ __global__ void pyramid_hwc_fwd_kernel(const PyramidArgs A) {
   const int jj = j - A.begin[s];
   const int oW = A.oW[s], oH = A.oH[s], H = A.H, W = A.W;
   const size_t P = (size_t)H * W;
-  const float* img = A.x + (size_t)ng * 3 * P;
-  float* out = A.y[s] + ((size_t)ng * oH * oW + jj) * 3;
+  const float* img = xin + (size_t)ng * 3 * P;
+  float* out = yout[s] + ((size_t)ng * oH * oW + jj) * 3;
   if (s == 0) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) out[c] = img[c * P + jj];
@@ -734,8 +741,33 @@ int sfm_pyramid_hwc_fwd(const float* x, float* const* y, int N, int G, int H, in
     A.begin[s + 1] = A.begin[s] + A.oH[s] * A.oW[s];
   }
   const int total = A.begin[n_scales];
-  hipLaunchKernelGGL(pyramid_hwc_fwd_kernel, dim3((total + 255) / 256, N * G), dim3(256), 0, (hipStream_t)stream, A);
+  hipLaunchKernelGGL(pyramid_hwc_fwd_kernel<false>, dim3((total + 255) / 256, N * G), dim3(256), 0, (hipStream_t)stream, A);
   return check_launch("sfm_pyramid_hwc_fwd");
+}
+
+int sfm_pyramid_pair_hwc_fwd(const float* tgt, const float* src, float* const* y_tgt, float* const* y_src, int N, int n_src, int H,
+                             int W, int n_scales, void* stream) {
+  if (N == 0) return SFM_OK;   // empty batch: nothing to do, pointers may be NULL
+  SFM_REQUIRE(tgt && src && y_tgt && y_src, SFM_ERR_NULL, "sfm_pyramid_pair_hwc_fwd: NULL pointer");
+  SFM_REQUIRE(n_scales >= 1 && n_scales <= SFM_MAX_SCALES, SFM_ERR_SHAPE, "sfm_pyramid_pair_hwc_fwd: n_scales=%d", n_scales);
+  SFM_REQUIRE(N >= 0 && n_src >= 1 && n_src <= SFM_MAX_SRC && H >= 1 && W >= 1 && (long long)N * (1 + n_src) <= 65535, SFM_ERR_SHAPE,
+              "sfm_pyramid_pair_hwc_fwd: bad shape");
+  PyramidArgs A;
+  A.x = tgt; A.x2 = src; A.n_first = N; A.G2 = n_src; A.H = H; A.W = W; A.n_scales = n_scales;
+  A.begin[0] = 0;
+  for (int s = 0; s < n_scales; ++s) {
+    SFM_REQUIRE(y_tgt[s] && y_src[s], SFM_ERR_NULL, "sfm_pyramid_pair_hwc_fwd: output of scale %d is NULL", s);
+    A.y[s] = y_tgt[s];
+    A.y2[s] = y_src[s];
+    A.oH[s] = H >> s;                                                   // H // 2**s, base_model.py:70
+    A.oW[s] = W >> s;
+    SFM_REQUIRE(A.oH[s] >= 1 && A.oW[s] >= 1, SFM_ERR_SHAPE, "sfm_pyramid_pair_hwc_fwd: scale %d is empty", s);
+    SFM_REQUIRE((long long)A.begin[s] + (long long)A.oH[s] * A.oW[s] < (1ll << 31), SFM_ERR_SHAPE, "sfm_pyramid_pair_hwc_fwd: image too large");
+    A.begin[s + 1] = A.begin[s] + A.oH[s] * A.oW[s];
+  }
+  const int total = A.begin[n_scales];
+  hipLaunchKernelGGL(pyramid_hwc_fwd_kernel<true>, dim3((total + 255) / 256, N * (1 + n_src)), dim3(256), 0, (hipStream_t)stream, A);
+  return check_launch("sfm_pyramid_pair_hwc_fwd");
 }
 
 int sfm_augment_fwd(const float* imgs, const float* params, float* out, int B, int F, int C, int H, int W, void* stream) {

@@ -77,10 +77,9 @@ class SFMLearnerLoss:
         do_exp = self.exp_reg is not None and self.exp_reg > 0                 # :61
         if n_sources != len(pred_poses):
             raise TypeError("src_imgs has %d sources but %d poses were given" % (n_sources, len(pred_poses)))
-        # :69-72 -- curr_tgt_img / curr_src_imgs of every scale, one launch per tensor, written pixel-interleaved
+        # :69-72 -- curr_tgt_img / curr_src_imgs of every scale, ONE launch for both tensors, written pixel-interleaved
         # (the layout the fused loss kernels fetch with the fewest loads; values identical to the planar pyramid)
-        tgt_pyr = ops.pyramid_hwc(tgt, n_scales)
-        src_pyr = ops.pyramid_hwc(stacked_src_imgs, n_scales)
+        tgt_pyr, src_pyr = ops.pyramid_pair_hwc(tgt, stacked_src_imgs, n_scales)
         fused = ops.FusedLoss(smooth_reg=self.smooth_reg or 0.0, exp_reg=self.exp_reg or 0.0,
                               ssim_rate=self.ssim_rate or 0.0, smooth_mode=self.smooth_mode)
         fused.bind(tgt_pyr, src_pyr, as_array(intrinsics), [as_array(d) for d in pred_disps],

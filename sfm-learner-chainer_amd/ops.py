@@ -185,6 +185,23 @@ def pyramid_hwc(x, n_scales):
     return outs
 
 
+def pyramid_pair_hwc(tgt, src, n_scales):
+    """Both pixel-interleaved pyramids of a step in one launch: tgt (N,3,H,W), src (N,3*n_src,H,W) ->
+    ([tgt_s (N,1,h,w,3)], [src_s (N,n_src,h,w,3)]) -- the loop head models/base_model.py:69-72."""
+    tgt, src = _dev(tgt, "tgt", 4), _dev(src, "src", 4)
+    N, Ct, H, W = tgt.shape
+    if Ct != 3 or src.shape[0] != N or tuple(src.shape[2:]) != (H, W) or src.shape[1] % 3 != 0 or src.shape[1] == 0:
+        raise TypeError("pyramid_pair_hwc: expected tgt (N,3,H,W) and src (N,3*n_src,H,W), got %s and %s" % (tuple(tgt.shape), tuple(src.shape)))
+    if not 1 <= n_scales <= _lib.SFM_MAX_SCALES:
+        raise TypeError("n_scales must be in [1, %d]" % _lib.SFM_MAX_SCALES)
+    n_src = src.shape[1] // 3
+    yt = [torch.empty((N, 1, H >> s, W >> s, 3), dtype=torch.float32, device=tgt.device) for s in range(n_scales)]
+    ys = [torch.empty((N, n_src, H >> s, W >> s, 3), dtype=torch.float32, device=tgt.device) for s in range(n_scales)]
+    with torch.cuda.device(tgt.device):
+        check(lib.sfm_pyramid_pair_hwc_fwd(_p(tgt), _p(src), _ptr_array(yt), _ptr_array(ys), N, n_src, H, W, n_scales, _stream()))
+    return yt, ys
+
+
 def to_hwc(x):
     """(N,3G,h,w) planar -> (N,G,h,w,3) pixel-interleaved copy (a torch permute; for callers that hold planar pyramids)."""
     N, Cc, h, w = x.shape

@@ -169,6 +169,21 @@ def test_pyramid_hwc_is_the_planar_pyramid_interleaved(ops, dev, shape, n_scales
         ops.pyramid_hwc(x[:, :2], n_scales)             # not RGB triples
 
 
+@pytest.mark.parametrize("N,n_src,H,W,n_scales", [(2, 2, 32, 48, 4), (3, 1, 37, 70, 3), (1, 4, 128, 416, 4), (9, 3, 9, 11, 1)])
+def test_pyramid_pair_is_the_two_pyramids_in_one_launch(ops, dev, N, n_src, H, W, n_scales):
+    rng = np.random.RandomState(7)
+    tgt = to_dev(rng.uniform(-1, 1, size=(N, 3, H, W)).astype(np.float32), dev)
+    src = to_dev(rng.uniform(-1, 1, size=(N, 3 * n_src, H, W)).astype(np.float32), dev)
+    yt, ys = ops.pyramid_pair_hwc(tgt, src, n_scales)
+    for a, b in zip(yt, ops.pyramid_hwc(tgt, n_scales)):
+        np.testing.assert_array_equal(to_np(a), to_np(b))
+    for a, b in zip(ys, ops.pyramid_hwc(src, n_scales)):
+        np.testing.assert_array_equal(to_np(a), to_np(b))
+    with pytest.raises(TypeError):
+        import torch
+        ops.pyramid_pair_hwc(torch.cat([tgt, tgt], 1), src, n_scales)        # the target is one image
+
+
 def test_type_checks(ops, dev):
     """check_type_forward of the reference (spational_transformer_sampler_interp.py:11-24)."""
     import torch

@@ -47,6 +47,7 @@ rows = [
     ("interp_bwd  (gx = 0, ggrid)", lambda: ops.interp_bwd(src, gridp, gy), px * (12 + 8 + 12 + 12 + 8)),
     ("pyramid  4 scales, 6 planes", lambda: ops.pyramid(full_src, 4), int(B * 6 * P * 4 * (1 + 0.328))),
     ("pyramid_hwc  4 scales, 6 planes (scale 0 included)", lambda: ops.pyramid_hwc(full_src, 4), int(B * 6 * P * 4 * (1 + 1.328))),
+    ("pyramid_pair_hwc  tgt + 2 src, 4 scales, one launch", lambda: ops.pyramid_pair_hwc(tgt, full_src, 4), int(B * 9 * P * 4 * (1 + 1.328))),
     ("disp_act_fwd  4 scales", lambda: ops.disp_act_fwd(logits), int(B * P * 1.328 * 8)),
     ("disp_act_bwd  4 scales", lambda: ops.disp_act_bwd(dd, dd), int(B * P * 1.328 * 12)),
 ]
