@@ -315,12 +315,13 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const int r, con
 #endif
   SFM_STAMP(t0);
   // ---------------- A: finish row r, put row r+1 in flight ----------------
-  if (r >= 0 && r < h) finish_row(C, ps, s0);
+  // (range tests as ONE unsigned compare each: the row step runs at the issue limit of its wave, scalar instructions included)
+  if ((unsigned)r < (unsigned)h) finish_row(C, ps, s0);
   else zero(s0);
   SFM_STAMP(t1);
   const int rn = r + 1, rnn = r + 2;
-  if (rn < rend && rn >= 0 && rn < h) issue_row<HWC>(C, rn, disp_next, ps);
-  if (rnn < rend && rnn >= 0 && rnn < h) disp_next = C.dp[(unsigned)rnn * (unsigned)w + C.xc];
+  if ((unsigned)rn < (unsigned)rend) issue_row<HWC>(C, rn, disp_next, ps);     // rend = min(last row of the pass + 1, h) > 0
+  if ((unsigned)rnn < (unsigned)rend) disp_next = C.dp[(unsigned)rnn * (unsigned)w + C.xc];
   SFM_STAMP(t2);
 
   // ---------------- B: SSIM at row r-1 ----------------
@@ -338,7 +339,7 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const int r, con
     ssim_stage_b<GRAD, LOSS>(s2.ih.p, s1.ih.p, s0.ih.p, s2.it.p, s1.it.p, s0.it.p, kq_nm, g0.a.p, g0.b.p, g0.e.p, ssum);
     ssim_stage_b<GRAD, LOSS>(s2.ih.s, s1.ih.s, s0.ih.s, s2.it.s, s1.it.s, s0.it.s, kq_nm, g0.a.s, g0.b.s, g0.e.s, ssum);
     if (LOSS) {   // branch-free: a halo row simply gets weight 0 (a branch here would split the block and un-fold the DPP adds)
-      const float wgt = (rb >= C.y0 && rb < C.y1) ? s1.nm * C.outf : 0.f;
+      const float wgt = ((unsigned)(rb - C.y0) < (unsigned)(C.y1 - C.y0)) ? s1.nm * C.outf : 0.f;
       acc_ssim = fmaf(ssum, wgt, acc_ssim);                            // base_model.py:114-115
       const float e1 = vabs_sum(s1.ih.p - s1.it.p) + vabs_sum(s1.ih.s - s1.it.s);   // :95
       acc_pix = fmaf(e1, wgt, acc_pix);                                // :98-100,:111
@@ -352,7 +353,7 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const int r, con
 #ifdef SFM_ABLATE_NO_C   // timing experiment only (wrong values)
     if (false) {
 #else
-    if (rc >= C.y0 && rc < C.y1) {
+    if ((unsigned)(rc - C.y0) < (unsigned)(C.y1 - C.y0)) {
 #endif
       const float kpn = C.k_pix * s2.nm;
       f2 gp, q0p, q1p;
@@ -375,6 +376,7 @@ __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, 
                                                  float* gpm_out /* 12 floats in global memory, or nullptr */ SFM_STAMPS_ARG) {
   constexpr int HS = GRAD ? 2 : 1;
   const int rbeg = C.y0 - HS, rend = C.y1 + HS;
+  const int rload = min(rend, C.h);   // rows below are neither inside the image nor part of this pass: never fetched
   float gpm[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) gpm[k] = 0.f;
@@ -388,11 +390,11 @@ __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, 
   if (rbeg >= 0 && rbeg < C.h) issue_row<HWC>(C, rbeg, C.dp[(unsigned)rbeg * (unsigned)C.w + C.xc], ps);
   if (rbeg + 1 >= 0 && rbeg + 1 < C.h) disp_next = C.dp[(unsigned)(rbeg + 1) * (unsigned)C.w + C.xc];
   for (int r = rbeg; r < rend; r += 3) {
-    ssim_row_step<GRAD, LOSS, HWC>(C, r, rend, ps, disp_next, S0, S2, S1, G0, G2, G1, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
+    ssim_row_step<GRAD, LOSS, HWC>(C, r, rload, ps, disp_next, S0, S2, S1, G0, G2, G1, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
     if (r + 1 < rend)
-      ssim_row_step<GRAD, LOSS, HWC>(C, r + 1, rend, ps, disp_next, S1, S0, S2, G1, G0, G2, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
+      ssim_row_step<GRAD, LOSS, HWC>(C, r + 1, rload, ps, disp_next, S1, S0, S2, G1, G0, G2, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
     if (r + 2 < rend)
-      ssim_row_step<GRAD, LOSS, HWC>(C, r + 2, rend, ps, disp_next, S2, S1, S0, G2, G1, G0, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
+      ssim_row_step<GRAD, LOSS, HWC>(C, r + 2, rload, ps, disp_next, S2, S1, S0, G2, G1, G0, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
   }
   if (GRAD) {
 #pragma unroll
