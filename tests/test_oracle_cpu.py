@@ -190,3 +190,23 @@ def test_shard_normalisation_is_additive():
         tot += part.total_loss
         np.testing.assert_allclose(part.d_disps[0], full.d_disps[0][sl], rtol=1e-5, atol=1e-12)
     assert abs(tot - full.total_loss) < 1e-6 * abs(full.total_loss)
+
+
+def test_chainer_op_restatements_agree_with_independent_implementations():
+    """The Chainer ops behind the path are absent from /root/reference, so their restatements cannot
+    be pinned on Chainer itself; they are cross-checked against independent implementations of the documented
+    semantics instead: F.average_pooling_2d(x, 3, 1, 1) == a zero-padded 3x3 box filter divided by 9
+    (scipy.ndimage.uniform_filter, mode='constant'); F.resize_images == bilinear interpolation on the align-corners
+    lattice linspace(0, H-1, oH) x linspace(0, W-1, oW) (scipy.ndimage.map_coordinates, order=1)."""
+    from scipy import ndimage
+    rng = np.random.RandomState(3)
+    x = rng.uniform(-1, 1, size=(2, 3, 17, 23))
+    want = ndimage.uniform_filter(x, size=(1, 1, 3, 3), mode="constant", cval=0.0)
+    np.testing.assert_allclose(O.average_pooling_3x3(x), want, rtol=0, atol=1e-12)
+    for oh, ow in [(8, 11), (17, 23), (5, 7)]:
+        got = O.resize_images(x, (oh, ow), dtype=np.float64)
+        vv, uu = np.meshgrid(np.linspace(0, 16, oh), np.linspace(0, 22, ow), indexing="ij")
+        for n in range(2):
+            for c in range(3):
+                ref = ndimage.map_coordinates(x[n, c], [vv, uu], order=1, mode="nearest")
+                np.testing.assert_allclose(got[n, c], ref, rtol=0, atol=1e-12)
