@@ -9,8 +9,10 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "fused"
 dev = torch.device("cuda:0")
 d = synth.make_inputs(B=32, H=128, W=416, n_src=2, n_scales=4, seed=1)
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-fl = ops.FusedLoss(smooth_reg=0.1, ssim_rate=0.15).bind([t(a) for a in d["tgt_pyr"]], [t(a) for a in d["src_pyr"]], t(d["intrinsics"]),
-                                                        [t(a) for a in d["disps"]], [t(a) for a in d["poses"]])
+layout = os.environ.get("SFM_LAYOUT", "hwc")
+cv = (lambda a: ops.to_hwc(t(a))) if layout == "hwc" else t
+fl = ops.FusedLoss(smooth_reg=0.1, ssim_rate=0.15).bind([cv(a) for a in d["tgt_pyr"]], [cv(a) for a in d["src_pyr"]], t(d["intrinsics"]),
+                                                        [t(a) for a in d["disps"]], [t(a) for a in d["poses"]], layout=layout)
 run = {"fused": fl.forward_backward, "fwd": fl.forward, "bwd": lambda: fl.backward(1.0)}[mode]
 for _ in range(5): run()
 buf = torch.zeros((60000, 4), dtype=torch.int64, device=dev)
