@@ -548,6 +548,14 @@ static void plan_chunks(const SfmLossDesc* d, int sw, int halo2, int slots, int*
   long long items, work;
   int maxcost;
   chunk_layout(d, sw, halo2, bestT, rows, &items, &work, &maxcost);
+  if (const char* rl = getenv("SFM_CHUNK_ROWS_LIST")) {   // tuning override: chunk height per scale, "13,13,16,8"
+    for (int k = 0; *rl && k < d->n_scales; ++k) {
+      const int v = atoi(rl);
+      if (v >= 1 && v <= MAX_CHUNK_ROWS) rows[k] = v;
+      while (*rl && *rl != ',') ++rl;
+      if (*rl == ',') ++rl;
+    }
+  }
 }
 
 // validates the descriptor and lays out items + workspace for the given mode
