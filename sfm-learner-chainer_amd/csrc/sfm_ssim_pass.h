@@ -236,12 +236,13 @@ __device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& 
   // (ds_add_f32: nothing to wait for, unlike a read-modify-write through a register)
   if (first) *ga = gdisp;
   else (void)__hip_atomic_fetch_add(ga, gdisp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-  const float cc0 = s2.D * fmaf(C.K1[0], yf, C.kx[0]);
-  const float cc1 = s2.D * fmaf(C.K1[1], yf, C.kx[1]);
-  const float cc2 = s2.D * fmaf(C.K1[2], yf, C.kx[2]);
-  gpm[0] = fmaf(gq0, cc0, gpm[0]); gpm[1] = fmaf(gq0, cc1, gpm[1]); gpm[2] = fmaf(gq0, cc2, gpm[2]); gpm[3] += gq0;
-  gpm[4] = fmaf(gq1, cc0, gpm[4]); gpm[5] = fmaf(gq1, cc1, gpm[5]); gpm[6] = fmaf(gq1, cc2, gpm[6]); gpm[7] += gq1;
-  gpm[8] = fmaf(gq2, cc0, gpm[8]); gpm[9] = fmaf(gq2, cc1, gpm[9]); gpm[10] = fmaf(gq2, cc2, gpm[10]); gpm[11] += gq2;
+  // dL/dPm[k][j] = sum over pixels of gq_k * c_j with c = D * (K1 y + kx) (the back-projected point), c_3 = 1.  The ray
+  // is linear in the row, so a lane only accumulates  A_k = sum gq_k D,  B_k = sum y gq_k D,  C_k = sum gq_k  (9 values
+  // instead of 12) and expands them once per pass: gpm[k][j] = K1[j] B_k + kx[j] A_k   (pose_sums_expand)
+  const float t0 = gq0 * s2.D, t1 = gq1 * s2.D, t2 = gq2 * s2.D;
+  gpm[0] += t0; gpm[1] += t1; gpm[2] += t2;
+  gpm[3] = fmaf(yf, t0, gpm[3]); gpm[4] = fmaf(yf, t1, gpm[4]); gpm[5] = fmaf(yf, t2, gpm[5]);
+  gpm[6] += gq0; gpm[7] += gq1; gpm[8] += gq2;
   if (C.dsp != nullptr) {   // optional dL/d(src): scatter of dL/dI^ over the four taps (uniform branch)
     const Proj p = project(a0, a1, a2, C.P3[0], C.P3[1], C.P3[2], s2.D, C.sc, h, w);
     if (p.inview && C.outf != 0.f) {
@@ -255,6 +256,20 @@ __device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& 
         atomicAdd(ds + c * C.P + w + 1, gI[c] * w11);
       }
     }
+  }
+}
+
+// the 12 sums of dL/dPm of this (wave, source) from the 9 per-lane accumulators of geometry_backward
+__device__ __forceinline__ void pose_sums_expand(const SsimCtx& C, const float* acc, float* gpm_out) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float v = wave_sum(fmaf(C.K1[j], acc[3 + k], C.kx[j] * acc[k]));
+      if (C.lane == 0) gpm_out[k * 4 + j] = v;
+    }
+    const float v = wave_sum(acc[6 + k]);
+    if (C.lane == 0) gpm_out[k * 4 + 3] = v;
   }
 }
 
@@ -377,9 +392,9 @@ __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, 
   constexpr int HS = GRAD ? 2 : 1;
   const int rbeg = C.y0 - HS, rend = C.y1 + HS;
   const int rload = min(rend, C.h);   // rows below are neither inside the image nor part of this pass: never fetched
-  float gpm[12];
+  float gpm[9];   // A_k, B_k, C_k of geometry_backward
 #pragma unroll
-  for (int k = 0; k < 12; ++k) gpm[k] = 0.f;
+  for (int k = 0; k < 9; ++k) gpm[k] = 0.f;
   // The rings need no initial value: stage B first runs on the third row of the pass, when all three RowS slots have
   // been written, and stage C two rows later, when all three RowG slots have (see ssim_row_step).
   RowS S0, S1, S2;
@@ -396,13 +411,7 @@ __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, 
     if (r + 2 < rend)
       ssim_row_step<GRAD, LOSS, HWC>(C, r + 2, rload, ps, disp_next, S2, S1, S0, G2, G1, G0, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
   }
-  if (GRAD) {
-#pragma unroll
-    for (int k = 0; k < 12; ++k) {
-      const float v = wave_sum(gpm[k]);
-      if (C.lane == 0) gpm_out[k] = v;
-    }
-  }
+  if (GRAD) pose_sums_expand(C, gpm, gpm_out);
 }
 
 // Photometric pass WITHOUT SSIM for one (wave, source): L1 (+ explainability weighting, base_model.py:103-109).
@@ -410,9 +419,9 @@ __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, 
 template <bool GRAD, bool LOSS, bool EXPL, bool HWC>
 __device__ __forceinline__ void l1_source_pass(const SsimCtx& C, float* gacc, const bool first, float& acc_pix, float& acc_exp,
                                                float* gpm_out) {
-  float gpm[12];
+  float gpm[9];   // A_k, B_k, C_k of geometry_backward
 #pragma unroll
-  for (int k = 0; k < 12; ++k) gpm[k] = 0.f;
+  for (int k = 0; k < 9; ++k) gpm[k] = 0.f;
   Pipe ps;
   ps.lg = 0.f;
   float disp_next = 1.f;
@@ -446,13 +455,7 @@ __device__ __forceinline__ void l1_source_pass(const SsimCtx& C, float* gacc, co
       geometry_backward(C, s0, r, gq0, gq1, gI, gacc, first, gpm);
     }
   }
-  if (GRAD) {
-#pragma unroll
-    for (int k = 0; k < 12; ++k) {
-      const float v = wave_sum(gpm[k]);
-      if (C.lane == 0) gpm_out[k] = v;
-    }
-  }
+  if (GRAD) pose_sums_expand(C, gpm, gpm_out);
 }
 
 }  // namespace sfm
