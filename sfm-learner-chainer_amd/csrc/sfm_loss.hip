@@ -94,10 +94,16 @@ __global__ void geom_kernel(const LossArgs A) {
 // ------------------------------------------------------------------------------------------
 // smoothness passes (one per wave, before the sources)
 // ------------------------------------------------------------------------------------------
+// the wave-private d_disp tile: the first contribution of a wave is a plain store, later ones are LDS adds
+__device__ __forceinline__ void tile_put(float* p, const float v, const bool add) {
+  if (add) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  else *p = v;
+}
+
 // second-order, models/base_model.py:169-185
 template <bool GRAD, bool LOSS>
 __device__ __forceinline__ void smooth2_pass(const LossArgs& A, const ScaleArgs& S, const float* __restrict__ dplane, int lane,
-                                             int x, bool xin, bool outl, int y0, int y1, float* gacc, float& acc_sm) {
+                                             int x, bool xin, bool outl, int y0, int y1, float* gacc, float& acc_sm, const bool add) {
   // Every term of compute_smooth_loss is a forward difference anchored at one pixel (a, x):
   //   dx2(a,x)  = d(a,x+2) - 2 d(a,x+1) + d(a,x)                      valid x <= w-3
   //   dy2(a,x)  = d(a+2,x) - 2 d(a+1,x) + d(a,x)                      valid a <= h-3
@@ -149,7 +155,7 @@ __device__ __forceinline__ void smooth2_pass(const LossArgs& A, const ScaleArgs&
         const float gx2 = from_left(s2x1) - 2.f * s2x1 + s2x;
         const float gy2 = s2y_m2 - 2.f * s2y_m1 + s2y;
         const float gxy = from_left(txy_m1) - txy_m1 - from_left(txy) + txy;
-        gacc[(a - y0) * 64 + lane] = gyv * (c_dx2 * gx2 + c_dy2 * gy2 + c_dxy * gxy);
+        tile_put(gacc + (a - y0) * 64 + lane, gyv * (c_dx2 * gx2 + c_dy2 * gy2 + c_dxy * gxy), add);
       }
       s2y_m2 = s2y_m1; s2y_m1 = s2y; txy_m1 = txy;
     }
@@ -161,7 +167,7 @@ __device__ __forceinline__ void smooth2_pass(const LossArgs& A, const ScaleArgs&
 template <bool GRAD, bool LOSS, bool HWC>
 __device__ __forceinline__ void smooth_edge_pass(const LossArgs& A, const ScaleArgs& S, const float* __restrict__ dplane,
                                                  const float* __restrict__ tplane, int lane, int x, bool xin, bool outl, int y0,
-                                                 int y1, float* gacc, float& acc_sm) {
+                                                 int y1, float* gacc, float& acc_sm, const bool add) {
   const int h = S.h, w = S.w;
   const size_t P = (size_t)h * w;
   float dm1 = 0.f, d0 = 0.f, dp1 = 0.f;
@@ -208,7 +214,7 @@ __device__ __forceinline__ void smooth_edge_pass(const LossArgs& A, const ScaleA
       const float tx = signf(ddx) * wx;
       const float gx = from_left(tx) - tx;
       const float gyv = signf(ddym1) * wym1 - signf(ddy0) * wy0;
-      gacc[(q - y0) * 64 + lane] = A.gy * (S.c_ex * gx + S.c_ey * gyv);
+      tile_put(gacc + (q - y0) * 64 + lane, A.gy * (S.c_ex * gx + S.c_ey * gyv), add);
     }
   }
 }
@@ -295,17 +301,22 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
   unsigned long long ts0 = 0, ts1 = 0;
   SFM_STAMP(ts0);
 #endif
-  if (SMODE == 1) {
-    smooth2_pass<GRAD, LOSS>(A, S, S.disp + (size_t)b * P, lane, x, xin, outl, y0, y1, gacc, acc_sm);
-    first = false;
-  } else if (SMODE == 2) {
-    smooth_edge_pass<GRAD, LOSS, HWC>(A, S, S.disp + (size_t)b * P, S.tgt + (size_t)b * 3 * P, lane, x, xin, outl, y0, y1, gacc, acc_sm);
-    first = false;
-  }
+  // Phases of a wave: the smoothness pass and one pass per source.  The smoothness pass is short on arithmetic and long
+  // on latency, and the co-resident waves of a SIMD start together: the middle one (by age) runs it LAST, so that it
+  // does not coincide with the others'.  (One call site per kind of pass: the phase loop costs no code.)
+  const bool smooth_last = (SMODE != 0) && (prio_rank == 1);
+  const int n_phases = A.n_src + (SMODE != 0 ? 1 : 0);
 #ifdef SFM_STAMPS
   SFM_STAMP(ts1);
 #endif
-  for (int i = 0; i < A.n_src; ++i) {
+  for (int ph = 0; ph < n_phases; ++ph) {
+    const int i = (SMODE != 0 && !smooth_last) ? ph - 1 : ph;   // source of this phase; -1 or n_src = the smoothness pass
+    if (SMODE != 0 && (i < 0 || i >= A.n_src)) {
+      if (SMODE == 1) smooth2_pass<GRAD, LOSS>(A, S, S.disp + (size_t)b * P, lane, x, xin, outl, y0, y1, gacc, acc_sm, !first);
+      else smooth_edge_pass<GRAD, LOSS, HWC>(A, S, S.disp + (size_t)b * P, S.tgt + (size_t)b * 3 * P, lane, x, xin, outl, y0, y1, gacc, acc_sm, !first);
+      first = false;
+      continue;
+    }
     if (i * 2 >= A.n_src) set_issue_prio(A.prio_top - prio_rank);
     SsimCtx C;
     // the geometry table was written by geom_kernel before this launch and is read-only here: reading it
