@@ -57,6 +57,7 @@ struct LossArgs {
   unsigned long long* trace;   // diagnostics: per item {t_start, t_end (100 MHz), HW_ID, XCC_ID}; normally nullptr
   int simds_per_xcd;           // SIMDs of one XCD (dispatch rounds -> age rank, see loss_kernel)
   int prio_top;                // resident waves per SIMD - 1, at most 3
+  unsigned prio_tab;           // issue priority levels: 2 bits per (phase, rank), phase = first / second half of the sources
 };
 
 template <bool SSIM, bool GRAD, int SMODE>
@@ -281,7 +282,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
   // order, so the dispatch round is the age rank: the youngest is preferred during the first half of the sources,
   // the oldest during the second, and the waves of a SIMD finish closer together.  Only ever affects speed.
   const int prio_rank = min((int)(blockIdx.x >> 3) / A.simds_per_xcd, A.prio_top);
-  set_issue_prio(prio_rank);
+  set_issue_prio((int)((A.prio_tab >> (2 * prio_rank)) & 3u));
   const int chunk = t / S.strips;
   const int strip = t - chunk * S.strips;
   const int h = S.h, w = S.w;
@@ -317,7 +318,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
       first = false;
       continue;
     }
-    if (i * 2 >= A.n_src) set_issue_prio(A.prio_top - prio_rank);
+    if (i * 2 >= A.n_src) set_issue_prio((int)((A.prio_tab >> (8 + 2 * prio_rank)) & 3u));
     SsimCtx C;
     // the geometry table was written by geom_kernel before this launch and is read-only here: reading it
     // through the constant address space lets the wave fetch the 32 floats with a few scalar loads
@@ -615,6 +616,18 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
   int waves_per_simd = 1;
   const int slots = wave_slots(kfn, &A.simds_per_xcd, &waves_per_simd);
   A.prio_top = waves_per_simd - 1 < 3 ? waves_per_simd - 1 : 3;
+  A.prio_tab = 0;
+  for (int r = 0; r <= A.prio_top; ++r)   // youngest preferred in the first half of the sources, oldest in the second
+    A.prio_tab |= (unsigned)r << (2 * r) | (unsigned)(A.prio_top - r) << (8 + 2 * r);
+  if (const char* pt = getenv("SFM_PRIO_TABLE")) {   // tuning override: "0123,3210" = levels of ranks 0.. in phase 1, phase 2
+    unsigned tab = 0;
+    int phase = 0, r = 0;
+    for (; *pt; ++pt) {
+      if (*pt == ',') { phase = 1; r = 0; }
+      else if (*pt >= '0' && *pt <= '3' && r < 4) { tab |= (unsigned)(*pt - '0') << (8 * phase + 2 * r); ++r; }
+    }
+    A.prio_tab = tab;
+  }
   plan_chunks(d, sw, 2 * (hs > hm ? hs : hm), slots, rows);
   int items = 0;
   for (int s = 0; s < d->n_scales; ++s) {
