@@ -59,7 +59,8 @@ def _knife(ref, s, n_src, thr=2e-5, cell_thr=3e-4, abs_thr=5e-5, clip_thr=1e-4):
     clip = (ref["clip_margin"][s] < clip_thr).any(axis=1)
     own = (ref["cell_margin"][s] < cell_thr).any(axis=1) | (ref["abs_margin"][s] < abs_thr).any(axis=1)
     m = dilate(flip, 2) | dilate(clip, 1) | own
-    assert m.mean() <= max(0.03 * n_src, 30.0 / m[0].size), "too many knife-edge pixels (%g): the exclusion would hide real errors" % m.mean()
+    # (images of a few hundred pixels: a handful of dilated knife-edge pixels is a large share of the image)
+    assert m.mean() <= max(0.03 * n_src, 120.0 / m[0].size), "too many knife-edge pixels (%g): the exclusion would hide real errors" % m.mean()
     return m[:, None]                                 # (B,1,h,w)
 
 
