@@ -4,15 +4,20 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = forward + backward of the multi-scale photometric loss through the C ABI over one
-synthetic batch that is already resident in HBM -- by default the single fused launch
-(sfm_loss_fwd_bwd: loss and all gradients, what SFMLearnerLoss.__call__ runs when backprop is
-enabled); `--mode separate` times sfm_loss_fwd followed by sfm_loss_bwd instead -- plus, for
-N > 1, the RCCL all-reduce of the five reported scalars.  The workload at any N is
-BASELINE.json configs[2]/[3]: B = 32 samples PER GPU, 128x416, 4 scales, 2 sources,
-L1 + SSIM(0.15) + second-order smoothness(0.1) (experiments/sfm_learner_v1_ssim.yml), weak scaling.
+One "step" = forward + backward of the multi-scale photometric loss through the C ABI over one synthetic batch
+that is already resident in HBM: the fused launch sfm_loss_fwd_bwd (loss and all gradients -- what
+SFMLearnerLoss.__call__ runs when backprop is enabled) plus, for N > 1, the RCCL all-reduce of the five
+reported scalars, EVERY step.  Workload at any N: BASELINE.json configs[2]/[3] -- B = 32 samples PER GPU,
+128x416, 4 scales, 2 sources, L1 + SSIM(0.15) + second-order smoothness(0.1) (experiments/sfm_learner_v1_ssim.yml),
+weak scaling.
 
-Metric: warped output Mpixels/s, pixels := B * n_src * sum_s h_s*w_s per step (SURVEY.md §8(d)).
+`--gpus N` with N > 1 and no torchrun environment: this process starts N ranks itself (as child processes, before
+anything touches a GPU) and returns their exit code.
+
+Timing: W untimed warm-up steps, then blocks of EXACTLY K steps, each bracketed by barrier + synchronize on both
+sides (max over ranks); blocks are repeated until >= --min-time seconds have been timed, `ms_per_step` is the MEDIAN
+block (p10 / p90 / first block alongside), `value` follows from it.
+Metric: warped output Mpixels/s, pixels := B * n_src * sum_s h_s*w_s per step (SURVEY.md 8(d)).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -20,6 +25,8 @@ import ctypes as C
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,16 +36,25 @@ if ROOT not in sys.path:
 PKG = "sfm-learner-chainer_amd"
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-BYTES_FWD, BYTES_BWD = 28, 32   # algorithmic bytes per warped pixel, SURVEY.md §8(d)
+BYTES_FWD, BYTES_BWD = 28, 32   # algorithmic bytes per warped pixel, SURVEY.md 8(d)
+N_SIMD = 1024                   # 256 CUs x 4 SIMDs
+# Vector-instruction issue ceiling of the SSIM instruction mix on one SIMD, measured with tools/mix_cycles.hip
+# (profiles/r01_valu_mix_microbench.txt: 175 VALU instructions per iteration; 498 / 447 cycles per iteration and SIMD at
+# 3 / 4 resident waves), and the in-kernel clock of the fused launch (profiles/r02_wave_stage_stamps.txt).
+VALU_CEILING_PER_CYCLE = {3: 175.0 / 498.0, 4: 175.0 / 447.0}
+KERNEL_CLOCK_GHZ = 2.04
+GRAD_BUFFER_FLOATS = 36489060 + 3393892   # DispNet + PoseNet parameters: the ~160 MB all-reduce probe
 
 WORKLOADS = {
     # name: (B per GPU, H, W, n_src, n_scales, loss config, description)
     "cfg3": (32, 128, 416, 2, 4, dict(smooth_reg=0.1, ssim_rate=0.15),
              "BASELINE cfg3: B=32/GPU, 128x416, 4 scales, 2 src, L1+SSIM(0.15)+2nd-order smoothness(0.1)"),
+    "cfg1": (1, 128, 416, 2, 1, dict(),
+             "BASELINE cfg1: B=1, 128x416, 1 scale, 2 src, L1 only (the CPU baseline's workload)"),
     "cfg2": (8, 128, 416, 2, 4, dict(smooth_reg=0.1),
              "BASELINE cfg2: B=8, 128x416, 4 scales, 2 src, L1 + smoothness"),
     "cfg3_edge": (32, 128, 416, 2, 4, dict(smooth_reg=0.1, ssim_rate=0.15, smooth_mode="edge_aware"),
-                  "cfg3 with the edge-aware smoothness (base_model.py:144-155)"),
+                  "BASELINE cfg3 as written: L1+SSIM(0.15)+EDGE-AWARE smoothness (base_model.py:144-155)"),
     "cfg5": (8, 256, 832, 4, 4, dict(smooth_reg=0.1, ssim_rate=0.15),
              "BASELINE cfg5: B=8, 256x832, 5-frame (4 src), 4 scales"),
     "cfg5_2src": (8, 256, 832, 2, 4, dict(smooth_reg=0.1, ssim_rate=0.15),
@@ -50,25 +66,42 @@ class HipEvents:
     """Raw hipEvent_t pairs (torch.cuda.Event does not expose a handle before its first record)."""
 
     def __init__(self):
-        self.hip = C.CDLL("libamdhip64.so")
+        # the HIP runtime instance torch (and libsfmwarp.so) already use: events of another copy of the
+        # library would belong to a different runtime
+        path = None
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64.so" in line:
+                    path = line.split()[-1]
+                    break
+        if path is None:
+            raise RuntimeError("libamdhip64.so is not loaded yet: import torch before creating HipEvents")
+        self.hip = C.CDLL(path)
         self.hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
         self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
         self.hip.hipEventDestroy.argtypes = [C.c_void_p]
 
     def create(self):
         ev = C.c_void_p()
-        assert self.hip.hipEventCreate(C.byref(ev)) == 0
+        rc = self.hip.hipEventCreate(C.byref(ev))
+        if rc != 0:
+            raise RuntimeError("hipEventCreate failed: %d" % rc)
         return ev
 
     def elapsed_ms(self, a, b):
         ms = C.c_float()
-        assert self.hip.hipEventElapsedTime(C.byref(ms), a, b) == 0
+        rc = self.hip.hipEventElapsedTime(C.byref(ms), a, b)
+        if rc != 0:
+            raise RuntimeError("hipEventElapsedTime failed: %d (was the kernel between the events launched?)" % rc)
         return ms.value
 
     def destroy(self, ev):
         self.hip.hipEventDestroy(ev)
 
 
+# ------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle on the host cores (rank 0, N = 1 only)
+# ------------------------------------------------------------------------------------------------
 def cpu_baseline(budget_s=15.0):
     """The oracle (NumPy restatement of the reference's CPU path) timed on this box's host
     cores on BASELINE cfg1: B=1, 128x416, 1 scale, 2 sources, L1 only, forward + backward."""
@@ -122,12 +155,10 @@ sys.stdout.write("%d %.6f\n" % (n, time.perf_counter() - t0)); sys.stdout.flush(
 def cpu_baseline_all_cores(px_per_step, budget_s=8.0):
     """the same cfg1 step as independent samples, one single-threaded process per usable
     core (the path shards by sample), all started together; value = samples finished / wall time."""
-    import subprocess
     # a 1-GPU box is given a share of 16 host cores, whatever the affinity mask says
     n = min(len(os.sched_getaffinity(0)), int(os.environ.get("SFM_CPU_BASELINE_PROCS", "16")))
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
-    here = os.path.dirname(os.path.abspath(__file__))
-    procs = [subprocess.Popen([sys.executable, "-c", _CPU_WORKER, here, PKG, str(k + 1), str(budget_s)], env=env,
+    procs = [subprocess.Popen([sys.executable, "-c", _CPU_WORKER, ROOT, PKG, str(k + 1), str(budget_s)], env=env,
                               stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for k in range(n)]
     try:
         for p in procs:
@@ -151,6 +182,156 @@ def cpu_baseline_all_cores(px_per_step, budget_s=8.0):
             "sample": "%d independent cfg1 samples in %d single-threaded processes, %.0f s each" % (steps, n, budget_s)}
 
 
+# ------------------------------------------------------------------------------------------------
+# multi-GPU: start the ranks (the parent never touches a GPU)
+# ------------------------------------------------------------------------------------------------
+def spawn_ranks(n):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------------------
+# one measured configuration
+# ------------------------------------------------------------------------------------------------
+class Runner:
+    """Inputs of one workload resident on the device and a bound FusedLoss; `block(K)` = K back-to-back steps."""
+
+    def __init__(self, torch, np, ops, synth, dev, workload, layout="hwc", mode="fused", batch=0, seed=1, norm_scale=1):
+        B, H, W, n_src, n_scales, cfg, desc = WORKLOADS[workload]
+        if batch > 0:
+            B, desc = batch, desc + " [per-GPU batch overridden to %d]" % batch
+        self.torch, self.ops, self.dev = torch, ops, dev
+        self.B, self.H, self.W, self.n_src, self.n_scales, self.cfg, self.desc = B, H, W, n_src, n_scales, cfg, desc
+        self.layout, self.mode = layout, mode
+        d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=n_scales, seed=seed)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        self.full = (t(d["tgt"]), t(d["src"]))                         # full-resolution frames (the link's inputs)
+        tgt, src = [t(a) for a in d["tgt_pyr"]], [t(a) for a in d["src_pyr"]]
+        if layout == "hwc":     # the same values, pixel-interleaved
+            tgt, src = [ops.to_hwc(a) for a in tgt], [ops.to_hwc(a) for a in src]
+        self.common = (t(d["intrinsics"]), [t(a) for a in d["disps"]], [t(a) for a in d["poses"]])
+        self.fl = ops.FusedLoss(**cfg).bind(tgt, src, *self.common, norm_B=B * norm_scale, layout=layout)
+        self.warped_px = B * n_src * sum((H >> s) * (W >> s) for s in range(n_scales))
+
+    def step(self, out=None, evs=None):
+        lib, fl = self.ops.lib, self.fl
+        if self.mode == "fused":
+            if evs:
+                lib.sfm_loss_profile_events(evs[0], evs[1])
+            fl.forward_backward(out=out)
+        else:
+            if evs:
+                lib.sfm_loss_profile_events(evs[0], evs[1])
+            fl.forward(out=out)
+            if evs:
+                lib.sfm_loss_profile_events(evs[2], evs[3])
+            fl.backward(1.0)
+
+
+def quick(torch, np, ev, runner, min_time=0.12, k=25):
+    """Secondary measurement (NOT the headline): blocks of k steps until min_time, median block; kernel times from events."""
+    pairs = [[ev.create() for _ in range(4)] for _ in range(k)]
+    for _ in range(8):
+        runner.step()
+    torch.cuda.synchronize()
+    blocks, kt, kt2 = [], [], []
+    t_all = time.perf_counter()
+    while time.perf_counter() - t_all < min_time or len(blocks) < 3:
+        t0 = time.perf_counter()
+        for i in range(k):
+            runner.step(evs=pairs[i])
+        torch.cuda.synchronize()
+        blocks.append((time.perf_counter() - t0) / k)
+        kt += [ev.elapsed_ms(p[0], p[1]) for p in pairs]
+        if runner.mode != "fused":
+            kt2 += [ev.elapsed_ms(p[2], p[3]) for p in pairs]
+    for p in pairs:
+        for e in p:
+            ev.destroy(e)
+    ms = float(np.median(blocks)) * 1e3
+    kms = float(np.mean(kt2 if kt2 else kt))
+    kbytes = (BYTES_FWD + BYTES_BWD) if runner.mode == "fused" else BYTES_BWD
+    return {"workload": runner.desc, "image_layout": runner.layout, "mode": runner.mode, "ms_per_step": round(ms, 5),
+            "value": round(runner.warped_px / (ms * 1e-3) / 1e6, 1), "main_kernel_ms": round(kms, 5),
+            "fwd_kernel_ms": round(float(np.mean(kt)), 5) if kt2 else None,
+            "roofline_frac": round(kbytes * runner.warped_px / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "step_roofline_frac": round((BYTES_FWD + BYTES_BWD) * runner.warped_px / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+
+def link_path(torch, np, runner, min_time=0.12, k=25):
+    """The drop-in path a user of the reference calls: SFMLearnerLoss.__call__ from FULL-RESOLUTION frames (pyramid
+    launch included) + loss.backward() (models/base_model.py:48-124), buffers cached across calls."""
+    links = importlib.import_module(PKG + ".links")
+    cs = importlib.import_module(PKG + ".chainer_surface")
+    r = runner
+    model = links.SFMLearnerLoss(dict(seq_len=r.n_src + 1, smooth_reg=r.cfg.get("smooth_reg", 0.0), exp_reg=0.0,
+                                      ssim_rate=r.cfg.get("ssim_rate", 0.0)), smooth_mode=r.cfg.get("smooth_mode", "second_order"))
+    K, disps, poses = r.common
+    vd, vp = [cs.Variable(a) for a in disps], [cs.Variable(a) for a in poses]
+    tgt, src = r.full
+
+    def step():
+        for v in vd + vp:
+            v.cleargrad()
+        loss = model(tgt, src, K, None, vd, vp)
+        loss.backward()
+        return loss
+
+    for _ in range(8):
+        step()
+    torch.cuda.synchronize()
+    blocks = []
+    t_all = time.perf_counter()
+    while time.perf_counter() - t_all < min_time or len(blocks) < 3:
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        torch.cuda.synchronize()
+        blocks.append((time.perf_counter() - t0) / k)
+    return round(float(np.median(blocks)) * 1e3, 5)
+
+
+def graph_path(torch, np, runner, min_time=0.12, k=25):
+    """The same step replayed from a HIP graph (one hipGraphLaunch per step instead of three kernel launches)."""
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            runner.step()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        runner.step()
+    torch.cuda.synchronize()
+    for _ in range(8):
+        g.replay()
+    torch.cuda.synchronize()
+    blocks = []
+    t_all = time.perf_counter()
+    while time.perf_counter() - t_all < min_time or len(blocks) < 3:
+        t0 = time.perf_counter()
+        for _ in range(k):
+            g.replay()
+        torch.cuda.synchronize()
+        blocks.append((time.perf_counter() - t0) / k)
+    return round(float(np.median(blocks)) * 1e3, 5)
+
+
+def profile_summary(tag_order=("r02", "r01")):
+    for tag in tag_order:
+        path = os.path.join(ROOT, "profiles", "%s_summary.json" % tag)
+        if os.path.exists(path):
+            try:
+                return tag, json.load(open(path))
+            except Exception:
+                pass
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,15 +342,19 @@ def main():
                     help="separate: sfm_loss_fwd then sfm_loss_bwd (the reference's forward / loss.backward()); "
                          "fused: one sfm_loss_fwd_bwd launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads / paths (profiling runs)")
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch of the workload (experiments only)")
     ap.add_argument("--layout", default="hwc", choices=["hwc", "planar"],
                     help="memory layout of the image pyramids resident in HBM when the timed region starts: hwc = pixel-"
                          "interleaved, as sfm_pyramid_hwc_fwd writes them (default); planar = the reference's (B,3,h,w)")
-    ap.add_argument("--report-interval", type=int, default=0,
-                    help="steps per reporting interval: the five scalars of the steps of an interval are summed over the ranks "
-                         "with ONE all-reduce at its end (the reference's trainer reports at LogReport's interval, not per "
-                         "iteration).  0 = one interval over the K timed steps; 1 = a collective every step")
+    ap.add_argument("--min-time", type=float, default=0.3, help="seconds of timed steps at least (blocks of --steps are repeated)")
+    ap.add_argument("--max-blocks", type=int, default=400)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: this process only starts the ranks (fresh child processes, nothing here
+        # has touched a GPU) and hands their exit code on
+        sys.exit(spawn_ranks(args.gpus))
 
     import numpy as np
     import torch
@@ -179,8 +364,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        sys.exit("bench.py --gpus %d, but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ     # under torch.distributed.run, also at N = 1
@@ -191,165 +375,184 @@ def main():
 
     ops = importlib.import_module(PKG + ".ops")
     synth = importlib.import_module(PKG + ".synth")
-    B, H, W, n_src, n_scales, cfg, desc = WORKLOADS[args.workload]
-    if args.batch > 0:
-        B, desc = args.batch, desc + " [per-GPU batch overridden to %d]" % args.batch
-    d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=n_scales, seed=1 + rank)
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    tgt_planar, src_planar = [t(a) for a in d["tgt_pyr"]], [t(a) for a in d["src_pyr"]]
-    common = (t(d["intrinsics"]), [t(a) for a in d["disps"]], [t(a) for a in d["poses"]])
-
-    def bound(layout):
-        if layout == "hwc":     # the same values, pixel-interleaved
-            return ops.FusedLoss(**cfg).bind([ops.to_hwc(a) for a in tgt_planar], [ops.to_hwc(a) for a in src_planar], *common,
-                                             norm_B=B * world, layout="hwc")
-        return ops.FusedLoss(**cfg).bind(tgt_planar, src_planar, *common, norm_B=B * world)
-
-    fl = bound(args.layout)
-    warped_px = B * n_src * sum((H >> s) * (W >> s) for s in range(n_scales))
-
     ev = HipEvents()
-    lib = ops.lib
+    R = Runner(torch, np, ops, synth, dev, args.workload, args.layout, args.mode, args.batch, seed=1 + rank, norm_scale=world)
+    K = max(args.steps, 1)
 
-    # The only collective of the path: the five reported scalars summed over the shards (RCCL over xGMI).  Every
-    # step writes its scalars into its own row of a device-resident log; the rows of a reporting interval are
-    # reduced with one all-reduce at the interval's end, in stream order, inside the timed region.  (Per-sample
-    # gradients never leave their rank.  A collective per step is --report-interval 1.)
-    interval = args.report_interval if args.report_interval > 0 else max(args.steps, 1)
-    n_log = max(args.steps, args.warmup, 1)
+    # The only collective of the path: the five reported scalars summed over the shards (RCCL over xGMI), once per step.
+    # Every step writes its scalars into its own row of a device-resident log and the row is all-reduced asynchronously on
+    # RCCL's stream, so that the next step's launches do not wait for it; per-sample gradients never leave their rank.
+    n_log = max(K, args.warmup, 1)
     loss_log = torch.zeros((n_log, 5), dtype=torch.float32, device=dev)
     rows = [loss_log[k] for k in range(n_log)]
+    events = [[ev.create() for _ in range(4)] for _ in range(K)]
 
-    def step(k, evs=None):
-        if args.mode == "fused":
-            if evs:
-                lib.sfm_loss_profile_events(evs[0], evs[1])
-            fl.forward_backward(out=rows[k])
-        else:
-            if evs:
-                lib.sfm_loss_profile_events(evs[0], evs[1])
-            fl.forward(out=rows[k])
-            if evs:
-                lib.sfm_loss_profile_events(evs[2], evs[3])
-            fl.backward(1.0)
-        if use_dist and ((k + 1) % interval == 0 or k + 1 == n_steps_now[0]):
-            lo = (k // interval) * interval
-            dist.all_reduce(loss_log[lo:k + 1])
+    def run_steps(n, collective, timed):
+        works = []
+        for k in range(n):
+            R.step(out=rows[k], evs=events[k] if timed else None)
+            if collective == "step":
+                works.append(dist.all_reduce(rows[k], async_op=True))
+        if collective == "interval":
+            works.append(dist.all_reduce(loss_log[:n], async_op=True))
+        for w in works:
+            w.wait()
 
-    n_steps_now = [args.warmup]
-    for k in range(args.warmup):
-        step(k)
-    n_steps_now[0] = args.steps
-    events = [[ev.create() for _ in range(4)] for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    if use_dist:
+    def timed_block(collective):
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(K, collective, True)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if use_dist:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return elapsed
+
+    coll = "step" if use_dist else None
+    run_steps(args.warmup, coll, False)
+    blocks, k_main, k_second = [], [], []
+
+    def collect_kernel_times():
+        k_main.extend(ev.elapsed_ms(e[0], e[1]) for e in events)
+        if args.mode == "separate":
+            k_second.extend(ev.elapsed_ms(e[2], e[3]) for e in events)
+
+    blocks.append(timed_block(coll))
+    collect_kernel_times()
+    n_blocks = int(min(args.max_blocks, max(1, np.ceil(args.min_time / max(blocks[0], 1e-9)))))   # the same on every rank
+    for _ in range(n_blocks - 1):
+        blocks.append(timed_block(coll))
+        collect_kernel_times()
+    loss = loss_log[K - 1].cpu().numpy().tolist()
+    per_step = np.array(blocks) / K
+    ms_step = float(np.median(per_step)) * 1e3
+
+    # N > 1: the same with ONE collective per K steps (what a trainer that reports per LogReport interval needs), and the
+    # all-reduce of a DispNet+PoseNet-sized gradient buffer (characterises xGMI; not part of this path)
+    interval_ms = allreduce_probe = None
+    if world > 1:
+        iv = [timed_block("interval") for _ in range(min(n_blocks, 5))]
+        interval_ms = float(np.median(iv)) / K * 1e3
+        buf = torch.zeros((GRAD_BUFFER_FLOATS,), dtype=torch.float32, device=dev)
+        for _ in range(3):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
         dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k, events[k])
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_ar = 10
+        for _ in range(n_ar):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        tt = torch.tensor([(time.perf_counter() - t0) / n_ar], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        t_ar = float(tt.item())
+        nbytes = GRAD_BUFFER_FLOATS * 4
+        allreduce_probe = {"bytes": nbytes, "ms": round(t_ar * 1e3, 4), "algbw_GBs": round(nbytes / t_ar / 1e9, 1),
+                           "busbw_GBs": round(2.0 * (world - 1) / world * nbytes / t_ar / 1e9, 1),
+                           "xgmi_per_link_GBs": 153, "links_per_gpu": 7,
+                           "note": "fp32 sum all-reduce of a DispNet+PoseNet-sized gradient buffer (out-of-scope trainer traffic), "
+                                   "timed only to characterise RCCL over xGMI on this node"}
+        del buf
 
-    # secondary measurements (NOT part of the timed K steps above), for the record: the other image layout ...
-    other_layout = "planar" if args.layout == "hwc" else "hwc"
-    other_layout_ms = None
-    if world == 1:
-        fl2 = bound(other_layout)
-        run2 = fl2.forward_backward if args.mode == "fused" else (lambda: (fl2.forward(), fl2.backward(1.0)))
-        for _ in range(5):
-            run2()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        n_other = max(10, args.steps // 4)
-        for _ in range(n_other):
-            run2()
-        torch.cuda.synchronize()
-        other_layout_ms = (time.perf_counter() - t1) / n_other * 1e3
-        del fl2
-    # ... and the other launch mode
-    other_mode = "separate" if args.mode == "fused" else "fused"
-    other_ms = None
-    if world == 1:
-        def other_step():
-            if other_mode == "fused":
-                fl.forward_backward()
-            else:
-                fl.forward()
-                fl.backward(1.0)
-        for _ in range(5):
-            other_step()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        n_other = max(10, args.steps // 4)
-        for _ in range(n_other):
-            other_step()
-        torch.cuda.synchronize()
-        other_ms = (time.perf_counter() - t1) / n_other * 1e3
+    # secondary measurements (NOT part of the timed blocks above), rank 0 of a single-GPU run only
+    secondary = {}
+    if world == 1 and not args.no_secondary:
+        def guarded(name, fn):
+            try:
+                secondary[name] = fn()
+            except Exception as e:   # a secondary figure must never cost the headline line
+                secondary[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        other_layout = "planar" if args.layout == "hwc" else "hwc"
+        guarded("other_layout", lambda: quick(torch, np, ev, Runner(torch, np, ops, synth, dev, args.workload, other_layout, args.mode, args.batch)))
+        guarded("other_mode", lambda: quick(torch, np, ev, Runner(torch, np, ops, synth, dev, args.workload, args.layout,
+                                                                    "separate" if args.mode == "fused" else "fused", args.batch)))
+        guarded("graph_ms_per_step", lambda: graph_path(torch, np, R))
+        guarded("link_ms_per_step", lambda: link_path(torch, np, R))
+        for name in ("cfg3_edge", "cfg2", "cfg5", "cfg5_2src", "cfg1"):
+            if name != args.workload:
+                guarded(name, lambda name=name: quick(torch, np, ev, Runner(torch, np, ops, synth, dev, name, args.layout, "fused")))
 
-    # per-launch duration of the main kernels, from the HIP events recorded inside the timed region
-    k_fwd = float(np.mean([ev.elapsed_ms(e[0], e[1]) for e in events]))
-    k_bwd = float(np.mean([ev.elapsed_ms(e[2], e[3]) for e in events])) if args.mode == "separate" else None
-    loss = loss_log[max(args.steps - 1, 0)].cpu().numpy().tolist()
     for e4 in events:
         for e in e4:
             ev.destroy(e)
 
     if rank == 0:
-        ms_step = elapsed / args.steps * 1e3
-        value = warped_px * world / (elapsed / args.steps) / 1e6
+        value = R.warped_px * world / (ms_step * 1e-3) / 1e6
         if args.mode == "fused":
-            kname, kbytes, kms = "loss_kernel<grad+loss> (sfm_loss_fwd_bwd)", BYTES_FWD + BYTES_BWD, k_fwd
+            kname, kbytes, kt = "loss_kernel<grad+loss> (sfm_loss_fwd_bwd)", BYTES_FWD + BYTES_BWD, k_main
         else:
-            kname, kbytes, kms = "loss_kernel<grad> (sfm_loss_bwd)", BYTES_BWD, k_bwd
-        achieved = kbytes * warped_px / (kms * 1e-3) / 1e9
-        # HBM-side bytes per launch of that kernel from the rocprofv3 PMC passes (collected offline with
-        # tools/collect_profiles.sh; bench.py itself cannot read hardware counters)
-        traffic = traffic_detail = None
+            kname, kbytes, kt = "loss_kernel<grad> (sfm_loss_bwd)", BYTES_BWD, k_second
+        kms = float(np.mean(kt))
+        achieved = kbytes * R.warped_px / (kms * 1e-3) / 1e9
+        # HBM-side bytes and issued vector instructions per launch of that kernel from the rocprofv3 PMC passes (collected
+        # offline with tools/collect_profiles.sh on this same command; bench.py itself cannot read hardware counters)
+        traffic = traffic_detail = valu = None
+        tag, prof = profile_summary()
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_summary.json")))
-            if prof["bench"]["config"]["mode"] == args.mode and args.workload == "cfg3" and args.batch == 0 \
-                    and prof["bench"]["config"].get("image_layout", "planar") == args.layout:
+            pc = prof["bench"]["config"]
+            if pc["mode"] == args.mode and args.workload == "cfg3" and args.batch == 0 and pc.get("image_layout", "planar") == args.layout:
                 want = "sfm_loss_fwd_bwd" if args.mode == "fused" else "sfm_loss_bwd"
                 for kn, kv in prof["kernels"].items():
                     is_hwc = kn.rstrip().endswith("true>(sfm::LossArgs)")      # last template argument: HWC
                     if kv.get("entry_point") == want and "hbm_bytes_raw" in kv and is_hwc == (args.layout == "hwc"):
-                        # bytes per launch with the guide's gfx950 correction (FETCH_SIZE x 2); raw value alongside
                         traffic = round(kv["hbm_bytes_fetch_x2"])
                         traffic_detail = {"bytes_per_launch_raw": round(kv["hbm_bytes_raw"]),
                                           "bytes_per_launch_fetch_x2": round(kv["hbm_bytes_fetch_x2"]),
-                                          "source": "profiles/r01_summary.json (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes; "
-                                                    "KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md, uncalibrated for 4-8 B/lane loads)"}
+                                          "source": "profiles/%s_summary.json (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes; "
+                                                    "KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md, uncalibrated for 4-12 B/lane loads)" % tag}
+                        if "SQ_INSTS_VALU" in kv.get("pmc", {}):
+                            valu = float(kv["pmc"]["SQ_INSTS_VALU"])
         except Exception:
-            traffic = traffic_detail = None
+            traffic = traffic_detail = valu = None
+        roofline = {
+            # what binds: vector-instruction issue at the kernel's occupancy, not HBM.  `achieved` / `frac` keep
+            # SURVEY 8(d)'s convention (ALGORITHMIC bytes / kernel time vs the 8 TB/s line) so that rounds stay comparable.
+            "bound": "valu_issue", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_detail": traffic_detail,
+            "measured_hbm_frac": round(traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+            "kernel": kname, "kernel_ms": round(kms, 5), "kernel_ms_median": round(float(np.median(kt)), 5),
+            "kernel_ms_p10_p90": [round(float(np.percentile(kt, 10)), 5), round(float(np.percentile(kt, 90)), 5)],
+            "bytes_per_warped_px": kbytes, "launches_timed": len(kt)}
+        roofline_valu = None
+        if valu:
+            wps = 3 if (R.cfg.get("ssim_rate") and not R.cfg.get("exp_reg")) else 4
+            floor_ms = valu / N_SIMD / VALU_CEILING_PER_CYCLE[wps] / (KERNEL_CLOCK_GHZ * 1e9) * 1e3
+            roofline_valu = {"bound": "valu_issue", "valu_insts_per_launch": valu, "waves_per_simd": wps,
+                             "ceiling_insts_per_cycle_per_simd": round(VALU_CEILING_PER_CYCLE[wps], 4), "clock_GHz": KERNEL_CLOCK_GHZ,
+                             "floor_ms": round(floor_ms, 5), "frac": round(floor_ms / kms, 4),
+                             "source": "SQ_INSTS_VALU from profiles/%s_summary.json; ceiling = tools/mix_cycles.hip at that occupancy" % tag}
         out = {
             "metric": "warp+photo-loss fwd+bwd Mpixels/s @128x416x4scales; % HBM roofline",
             "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc, "per_gpu_batch": B, "global_batch": B * world, "H": H, "W": W, "n_src": n_src,
-                       "n_scales": n_scales, "mode": args.mode, "image_layout": args.layout, "warped_px_per_gpu_step": warped_px,
-                       "parallelism": "batch-sharded x%d, RCCL all-reduce of the 5 scalars per reporting interval (%d steps)" % (world, interval)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_detail": traffic_detail, "kernel": kname, "kernel_ms": round(kms, 5), "bytes_per_warped_px": kbytes},
-            "kernel_ms": {"fwd_main": round(k_fwd, 5) if args.mode == "separate" else None,
-                          "bwd_main": round(k_bwd, 5) if k_bwd is not None else None,
-                          "fused_main": round(k_fwd, 5) if args.mode == "fused" else None},
-            "step_roofline_frac": round((BYTES_FWD + BYTES_BWD) * warped_px / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "other_mode": {"mode": other_mode, "ms_per_step": round(other_ms, 5) if other_ms else None,
-                           "value": round(warped_px / (other_ms * 1e-3) / 1e6, 1) if other_ms else None},
-            "other_layout": {"image_layout": other_layout, "ms_per_step": round(other_layout_ms, 5) if other_layout_ms else None,
-                             "value": round(warped_px / (other_layout_ms * 1e-3) / 1e6, 1) if other_layout_ms else None},
+            "config": {"workload": R.desc, "per_gpu_batch": R.B, "global_batch": R.B * world, "H": R.H, "W": R.W, "n_src": R.n_src,
+                       "n_scales": R.n_scales, "mode": args.mode, "image_layout": args.layout, "warped_px_per_gpu_step": R.warped_px,
+                       "parallelism": "batch-sharded x%d; RCCL all-reduce of the 5 scalars EVERY step (async on RCCL's stream)" % world
+                       if use_dist else "single GPU, no collective"},
+            "timing": {"blocks": len(blocks), "steps_per_block": K, "timed_s": round(float(np.sum(blocks)), 4),
+                       "ms_per_step_median": round(ms_step, 5), "ms_per_step_p10": round(float(np.percentile(per_step, 10)) * 1e3, 5),
+                       "ms_per_step_p90": round(float(np.percentile(per_step, 90)) * 1e3, 5),
+                       "ms_per_step_first_block": round(float(per_step[0]) * 1e3, 5), "ms_per_step_min": round(float(per_step.min()) * 1e3, 5)},
+            "roofline": roofline,
+            "roofline_valu": roofline_valu,
+            "step_roofline_frac": round((BYTES_FWD + BYTES_BWD) * R.warped_px / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "loss5": [round(v, 6) for v in loss],
         }
+        if world > 1:
+            out["interval_variant"] = {"ms_per_step": round(interval_ms, 5), "value": round(R.warped_px * world / (interval_ms * 1e-3) / 1e6, 1),
+                                       "note": "ONE all-reduce of the K rows per K steps (reporting per LogReport interval)"}
+            out["allreduce_160MB"] = allreduce_probe
+        out.update(secondary)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

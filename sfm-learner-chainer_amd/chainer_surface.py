@@ -16,10 +16,11 @@ from __future__ import annotations
 
 import contextlib
 import threading
+import weakref
 
 import torch
 
-__all__ = ["Variable", "Function", "InvalidType", "type_check", "argument", "report", "get_report",
+__all__ = ["Variable", "Function", "InvalidType", "type_check", "argument", "report", "get_report", "clear_report",
            "no_backprop_mode", "using_config", "config", "as_array"]
 
 
@@ -113,17 +114,50 @@ argument = _Argument()
 # --------------------------------------------------------------------------------------------
 # chainer.report
 # --------------------------------------------------------------------------------------------
-_reported = {}
+class _Reported(threading.local):
+    """Latest observations of the calling thread, per observer (Chainer scopes a report by the reporter that is current
+    in the calling thread and prefixes the key with the observer's name; here the observer object itself is the scope).
+    Nothing is shared between threads or between two links; an observer's entries go away with the observer."""
+
+    def __init__(self):
+        self.by_observer = weakref.WeakKeyDictionary()
+        self.anonymous = {}
+
+    def slot(self, observer, create):
+        if observer is None:
+            return self.anonymous
+        try:
+            if create:
+                return self.by_observer.setdefault(observer, {})
+            return self.by_observer.get(observer, {})
+        except TypeError:      # an observer that cannot be weakly referenced
+            return self.anonymous
+
+
+_reported = _Reported()
 
 
 def report(values, observer=None):
-    """chainer.report(values, observer): keeps the latest observation under the same keys."""
-    for k, v in values.items():
-        _reported[k] = v
+    """chainer.report(values, observer) (models/base_model.py:119-123): keeps the latest observation under the same keys."""
+    _reported.slot(observer, True).update(values)
 
 
-def get_report():
-    return dict(_reported)
+def get_report(observer=None):
+    """The observations `observer` reported from this thread; without an observer, all of this thread's, merged."""
+    if observer is not None:
+        return dict(_reported.slot(observer, False))
+    out = dict(_reported.anonymous)
+    for d in list(_reported.by_observer.values()):
+        out.update(d)
+    return out
+
+
+def clear_report(observer=None):
+    if observer is None:
+        _reported.by_observer.clear()
+        _reported.anonymous.clear()
+    else:
+        _reported.slot(observer, False).clear()
 
 
 # --------------------------------------------------------------------------------------------
@@ -146,6 +180,7 @@ class Variable:
         self.requires_grad = requires_grad
         self.name = name
         self._out_index = 0
+        self._unit_grad = False
 
     array = property(lambda self: self.data)
     shape = property(lambda self: tuple(self.data.shape))
@@ -166,11 +201,21 @@ class Variable:
         a gradient of one when none has been set."""
         if self.creator is None:
             return
+        seeded_here = False
         if self.grad is None:
             if self.data.numel() != 1:
                 raise RuntimeError("backward() on a non-scalar Variable needs .grad to be set first")
             self.grad = torch.ones_like(self.data)
-            self._unit_grad = True   # lets a fused loss node skip the multiplication by one
+            seeded_here = True
+        # lets a fused loss node skip the multiplication by one -- only during THIS sweep, and only when the seed of ones
+        # was created here (a gradient the caller has set, e.g. a loss scale, is always multiplied in)
+        self._unit_grad = seeded_here
+        try:
+            self._sweep(retain_grad)
+        finally:
+            self._unit_grad = False
+
+    def _sweep(self, retain_grad):
         # topological order by rank (rank = 1 + max rank of the inputs)
         funcs, seen = [], set()
 

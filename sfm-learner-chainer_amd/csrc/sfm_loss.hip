@@ -20,12 +20,15 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <hip/hip_ext.h>
+
 #include "sfm_common.h"
 #include "sfm_ssim_pass.h"
 
 namespace sfm {
 
 constexpr int MAX_CHUNK_ROWS = 32;
+constexpr int MIN_CHUNK_ROWS = 4;
 constexpr int WAVES_PER_BLOCK = 1;   // independent wavefronts; grouped only so that a CU is filled with few workgroups
 
 struct ScaleArgs {
@@ -299,23 +302,28 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
   bool first = true;
 #ifdef SFM_STAMPS
   Stamps st = {0, 0, 0, 0, 0};
-  unsigned long long ts0 = 0, ts1 = 0;
-  SFM_STAMP(ts0);
+  unsigned long long ts0 = 0, cyc_smooth = 0, cyc_src = 0;
+  SFM_STAMP(ts0);      // wave start, in shader cycles (the trace's t_start / t_end are 100 MHz ticks)
 #endif
   // Phases of a wave: the smoothness pass and one pass per source.  The smoothness pass is short on arithmetic and long
   // on latency, and the co-resident waves of a SIMD start together: the middle one (by age) runs it LAST, so that it
   // does not coincide with the others'.  (One call site per kind of pass: the phase loop costs no code.)
   const bool smooth_last = (SMODE != 0) && (prio_rank == 1);
   const int n_phases = A.n_src + (SMODE != 0 ? 1 : 0);
-#ifdef SFM_STAMPS
-  SFM_STAMP(ts1);
-#endif
   for (int ph = 0; ph < n_phases; ++ph) {
     const int i = (SMODE != 0 && !smooth_last) ? ph - 1 : ph;   // source of this phase; -1 or n_src = the smoothness pass
+#ifdef SFM_STAMPS
+    unsigned long long tp0 = 0, tp1 = 0;
+    SFM_STAMP(tp0);
+#endif
     if (SMODE != 0 && (i < 0 || i >= A.n_src)) {
       if (SMODE == 1) smooth2_pass<GRAD, LOSS>(A, S, S.disp + (size_t)b * P, lane, x, xin, outl, y0, y1, gacc, acc_sm, !first);
       else smooth_edge_pass<GRAD, LOSS, HWC>(A, S, S.disp + (size_t)b * P, S.tgt + (size_t)b * 3 * P, lane, x, xin, outl, y0, y1, gacc, acc_sm, !first);
       first = false;
+#ifdef SFM_STAMPS
+      SFM_STAMP(tp1);
+      cyc_smooth += tp1 - tp0;
+#endif
       continue;
     }
     if (i * 2 >= A.n_src) set_issue_prio((int)((A.prio_tab >> (8 + 2 * prio_rank)) & 3u));
@@ -357,11 +365,11 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
       l1_source_pass<GRAD, LOSS, EXPL, HWC>(C, gacc, first, acc_pix, acc_exp, gpm_out);
     }
     first = false;
-  }
 #ifdef SFM_STAMPS
-  unsigned long long ts2 = 0;
-  SFM_STAMP(ts2);
+    SFM_STAMP(tp1);
+    cyc_src += tp1 - tp0;
 #endif
+  }
   if (GRAD) {
     if (outl) {
       float* o = S.d_disp + (size_t)b * P;
@@ -379,9 +387,10 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
       unsigned long long* q = A.trace + (size_t)A.items * 4 + (size_t)item * 8;
       unsigned long long ts3 = 0;
       SFM_STAMP(ts3);
-      q[0] = st.a_fin; q[1] = st.a_iss; q[2] = st.b; q[3] = st.c; q[4] = st.steps; q[5] = ts1 - ts0;
-      q[6] = ts2 - ts1;   // both source passes, everything included
-      q[7] = ts3 - ts2;   // epilogue: d_disp write-out, loss sums
+      q[0] = st.a_fin; q[1] = st.a_iss; q[2] = st.b; q[3] = st.c; q[4] = st.steps;
+      q[5] = cyc_smooth;   // the smoothness pass
+      q[6] = cyc_src;      // the source passes, everything included (context set-up, prologue, row loop, pose sums)
+      q[7] = ts3 - ts0;    // the whole wave in shader cycles (start-up and d_disp write-out = the rest)
     }
 #endif
   }
@@ -504,24 +513,57 @@ static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 static thread_local unsigned long long* g_trace = nullptr;   // sfm_loss_debug_trace
 
 // ---- work decomposition -----------------------------------------------------------------
-// One wavefront per (scale, sample, strip, chunk of rows).  The register footprint of the SSIM
-// gradient kernel allows 2 wavefronts per SIMD (2048 slots on 256 CUs), and a wave lives for the
-// whole launch, so the chunk height is chosen such that all items fit in as few full "rounds" of
-// resident waves as possible while the halo rows (recomputed per chunk) stay a small fraction.
+// One wavefront per (scale, sample, strip, chunk of rows).  A wave lives for the whole launch, so the chunk
+// height is chosen such that all items fit in as few full "rounds" of resident waves as possible while the
+// halo rows (recomputed per chunk) stay a small fraction.  The number of resident waves follows from the
+// __launch_bounds__ of the kernel variant (3 waves per SIMD for the SSIM gradient kernels, 4 otherwise; LDS
+// and the 32-waves-per-CU cap allow more) and from the CU count of the device -- no occupancy query, nothing
+// that differs between a CPU-only host and the GPU box.
 template <bool GRAD, bool LOSS>
 static const void* kernel_ptr(bool ssim, bool expl, int smode, bool hwc);
 
-static int wave_slots(const void* kernel, int* simds_per_xcd = nullptr, int* waves_per_simd = nullptr) {
-  int dev = 0, cus = 0, per_cu = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64 * WAVES_PER_BLOCK, 0) != hipSuccess || cus <= 0 || per_cu <= 0) {
-    (void)hipGetLastError();
-    cus = 256; per_cu = 8;   // no device visible (workspace query on a CPU-only host): MI355X, 2 waves per SIMD
+constexpr int MI355X_CUS = 256;   // 8 XCDs x 32 CUs (MI355X_MICROARCH.md); used when no device is visible
+
+static int device_cus() {
+  static int cus_of[64];   // 0 = not asked yet; a benign race writes the same value twice
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return MI355X_CUS; }
+  if (cus_of[dev] == 0) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = MI355X_CUS; }
+    cus_of[dev] = cus;
   }
-  if (simds_per_xcd) *simds_per_xcd = (cus % 8 == 0) ? cus / 8 * 4 : 128;   // gfx950: 8 XCDs, 4 SIMDs per CU
-  if (waves_per_simd) *waves_per_simd = (per_cu * WAVES_PER_BLOCK + 3) / 4;
-  return cus * per_cu * WAVES_PER_BLOCK;
+  return cus_of[dev];
 }
+
+static int waves_per_simd_of(bool ssim, bool grad) { return (ssim && grad) ? 3 : 4; }   // = __launch_bounds__ of loss_kernel
+
+// tuning overrides (development only), read from the environment ONCE per process
+struct Tuning {
+  int chunk_rows = 0;                       // SFM_CHUNK_ROWS: fixed target height
+  int rows_list[SFM_MAX_SCALES] = {0};      // SFM_CHUNK_ROWS_LIST: chunk height per scale, "13,13,16,8"
+  bool has_prio = false;
+  unsigned prio_tab = 0;                    // SFM_PRIO_TABLE: "0123,3210" = levels of ranks 0.. in phase 1, phase 2
+  Tuning() {
+    if (const char* e = getenv("SFM_CHUNK_ROWS")) chunk_rows = atoi(e);
+    if (const char* rl = getenv("SFM_CHUNK_ROWS_LIST")) {
+      for (int k = 0; *rl && k < SFM_MAX_SCALES; ++k) {
+        rows_list[k] = atoi(rl);
+        while (*rl && *rl != ',') ++rl;
+        if (*rl == ',') ++rl;
+      }
+    }
+    if (const char* pt = getenv("SFM_PRIO_TABLE")) {
+      int phase = 0, r = 0;
+      for (; *pt; ++pt) {
+        if (*pt == ',') { phase = 1; r = 0; }
+        else if (*pt >= '0' && *pt <= '3' && r < 4) { prio_tab |= (unsigned)(*pt - '0') << (8 * phase + 2 * r); ++r; }
+      }
+      has_prio = true;
+    }
+  }
+};
+static const Tuning& tuning() { static const Tuning t; return t; }
 
 // chunk height per scale for a target height T: equal chunks, never more than T rows
 static void chunk_layout(const SfmLossDesc* d, int sw, int halo2, int T, int* rows, long long* items, long long* work, int* maxcost) {
@@ -539,12 +581,11 @@ static void chunk_layout(const SfmLossDesc* d, int sw, int halo2, int T, int* ro
 }
 
 static void plan_chunks(const SfmLossDesc* d, int sw, int halo2, int slots, int* rows) {
-  const char* e = getenv("SFM_CHUNK_ROWS");   // tuning override: fixed target height
-  const int forced = e ? atoi(e) : 0;
+  const int forced = tuning().chunk_rows;
   int bestT = MAX_CHUNK_ROWS;
   double best = 1e300;
-  for (int T = 4; T <= MAX_CHUNK_ROWS; ++T) {
-    if (forced >= 1 && forced <= MAX_CHUNK_ROWS && T != forced) continue;
+  for (int T = MIN_CHUNK_ROWS; T <= MAX_CHUNK_ROWS; ++T) {
+    if (forced >= MIN_CHUNK_ROWS && forced <= MAX_CHUNK_ROWS && T != forced) continue;
     long long items, work;
     int maxcost, r[SFM_MAX_SCALES];
     chunk_layout(d, sw, halo2, T, r, &items, &work, &maxcost);
@@ -560,14 +601,21 @@ static void plan_chunks(const SfmLossDesc* d, int sw, int halo2, int slots, int*
   long long items, work;
   int maxcost;
   chunk_layout(d, sw, halo2, bestT, rows, &items, &work, &maxcost);
-  if (const char* rl = getenv("SFM_CHUNK_ROWS_LIST")) {   // tuning override: chunk height per scale, "13,13,16,8"
-    for (int k = 0; *rl && k < d->n_scales; ++k) {
-      const int v = atoi(rl);
-      if (v >= 1 && v <= MAX_CHUNK_ROWS) rows[k] = v;
-      while (*rl && *rl != ',') ++rl;
-      if (*rl == ',') ++rl;
-    }
+  for (int k = 0; k < d->n_scales; ++k) {
+    const int v = tuning().rows_list[k];
+    if (v >= MIN_CHUNK_ROWS && v <= MAX_CHUNK_ROWS) rows[k] = v;
   }
+}
+
+// upper bound of the item count over every chunking plan_chunks can choose (chunks are never shorter than
+// MIN_CHUNK_ROWS unless the image is): what sfm_loss_workspace_bytes sizes for, on any host
+static long long max_items(const SfmLossDesc* d, int sw) {
+  long long items = 0;
+  for (int s = 0; s < d->n_scales; ++s) {
+    const int h = d->H[s], strips = (d->W[s] + sw - 1) / sw;
+    items += (long long)d->B * strips * ((h + MIN_CHUNK_ROWS - 1) / MIN_CHUNK_ROWS);
+  }
+  return items;
 }
 
 // validates the descriptor and lays out items + workspace for the given mode
@@ -611,23 +659,15 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
   int rows[SFM_MAX_SCALES];
   for (int s = 0; s < d->n_scales; ++s)
     if (d->H[s] < 3 || d->W[s] < 3) return fail(SFM_ERR_SHAPE, "sfm_loss: scale %d is %dx%d, need H,W >= 3", s, d->H[s], d->W[s]);
-  const void* kfn = grad ? (need_loss ? kernel_ptr<true, true>(p.ssim, p.expl, p.smode, p.hwc) : kernel_ptr<true, false>(p.ssim, p.expl, p.smode, p.hwc))
-                         : kernel_ptr<false, true>(p.ssim, p.expl, p.smode, p.hwc);
-  int waves_per_simd = 1;
-  const int slots = wave_slots(kfn, &A.simds_per_xcd, &waves_per_simd);
+  const int cus = device_cus();
+  const int waves_per_simd = waves_per_simd_of(p.ssim, grad);
+  const int slots = cus * 4 * waves_per_simd;
+  A.simds_per_xcd = (cus % 8 == 0) ? cus / 8 * 4 : 128;   // gfx950: 8 XCDs, 4 SIMDs per CU
   A.prio_top = waves_per_simd - 1 < 3 ? waves_per_simd - 1 : 3;
   A.prio_tab = 0;
   for (int r = 0; r <= A.prio_top; ++r)   // youngest preferred in the first half of the sources, oldest in the second
     A.prio_tab |= (unsigned)r << (2 * r) | (unsigned)(A.prio_top - r) << (8 + 2 * r);
-  if (const char* pt = getenv("SFM_PRIO_TABLE")) {   // tuning override: "0123,3210" = levels of ranks 0.. in phase 1, phase 2
-    unsigned tab = 0;
-    int phase = 0, r = 0;
-    for (; *pt; ++pt) {
-      if (*pt == ',') { phase = 1; r = 0; }
-      else if (*pt >= '0' && *pt <= '3' && r < 4) { tab |= (unsigned)(*pt - '0') << (8 * phase + 2 * r); ++r; }
-    }
-    A.prio_tab = tab;
-  }
+  if (tuning().has_prio) A.prio_tab = tuning().prio_tab;
   plan_chunks(d, sw, 2 * (hs > hm ? hs : hm), slots, rows);
   int items = 0;
   for (int s = 0; s < d->n_scales; ++s) {
@@ -667,10 +707,14 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
     S.c_exp = (float)((double)d->exp_reg / (nb * h * w));
   }
   A.items = items;
+  // The workspace layout does not depend on the chunking (nor on the device): the two partial-sum arrays are placed
+  // and sized for the largest item count any chunking can produce.
+  const size_t cap = (size_t)max_items(d, sw);
+  if ((size_t)items > cap) return fail(SFM_ERR_CONFIG, "sfm_loss: internal error: %d items exceed the bound %zu", items, cap);
   p.off_geom = 0;
   p.off_loss = align_up(p.off_geom + (size_t)d->B * d->n_scales * d->n_src * sizeof(Geom), 256);
-  p.off_gpm = align_up(p.off_loss + (size_t)items * 4 * sizeof(float), 256);
-  p.total = align_up(p.off_gpm + (size_t)items * d->n_src * 12 * sizeof(float), 256);
+  p.off_gpm = align_up(p.off_loss + cap * 4 * sizeof(float), 256);
+  p.total = align_up(p.off_gpm + cap * d->n_src * 12 * sizeof(float), 256);
   return SFM_OK;
 }
 
@@ -701,50 +745,80 @@ static const void* kernel_ptr(bool ssim, bool expl, int smode, bool hwc) {
 }
 
 template <bool GRAD, bool LOSS>
-static void launch_main(const Plan& p, hipStream_t st) {
+static hipError_t launch_main(const Plan& p, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
   LossArgs args = p.args;
   void* kargs[] = {&args};
   // 8 x (items of the busiest XCD): see the item mapping at the top of loss_kernel
   int tiles_per_sample = 0;
   for (int s = 0; s < p.args.n_scales; ++s) tiles_per_sample += p.args.sc[s].tiles;
   const int per_xcd = p.args.B >= 8 ? ((p.args.B + 7) / 8) * tiles_per_sample : (p.args.items + 7) / 8;
-  (void)hipLaunchKernel(kernel_ptr<GRAD, LOSS>(p.ssim, p.expl, p.smode, p.hwc), dim3(8 * per_xcd), dim3(64 * WAVES_PER_BLOCK), kargs, 0, st);
+  const void* fn = kernel_ptr<GRAD, LOSS>(p.ssim, p.expl, p.smode, p.hwc);
+  // With profiling events the kernel is launched through hipExtLaunchKernel: the events then carry the begin / end
+  // timestamps of THIS dispatch (what rocprofv3's kernel trace reports), and no marker packets are put between the
+  // launches of a step (hipEventRecord on either side of the kernel costs the step several microseconds).
+  if (ev_start && ev_stop) return hipExtLaunchKernel(fn, dim3(8 * per_xcd), dim3(64 * WAVES_PER_BLOCK), kargs, 0, st, ev_start, ev_stop, 0);
+  return hipLaunchKernel(fn, dim3(8 * per_xcd), dim3(64 * WAVES_PER_BLOCK), kargs, 0, st);
+}
+
+// The plan of a descriptor depends only on the descriptor's bytes and the entry point: the last few are kept per
+// thread, so that a training loop that calls with the same buffers every step does the validation and the chunk
+// search once.  (Thread-local, like the error string: no state is shared between threads.)
+struct CachedPlan {
+  SfmLossDesc desc;
+  int device;
+  bool grad, loss, valid;
+  Plan plan;
+};
+constexpr int PLAN_CACHE = 4;
+static thread_local CachedPlan g_plans[PLAN_CACHE];
+static thread_local unsigned g_plan_clock = 0;
+
+static int cached_plan(const SfmLossDesc* d, bool grad, bool loss, float gy, Plan& out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; }
+  for (int k = 0; k < PLAN_CACHE; ++k) {
+    CachedPlan& c = g_plans[k];
+    if (c.valid && c.grad == grad && c.loss == loss && c.device == dev && memcmp(&c.desc, d, sizeof(SfmLossDesc)) == 0) {
+      out = c.plan;
+      out.args.gy = gy;
+      return SFM_OK;
+    }
+  }
+  if (int e = make_plan(d, grad, loss, true, gy, out)) return e;
+  CachedPlan& c = g_plans[g_plan_clock++ % PLAN_CACHE];
+  c.desc = *d; c.device = dev; c.grad = grad; c.loss = loss; c.plan = out; c.valid = true;
+  return SFM_OK;
 }
 
 static int run(const SfmLossDesc* d, bool grad, bool loss, float gy, float* loss5, void* ws, size_t ws_bytes, void* stream,
                const char* who) {
+  hipStream_t st = (hipStream_t)stream;
   if (d && d->B == 0) {   // empty shard: nothing to launch (input pointers of empty arrays may be NULL)
     if (loss) {
       if (!loss5) return fail(SFM_ERR_NULL, "%s: loss5 is NULL", who);
-      hipError_t e = hipMemsetAsync(loss5, 0, 5 * sizeof(float), (hipStream_t)stream);
-      if (e != hipSuccess) return fail((int)e, "%s: memset: %s", who, hipGetErrorString(e));
-    }
-    return SFM_OK;
-  }
-  Plan p;
-  if (int e = make_plan(d, grad, loss, true, gy, p)) return e;
-  if (loss && !loss5) return fail(SFM_ERR_NULL, "%s: loss5 is NULL", who);
-  if (!ws || ws_bytes < p.total) return fail(SFM_ERR_WORKSPACE, "%s: workspace of %zu bytes needed, got %zu", who, p.total, ws_bytes);
-  if (((uintptr_t)ws & 255) != 0) return fail(SFM_ERR_WORKSPACE, "%s: workspace must be 256-byte aligned", who);
-  bind_workspace(p, ws);
-  hipStream_t st = (hipStream_t)stream;
-  if (d->B == 0) {
-    if (loss) {
       hipError_t e = hipMemsetAsync(loss5, 0, 5 * sizeof(float), st);
       if (e != hipSuccess) return fail((int)e, "%s: memset: %s", who, hipGetErrorString(e));
     }
     return SFM_OK;
   }
+  if (!d) return fail(SFM_ERR_NULL, "%s: NULL descriptor", who);
+  Plan p;
+  if (int e = cached_plan(d, grad, loss, gy, p)) return e;
+  if (loss && !loss5) return fail(SFM_ERR_NULL, "%s: loss5 is NULL", who);
+  if (!ws || ws_bytes < p.total) return fail(SFM_ERR_WORKSPACE, "%s: workspace of %zu bytes needed, got %zu", who, p.total, ws_bytes);
+  if (((uintptr_t)ws & 255) != 0) return fail(SFM_ERR_WORKSPACE, "%s: workspace must be 256-byte aligned", who);
+  bind_workspace(p, ws);
   const int ng = d->B * d->n_scales * d->n_src;
   hipLaunchKernelGGL(geom_kernel, dim3((ng + 63) / 64), dim3(64), 0, st, p.args);
   p.args.trace = g_trace;
   g_trace = nullptr;
-  if (g_ev_start) (void)hipEventRecord(g_ev_start, st);
-  if (grad && loss) launch_main<true, true>(p, st);
-  else if (grad) launch_main<true, false>(p, st);
-  else launch_main<false, true>(p, st);
-  if (g_ev_stop) (void)hipEventRecord(g_ev_stop, st);
+  hipEvent_t ev_start = g_ev_start, ev_stop = g_ev_stop;
   g_ev_start = g_ev_stop = nullptr;
+  hipError_t le;
+  if (grad && loss) le = launch_main<true, true>(p, st, ev_start, ev_stop);
+  else if (grad) le = launch_main<true, false>(p, st, ev_start, ev_stop);
+  else le = launch_main<false, true>(p, st, ev_start, ev_stop);
+  if (le != hipSuccess) return fail((int)le, "%s: launch of the main kernel: %s", who, hipGetErrorString(le));
   const int n_pose_blocks = grad ? d->B * d->n_src : 0;
   hipLaunchKernelGGL(finalize_kernel, dim3(n_pose_blocks + 1), dim3(64 * FINALIZE_WAVES), 0, st, p.args, loss ? loss5 : (float*)nullptr, n_pose_blocks);
   return check_launch(who);

@@ -81,14 +81,96 @@ __global__ void pose_proj_bwd_kernel(const float* __restrict__ pose6, const floa
 }
 
 // ------------------------------------------------------------------------------------------
-// projective_inverse_warp  (models/transform.py:156-193)
+// F.spatial_transformer_sampler (call site models/transform.py:189): general semantics on the
+// zero-padded image, for arbitrary grids
+// ------------------------------------------------------------------------------------------
+struct PadTap {
+  int u0, v0;             // top-left tap in PADDED coordinates, u0 in [0,W], v0 in [0,H]
+  float wx0, wx1, wy0, wy1;
+  bool ok_u, ok_v;        // coordinate inside the padded image (gradient mask)
+};
+
+__device__ __forceinline__ PadTap pad_taps(float gx, float gy, int H, int W) {
+#pragma clang fp contract(off)
+  PadTap t;
+  const float up = (gx + 1.0f) * (float)(W - 1) * 0.5f + 1.0f;
+  const float vp = (gy + 1.0f) * (float)(H - 1) * 0.5f + 1.0f;
+  const float uc = fminf(fmaxf(up, 0.0f), (float)(W + 1));
+  const float vc = fminf(fmaxf(vp, 0.0f), (float)(H + 1));
+  t.u0 = min(max((int)floorf(uc), 0), W);
+  t.v0 = min(max((int)floorf(vc), 0), H);
+  t.wx0 = (float)(t.u0 + 1) - uc;
+  t.wx1 = uc - (float)t.u0;
+  t.wy0 = (float)(t.v0 + 1) - vc;
+  t.wy1 = vc - (float)t.v0;
+  t.ok_u = (up >= 0.0f) && (up <= (float)(W + 1));
+  t.ok_v = (vp >= 0.0f) && (vp <= (float)(H + 1));
+  return t;
+}
+
+__device__ __forceinline__ float pad_read(const float* img, int v, int u, int H, int W) {  // padded coords
+  return (u >= 1 && u <= W && v >= 1 && v <= H) ? img[(v - 1) * W + (u - 1)] : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------
+// projective_inverse_warp  (models/transform.py:156-193) -- the API-parity operator.
+//
+// Unlike the fused loss kernels (which pre-multiply the geometry), this operator keeps the REFERENCE'S
+// evaluation order, step by step and without fused multiply-adds:
+//   ray = K^-1 . (x, y, 1)                         transform.py:105-106   (batch_matmul: left to right over k)
+//   c   = D (.) ray ; c4 = (c, 1)                  :107-108
+//   q   = Pm . c4 ; z = q2 + 1e-10                 :122-123
+//   xn  = (q0 / z) / ((W-1)/2.) - 1 ; yn likewise  :124-125
+//   each component not strictly inside (-1, 1) is doubled   :128-131
+//   F.spatial_transformer_sampler on the zero-padded image  :189  (pad_taps / pad_read above)
+// so that the set of exactly-zero output pixels and the sampling positions are the reference's own.
 // one block = 256 consecutive pixels of one sample; the block's geometry is built once in LDS
 // ------------------------------------------------------------------------------------------
 constexpr int WARP_BLOCK = 256;
 
+struct RefProj {
+  float ray[3], c[3];   // K^-1 . pix ; D (.) ray
+  float z, U, V;        // q2 + 1e-10 ; q0 / z ; q1 / z
+  float mx, my;         // 1 inside (-1, 1), else 2     (transform.py:128-130)
+  float gx, gy;         // the grid coordinates handed to the sampler (xn * mx, yn * my)
+};
+
+__device__ __forceinline__ RefProj ref_project(const Geom& g, const float xf, const float yf, const float* D, const int H, const int W) {
+#pragma clang fp contract(off)
+  RefProj r;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    r.ray[j] = (g.Kinv[j * 3 + 0] * xf + g.Kinv[j * 3 + 1] * yf) + g.Kinv[j * 3 + 2];   // the third coordinate of pix is 1
+    r.c[j] = D[j] * r.ray[j];
+  }
+  float q[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) q[k] = ((g.P[k * 4 + 0] * r.c[0] + g.P[k * 4 + 1] * r.c[1]) + g.P[k * 4 + 2] * r.c[2]) + g.P[k * 4 + 3];
+  r.z = q[2] + 1e-10f;
+  r.U = q[0] / r.z;
+  r.V = q[1] / r.z;
+  const float half_w = (float)((double)(W - 1) / 2.0), half_h = (float)((double)(H - 1) / 2.0);
+  const float xn = r.U / half_w - 1.0f, yn = r.V / half_h - 1.0f;
+  r.mx = (xn > -1.0f && xn < 1.0f) ? 1.0f : 2.0f;     // NaN compares false: doubled, stays NaN
+  r.my = (yn > -1.0f && yn < 1.0f) ? 1.0f : 2.0f;
+  r.gx = xn * r.mx;
+  r.gy = yn * r.my;
+  return r;
+}
+
+__device__ __forceinline__ void load_depth3(const float* depth, const int n, const int drows, const int P, const int j, float* D) {
+  if (drows == 1) {   // one row of the reference's (N,3,H*W) broadcast (base_model.py:82-84)
+    D[0] = D[1] = D[2] = depth[(size_t)n * P + j];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) D[r] = depth[((size_t)n * 3 + r) * P + j];
+  }
+}
+
 __global__ void __launch_bounds__(WARP_BLOCK) warp_fwd_kernel(const float* __restrict__ src, const float* __restrict__ depth,
                                                               const float* __restrict__ pose6, const float* __restrict__ K,
                                                               float* __restrict__ warped, int C, int H, int W, int drows) {
+#pragma clang fp contract(off)
   __shared__ Geom g;
   const int n = blockIdx.y;
   if (threadIdx.x == 0) make_geom(pose6 + n * 6, K + n * 9, g);
@@ -97,45 +179,29 @@ __global__ void __launch_bounds__(WARP_BLOCK) warp_fwd_kernel(const float* __res
   const int j = blockIdx.x * WARP_BLOCK + threadIdx.x;
   if (j >= P) return;
   const int y = j / W, x = j - y * W;
-  const float xf = (float)x, yf = (float)y;
-  const ScaleConst sc = make_scale_const(H, W);
-  Proj p;
-  if (drows == 1) {
-    const float D = depth[(size_t)n * P + j];
-    const float a0 = fmaf(g.M[0], xf, fmaf(g.M[1], yf, g.M[2]));
-    const float a1 = fmaf(g.M[3], xf, fmaf(g.M[4], yf, g.M[5]));
-    const float a2 = fmaf(g.M[6], xf, fmaf(g.M[7], yf, g.M[8]));
-    p = project(a0, a1, a2, g.P[3], g.P[7], g.P[11], D, sc, H, W);
-  } else {   // three independent depth rows: c_j = D_j * (Kinv . pix)_j   (transform.py:105-107)
-    float c[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-      c[r] = depth[((size_t)n * 3 + r) * P + j] * fmaf(g.Kinv[r * 3 + 0], xf, fmaf(g.Kinv[r * 3 + 1], yf, g.Kinv[r * 3 + 2]));
-    p = project_q(fmaf(g.P[0], c[0], fmaf(g.P[1], c[1], fmaf(g.P[2], c[2], g.P[3]))),
-                  fmaf(g.P[4], c[0], fmaf(g.P[5], c[1], fmaf(g.P[6], c[2], g.P[7]))),
-                  fmaf(g.P[8], c[0], fmaf(g.P[9], c[1], fmaf(g.P[10], c[2], g.P[11]))), sc);
-  }
-  const float* s = src + (size_t)n * C * P + p.v0 * W + p.u0;
-  float* o = warped + (size_t)n * C * P + j;
+  float D[3];
+  load_depth3(depth, n, drows, P, j, D);
+  const RefProj r = ref_project(g, (float)x, (float)y, D, H, W);
+  const PadTap t = pad_taps(r.gx, r.gy, H, W);
+  const float w1 = t.wx0 * t.wy0, w2 = t.wx1 * t.wy0, w3 = t.wx0 * t.wy1, w4 = t.wx1 * t.wy1;
   for (int c = 0; c < C; ++c) {
-    float val = 0.f;
-    if (p.inview) {
-      const Tap2 t = load_tap2(s + (size_t)c * P);
-      const Tap2 b = load_tap2(s + (size_t)c * P + W);
-      const float top = fmaf(p.fu, t.b - t.a, t.a);
-      const float bot = fmaf(p.fu, b.b - b.a, b.a);
-      val = fmaf(p.fv, bot - top, top);
-    }
-    o[(size_t)c * P] = val;
+    const float* img = src + ((size_t)n * C + c) * P;
+    float v = w1 * pad_read(img, t.v0, t.u0, H, W);
+    v += w2 * pad_read(img, t.v0, t.u0 + 1, H, W);
+    v += w3 * pad_read(img, t.v0 + 1, t.u0, H, W);
+    v += w4 * pad_read(img, t.v0 + 1, t.u0 + 1, H, W);
+    warped[((size_t)n * C + c) * P + j] = v;
   }
 }
 
-// per pixel: gq from g_warped, d_depth, and the 12 sums of gPm (block-reduced into ws)
+// per pixel: the reference's backward chain (sampler -> x mask -> normalisation -> perspective division -> Pm . c4 -> D (.) ray),
+// d_depth, and the 12 sums of gPm (block-reduced into ws)
 __global__ void __launch_bounds__(WARP_BLOCK) warp_bwd_kernel(const float* __restrict__ src, const float* __restrict__ depth,
                                                               const float* __restrict__ pose6, const float* __restrict__ K,
                                                               const float* __restrict__ g_warped, float* __restrict__ d_depth,
                                                               float* __restrict__ d_src, float* __restrict__ part, int C, int H,
                                                               int W, int drows) {
+#pragma clang fp contract(off)
   __shared__ Geom g;
   __shared__ float red[WARP_BLOCK / 64][12];
   const int n = blockIdx.y;
@@ -148,57 +214,48 @@ __global__ void __launch_bounds__(WARP_BLOCK) warp_bwd_kernel(const float* __res
   for (int k = 0; k < 12; ++k) acc[k] = 0.f;
   if (j < P) {
     const int y = j / W, x = j - y * W;
-    const float xf = (float)x, yf = (float)y;
-    const ScaleConst sc = make_scale_const(H, W);
-    const float r0 = fmaf(g.Kinv[0], xf, fmaf(g.Kinv[1], yf, g.Kinv[2]));
-    const float r1 = fmaf(g.Kinv[3], xf, fmaf(g.Kinv[4], yf, g.Kinv[5]));
-    const float r2 = fmaf(g.Kinv[6], xf, fmaf(g.Kinv[7], yf, g.Kinv[8]));
-    float Dj[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) Dj[r] = depth[((size_t)n * drows + (drows == 1 ? 0 : r)) * P + j];
-    const float c0 = Dj[0] * r0, c1 = Dj[1] * r1, c2 = Dj[2] * r2;
-    const Proj p = project_q(fmaf(g.P[0], c0, fmaf(g.P[1], c1, fmaf(g.P[2], c2, g.P[3]))),
-                             fmaf(g.P[4], c0, fmaf(g.P[5], c1, fmaf(g.P[6], c2, g.P[7]))),
-                             fmaf(g.P[8], c0, fmaf(g.P[9], c1, fmaf(g.P[10], c2, g.P[11]))), sc);
-    float gU = 0.f, gV = 0.f;
-    if (p.inview) {
-      const size_t base = (size_t)n * C * P + p.v0 * W + p.u0;
-      for (int c = 0; c < C; ++c) {
-        const float gc = g_warped[(size_t)n * C * P + (size_t)c * P + j];
-        const Tap2 t = load_tap2(src + base + (size_t)c * P);
-        const Tap2 b = load_tap2(src + base + (size_t)c * P + W);
-        const float dxt = t.b - t.a, dxb = b.b - b.a;
-        const float top = fmaf(p.fu, dxt, t.a);
-        const float bot = fmaf(p.fu, dxb, b.a);
-        gU = fmaf(gc, fmaf(p.fv, dxb - dxt, dxt), gU);
-        gV = fmaf(gc, bot - top, gV);
-        if (d_src) {
-          float* ds = d_src + base + (size_t)c * P;
-          const float w00 = (1.f - p.fu) * (1.f - p.fv), w01 = p.fu * (1.f - p.fv);
-          const float w10 = (1.f - p.fu) * p.fv, w11 = p.fu * p.fv;
-          atomicAdd(ds, gc * w00);
-          atomicAdd(ds + 1, gc * w01);
-          atomicAdd(ds + W, gc * w10);
-          atomicAdd(ds + W + 1, gc * w11);
-        }
+    float D[3];
+    load_depth3(depth, n, drows, P, j, D);
+    const RefProj r = ref_project(g, (float)x, (float)y, D, H, W);
+    const PadTap t = pad_taps(r.gx, r.gy, H, W);
+    float gu = 0.f, gv = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float* img = src + ((size_t)n * C + c) * P;
+      const float gc = g_warped[((size_t)n * C + c) * P + j];
+      const float x1 = pad_read(img, t.v0, t.u0, H, W), x2 = pad_read(img, t.v0, t.u0 + 1, H, W);
+      const float x3 = pad_read(img, t.v0 + 1, t.u0, H, W), x4 = pad_read(img, t.v0 + 1, t.u0 + 1, H, W);
+      gu += gc * (-t.wy0 * x1 + t.wy0 * x2 - t.wy1 * x3 + t.wy1 * x4);
+      gv += gc * (-t.wx0 * x1 - t.wx1 * x2 + t.wx0 * x3 + t.wx1 * x4);
+      if (d_src) {
+        float* o = d_src + ((size_t)n * C + c) * P;
+        const int u = t.u0, v = t.v0;   // padded coordinates: taps on the zero frame receive nothing
+        if (u >= 1 && u <= W && v >= 1 && v <= H) atomicAdd(o + (v - 1) * W + (u - 1), gc * t.wx0 * t.wy0);
+        if (u + 1 >= 1 && u + 1 <= W && v >= 1 && v <= H) atomicAdd(o + (v - 1) * W + u, gc * t.wx1 * t.wy0);
+        if (u >= 1 && u <= W && v + 1 >= 1 && v + 1 <= H) atomicAdd(o + v * W + (u - 1), gc * t.wx0 * t.wy1);
+        if (u + 1 >= 1 && u + 1 <= W && v + 1 >= 1 && v + 1 <= H) atomicAdd(o + v * W + u, gc * t.wx1 * t.wy1);
       }
     }
-    const float gq0 = gU * p.rz, gq1 = gV * p.rz;
-    const float gq2 = -(gU * p.U + gV * p.V) * p.rz;
+    // sampler backward to the grid, then p_s_xy *= mask (transform.py:131)
+    const float ggx = t.ok_u ? gu * ((float)(W - 1) * 0.5f) : 0.f;
+    const float ggy = t.ok_v ? gv * ((float)(H - 1) * 0.5f) : 0.f;
+    const float half_w = (float)((double)(W - 1) / 2.0), half_h = (float)((double)(H - 1) / 2.0);
+    const float gU = (ggx * r.mx) / half_w, gV = (ggy * r.my) / half_h;
+    const float gq0 = gU / r.z, gq1 = gV / r.z;
+    const float gq2 = -(gU * r.U + gV * r.V) / r.z;
     // g_c = Pm^T . gq ; g_depthes[j] = g_c[j] * ray[j]   (transform.py:107,122 backward)
-    const float gd0 = (g.P[0] * gq0 + g.P[4] * gq1 + g.P[8] * gq2) * r0;
-    const float gd1 = (g.P[1] * gq0 + g.P[5] * gq1 + g.P[9] * gq2) * r1;
-    const float gd2 = (g.P[2] * gq0 + g.P[6] * gq1 + g.P[10] * gq2) * r2;
+    const float gd0 = ((g.P[0] * gq0 + g.P[4] * gq1) + g.P[8] * gq2) * r.ray[0];
+    const float gd1 = ((g.P[1] * gq0 + g.P[5] * gq1) + g.P[9] * gq2) * r.ray[1];
+    const float gd2 = ((g.P[2] * gq0 + g.P[6] * gq1) + g.P[10] * gq2) * r.ray[2];
     if (drows == 1) {
-      d_depth[(size_t)n * P + j] = gd0 + gd1 + gd2;     // broadcast_to backward: sum of the three rows
+      d_depth[(size_t)n * P + j] = (gd0 + gd1) + gd2;     // broadcast_to backward: sum of the three rows
     } else {
       d_depth[((size_t)n * 3 + 0) * P + j] = gd0;
       d_depth[((size_t)n * 3 + 1) * P + j] = gd1;
       d_depth[((size_t)n * 3 + 2) * P + j] = gd2;
     }
-    acc[0] = gq0 * c0; acc[1] = gq0 * c1; acc[2] = gq0 * c2;  acc[3] = gq0;
-    acc[4] = gq1 * c0; acc[5] = gq1 * c1; acc[6] = gq1 * c2;  acc[7] = gq1;
-    acc[8] = gq2 * c0; acc[9] = gq2 * c1; acc[10] = gq2 * c2; acc[11] = gq2;
+    acc[0] = gq0 * r.c[0]; acc[1] = gq0 * r.c[1]; acc[2] = gq0 * r.c[2];  acc[3] = gq0;
+    acc[4] = gq1 * r.c[0]; acc[5] = gq1 * r.c[1]; acc[6] = gq1 * r.c[2];  acc[7] = gq1;
+    acc[8] = gq2 * r.c[0]; acc[9] = gq2 * r.c[1]; acc[10] = gq2 * r.c[2]; acc[11] = gq2;
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
@@ -244,37 +301,8 @@ __global__ void __launch_bounds__(64) warp_bwd_pose_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------
-// F.spatial_transformer_sampler (call site models/transform.py:189): general semantics on the
-// zero-padded image, for arbitrary grids
+// F.spatial_transformer_sampler kernels (helpers above)
 // ------------------------------------------------------------------------------------------
-struct PadTap {
-  int u0, v0;             // top-left tap in PADDED coordinates, u0 in [0,W], v0 in [0,H]
-  float wx0, wx1, wy0, wy1;
-  bool ok_u, ok_v;        // coordinate inside the padded image (gradient mask)
-};
-
-__device__ __forceinline__ PadTap pad_taps(float gx, float gy, int H, int W) {
-#pragma clang fp contract(off)
-  PadTap t;
-  const float up = (gx + 1.0f) * (float)(W - 1) * 0.5f + 1.0f;
-  const float vp = (gy + 1.0f) * (float)(H - 1) * 0.5f + 1.0f;
-  const float uc = fminf(fmaxf(up, 0.0f), (float)(W + 1));
-  const float vc = fminf(fmaxf(vp, 0.0f), (float)(H + 1));
-  t.u0 = min(max((int)floorf(uc), 0), W);
-  t.v0 = min(max((int)floorf(vc), 0), H);
-  t.wx0 = (float)(t.u0 + 1) - uc;
-  t.wx1 = uc - (float)t.u0;
-  t.wy0 = (float)(t.v0 + 1) - vc;
-  t.wy1 = vc - (float)t.v0;
-  t.ok_u = (up >= 0.0f) && (up <= (float)(W + 1));
-  t.ok_v = (vp >= 0.0f) && (vp <= (float)(H + 1));
-  return t;
-}
-
-__device__ __forceinline__ float pad_read(const float* img, int v, int u, int H, int W) {  // padded coords
-  return (u >= 1 && u <= W && v >= 1 && v <= H) ? img[(v - 1) * W + (u - 1)] : 0.0f;
-}
-
 __global__ void sampler_fwd_kernel(const float* __restrict__ x, const float* __restrict__ grid, float* __restrict__ y, int C,
                                    int H, int W, int oP) {
   const int n = blockIdx.y;

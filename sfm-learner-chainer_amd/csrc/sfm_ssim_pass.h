@@ -389,7 +389,11 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const int r, con
 template <bool GRAD, bool LOSS, bool HWC>
 __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, const bool first, float& acc_pix, float& acc_ssim,
                                                  float* gpm_out /* 12 floats in global memory, or nullptr */ SFM_STAMPS_ARG) {
+#ifdef SFM_ABLATE_HALO   // timing experiment only (wrong values): no halo rows recomputed above / below the chunk
+  constexpr int HS = 0;
+#else
   constexpr int HS = GRAD ? 2 : 1;
+#endif
   const int rbeg = C.y0 - HS, rend = C.y1 + HS;
   const int rload = min(rend, C.h);   // rows below are neither inside the image nor part of this pass: never fetched
   float gpm[9];   // A_k, B_k, C_k of geometry_backward

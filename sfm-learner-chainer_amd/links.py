@@ -25,26 +25,45 @@ class _FusedLossFunction(Function):
     With backprop enabled the forward launch already produces every gradient
     (sfm_loss_fwd_bwd); backward only hands them out, scaled by the upstream gradient."""
 
-    def __init__(self, fused, S, n, with_masks, need_grad):
-        self.fused, self.S, self.n, self.with_masks, self.need_grad = fused, S, n, with_masks, need_grad
+    def __init__(self, fused, S, n, with_masks, need_grad, run=None):
+        self.fused, self.S, self.n, self.with_masks, self.need_grad, self.run = fused, S, n, with_masks, need_grad, run
 
     def forward_gpu(self, inputs):
-        loss5 = self.fused.forward_backward() if self.need_grad else self.fused.forward()
+        if self.run is not None:
+            loss5 = self.run()                 # pyramid + fused launch of this call, replayed from a HIP graph
+        else:
+            loss5 = self.fused.forward_backward() if self.need_grad else self.fused.forward()
         self.loss5 = loss5
         return loss5[0:1].reshape(()),
 
     def backward_gpu(self, inputs, grad_outputs):
         gy = grad_outputs[0]
+        # the seed of ones that Variable.backward() creates itself is not multiplied in (flag valid during that sweep only);
+        # any gradient the caller has set on the loss (e.g. a loss scale) is
         unit = getattr(self._outputs[0], "_unit_grad", False)
         f = self.fused
         grads = list(f.d_disps) + list(f.d_poses) + (list(f.d_masks) if self.with_masks else [])
         return tuple(g if unit else g * gy for g in grads)
 
 
-class SFMLearnerLoss:
-    """Sfm Learner loss: multi-scale photometric (+SSIM) + smoothness + explainability."""
+class _Cached:
+    """What one link keeps between calls for one set of shapes."""
+    __slots__ = ("fused", "pyr", "graph", "graph_key", "graph_stream", "calls")
 
-    def __init__(self, config, pretrained_model=None, smooth_mode="second_order"):
+
+class SFMLearnerLoss:
+    """Sfm Learner loss: multi-scale photometric (+SSIM) + smoothness + explainability.
+
+    cache_buffers (default True): the image pyramids, the workspace and the gradient arrays are allocated once per set
+      of input shapes and reused by every later call (only the input pointers are re-bound).  The arrays that
+      `loss.backward()` hands to `x.grad` are therefore owned by the link and are overwritten by its next call with the same
+      shapes -- the cleargrads() / forward / backward / update cycle of the reference's trainer (a caller that keeps
+      gradients across iterations copies them, or passes cache_buffers=False).
+    use_graph (default False): when a call repeats the previous call's arrays exactly (same addresses: static input buffers),
+      the pyramid launch and the three launches of the loss are replayed from one HIP graph.
+    """
+
+    def __init__(self, config, pretrained_model=None, smooth_mode="second_order", cache_buffers=True, use_graph=False):
         # models/base_model.py:34-39
         self.n_sources = config['seq_len'] - 1
         self.smooth_reg = config['smooth_reg']
@@ -53,6 +72,29 @@ class SFMLearnerLoss:
         # base_model.py:75-80: the second-order form is live, the edge-aware one is commented out there
         self.smooth_mode = smooth_mode
         self.xp = torch
+        self.cache_buffers = cache_buffers
+        self.use_graph = use_graph
+        self._cache = {}
+
+    def _state(self, tgt, stacked, intrinsics, disps, poses, masks, norm_batch):
+        """The bound FusedLoss + pyramid buffers for these shapes (built on first use)."""
+        key = (tgt.device, tuple(tgt.shape), tuple(stacked.shape), tuple(intrinsics.shape), tuple(tuple(a.shape) for a in disps),
+               masks is not None, norm_batch)
+        st = self._cache.get(key) if self.cache_buffers else None
+        if st is None:
+            st = _Cached()
+            st.pyr = ops.pyramid_pair_hwc(tgt, stacked, len(disps))
+            st.fused = ops.FusedLoss(smooth_reg=self.smooth_reg or 0.0, exp_reg=self.exp_reg or 0.0,
+                                     ssim_rate=self.ssim_rate or 0.0, smooth_mode=self.smooth_mode)
+            st.fused.bind(st.pyr[0], st.pyr[1], intrinsics, disps, poses, masks, norm_B=norm_batch, layout="hwc")
+            st.graph = st.graph_key = st.graph_stream = None
+            st.calls = 0
+            if self.cache_buffers:
+                self._cache.clear()            # one set of shapes at a time: a training loop has one
+                self._cache[key] = st
+            return st, True
+        st.fused.rebind(intrinsics, disps, poses, masks)
+        return st, False
 
     def __call__(self, tgt_img, src_imgs, intrinsics, inv_intrinsics, pred_disps, pred_poses, pred_maskes=None,
                  norm_batch=None):
@@ -69,25 +111,30 @@ class SFMLearnerLoss:
            Return:
                loss (Variable).
         """
-        tgt = as_array(tgt_img)
+        tgt = ops._dev(as_array(tgt_img), "tgt_img", 4)
         src = as_array(src_imgs)
         batchsize, n_sources, _, H, W = src.shape                              # :57
-        stacked_src_imgs = src.reshape(batchsize, -1, H, W)                    # :58
+        stacked_src_imgs = ops._dev(src.reshape(batchsize, -1, H, W), "src_imgs", 4)   # :58
         n_scales = len(pred_disps)                                             # :66
         do_exp = self.exp_reg is not None and self.exp_reg > 0                 # :61
         if n_sources != len(pred_poses):
             raise TypeError("src_imgs has %d sources but %d poses were given" % (n_sources, len(pred_poses)))
-        # :69-72 -- curr_tgt_img / curr_src_imgs of every scale, ONE launch for both tensors, written pixel-interleaved
-        # (the layout the fused loss kernels fetch with the fewest loads; values identical to the planar pyramid)
-        tgt_pyr, src_pyr = ops.pyramid_pair_hwc(tgt, stacked_src_imgs, n_scales)
-        fused = ops.FusedLoss(smooth_reg=self.smooth_reg or 0.0, exp_reg=self.exp_reg or 0.0,
-                              ssim_rate=self.ssim_rate or 0.0, smooth_mode=self.smooth_mode)
-        fused.bind(tgt_pyr, src_pyr, as_array(intrinsics), [as_array(d) for d in pred_disps],
-                   [as_array(p) for p in pred_poses],
-                   [as_array(m) for m in pred_maskes] if do_exp else None, norm_B=norm_batch, layout="hwc")
+        K = as_array(intrinsics)
+        disps = [as_array(d) for d in pred_disps]
+        poses = [as_array(p) for p in pred_poses]
+        masks = [as_array(m) for m in pred_maskes] if do_exp else None
         inputs = list(pred_disps) + list(pred_poses) + (list(pred_maskes) if do_exp else [])
         need_grad = config.enable_backprop and any(isinstance(v, Variable) and v.requires_grad for v in inputs)
-        node = _FusedLossFunction(fused, n_scales, n_sources, do_exp, need_grad)
+        st, fresh = self._state(tgt, stacked_src_imgs, K, disps, poses, masks, norm_batch)
+        fused = st.fused
+        run = None
+        if self.use_graph and self.cache_buffers:
+            run = self._graph_step(st, tgt, stacked_src_imgs, n_scales, need_grad, fresh)
+        if run is None and not fresh:
+            # :69-72 -- curr_tgt_img / curr_src_imgs of every scale, ONE launch for both tensors, written pixel-interleaved
+            # (the layout the fused loss kernels fetch with the fewest loads; values identical to the planar pyramid)
+            ops.pyramid_pair_hwc(tgt, stacked_src_imgs, n_scales, out=st.pyr)
+        node = _FusedLossFunction(fused, n_scales, n_sources, do_exp, need_grad, run)
         total_loss = node(*inputs)
         l5 = node.loss5
         report({'total_loss': l5[0]}, self)                                    # :119-123
@@ -96,3 +143,25 @@ class SFMLearnerLoss:
         report({'exp_loss': l5[3]}, self)
         report({'ssim_loss': l5[4]}, self)
         return total_loss
+
+    def _graph_step(self, st, tgt, stacked, n_scales, need_grad, fresh):
+        """Returns a callable that replays [pyramid, fused loss] of THIS call from a HIP graph, or None (run eagerly).
+        The graph is captured on the second call that repeats the same addresses and is dropped when they change."""
+        f = st.fused
+        key = (tgt.data_ptr(), stacked.data_ptr(), need_grad, bytes(f.desc))
+        if st.graph is not None and st.graph_key == key:
+            g = st.graph
+            return lambda: (g.replay(), f.loss5)[1]
+        st.graph = None
+        if fresh or st.graph_key != key:
+            st.graph_key = key             # first sighting of these addresses: run eagerly, capture next time
+            return None
+        side = torch.cuda.Stream(device=tgt.device)
+        side.wait_stream(torch.cuda.current_stream(tgt.device))
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            ops.pyramid_pair_hwc(tgt, stacked, n_scales, out=st.pyr)
+            f.forward_backward() if need_grad else f.forward()
+        torch.cuda.current_stream(tgt.device).wait_stream(side)
+        st.graph = g
+        return lambda: (g.replay(), f.loss5)[1]

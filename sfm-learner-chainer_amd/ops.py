@@ -33,8 +33,15 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _stream(index=None):
+    """The HIP stream torch currently issues work on for that device, as a raw handle.  (The private accessor
+    skips the construction of a torch.cuda.Stream object: it is what torch's own launchers use per call.)"""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device() if index is None else index))
+    return C.c_void_p(torch.cuda.current_stream(index).cuda_stream)
 
 
 def pose_proj_fwd(pose6, K):
@@ -185,9 +192,10 @@ def pyramid_hwc(x, n_scales):
     return outs
 
 
-def pyramid_pair_hwc(tgt, src, n_scales):
+def pyramid_pair_hwc(tgt, src, n_scales, out=None):
     """Both pixel-interleaved pyramids of a step in one launch: tgt (N,3,H,W), src (N,3*n_src,H,W) ->
-    ([tgt_s (N,1,h,w,3)], [src_s (N,n_src,h,w,3)]) -- the loop head models/base_model.py:69-72."""
+    ([tgt_s (N,1,h,w,3)], [src_s (N,n_src,h,w,3)]) -- the loop head models/base_model.py:69-72.
+    `out` = (yt, ys) of an earlier call with the same shapes: written in place instead of allocating."""
     tgt, src = _dev(tgt, "tgt", 4), _dev(src, "src", 4)
     N, Ct, H, W = tgt.shape
     if Ct != 3 or src.shape[0] != N or tuple(src.shape[2:]) != (H, W) or src.shape[1] % 3 != 0 or src.shape[1] == 0:
@@ -195,8 +203,13 @@ def pyramid_pair_hwc(tgt, src, n_scales):
     if not 1 <= n_scales <= _lib.SFM_MAX_SCALES:
         raise TypeError("n_scales must be in [1, %d]" % _lib.SFM_MAX_SCALES)
     n_src = src.shape[1] // 3
-    yt = [torch.empty((N, 1, H >> s, W >> s, 3), dtype=torch.float32, device=tgt.device) for s in range(n_scales)]
-    ys = [torch.empty((N, n_src, H >> s, W >> s, 3), dtype=torch.float32, device=tgt.device) for s in range(n_scales)]
+    if out is not None:
+        yt, ys = out
+        if len(yt) != n_scales or tuple(yt[0].shape) != (N, 1, H, W, 3) or tuple(ys[0].shape) != (N, n_src, H, W, 3):
+            raise TypeError("pyramid_pair_hwc: `out` does not match the inputs")
+    else:
+        yt = [torch.empty((N, 1, H >> s, W >> s, 3), dtype=torch.float32, device=tgt.device) for s in range(n_scales)]
+        ys = [torch.empty((N, n_src, H >> s, W >> s, 3), dtype=torch.float32, device=tgt.device) for s in range(n_scales)]
     with torch.cuda.device(tgt.device):
         check(lib.sfm_pyramid_pair_hwc_fwd(_p(tgt), _p(src), _ptr_array(yt), _ptr_array(ys), N, n_src, H, W, n_scales, _stream()))
     return yt, ys
@@ -320,9 +333,40 @@ class FusedLoss:
         self._ws_bytes = nbytes
         self.loss5 = torch.zeros((5,), dtype=torch.float32, device=dev)
         self.desc, self.device = d, dev
+        self._desc_ref, self._ws_arg, self._loss5_arg = C.byref(d), C.c_void_p(self._ws_ptr), _p(self.loss5)
         self.d_disps, self.d_poses, self.d_masks, self.d_srcs = d_disps, d_poses, (d_masks if use_masks else None), \
             (d_srcs if want_d_src else None)
         self._keep = (tgt_pyr, src_pyr, intrinsics, disps, poses, masks)
+        return self
+
+    def rebind(self, intrinsics, disps, poses, masks=None):
+        """Points the bound descriptor at other input arrays of the SAME shapes (the network outputs of the next
+        iteration); pyramids, workspace and gradient buffers stay.  Only pointers change: the plan cached inside the
+        library for this descriptor shape is found again as long as the addresses repeat."""
+        d = self.desc
+        old = self._keep
+        intrinsics = _dev(intrinsics, "intrinsics", 4)
+        disps = [_dev(t, "disps[%d]" % s, 4) for s, t in enumerate(disps)]
+        poses = [_dev(t, "poses[%d]" % i, 2) for i, t in enumerate(poses)]
+        if intrinsics.shape != old[2].shape or len(disps) != len(old[3]) or len(poses) != len(old[4]) \
+                or any(a.shape != b.shape for a, b in zip(disps, old[3])) or any(a.shape != b.shape for a, b in zip(poses, old[4])):
+            raise TypeError("rebind: shapes differ from the bound ones (call bind)")
+        if self.exp_reg > 0:
+            if masks is None:
+                raise ValueError("exp_reg > 0 needs the explainability logits (masks)")
+            masks = [_dev(t, "masks[%d]" % s, 4) for s, t in enumerate(masks)]
+            if any(a.shape != b.shape for a, b in zip(masks, old[5])):
+                raise TypeError("rebind: mask shapes differ from the bound ones (call bind)")
+            for s, t in enumerate(masks):
+                d.mask_logits[s] = t.data_ptr()
+        else:
+            masks = None
+        d.intrinsics = intrinsics.data_ptr()
+        for s, t in enumerate(disps):
+            d.disp[s] = t.data_ptr()
+        for i, t in enumerate(poses):
+            d.pose[i] = t.data_ptr()
+        self._keep = (old[0], old[1], intrinsics, disps, poses, masks)
         return self
 
     def _zero_d_src(self):
@@ -330,17 +374,25 @@ class FusedLoss:
             for t in self.d_srcs:
                 t.zero_()
 
+    def _launch(self, fn, *mid):
+        """One call through the C ABI on the device's current stream.  The argument objects that never change between
+        calls are built once per bind (a step is 70 us of GPU time: the host side of a call has to stay well below)."""
+        idx = self.device.index
+        if torch.cuda.current_device() == idx:
+            check(fn(self._desc_ref, *mid, self._ws_arg, self._ws_bytes, _stream(idx)))
+        else:
+            with torch.cuda.device(self.device):
+                check(fn(self._desc_ref, *mid, self._ws_arg, self._ws_bytes, _stream(idx)))
+
     def forward(self, out=None):
         """`out`: as for forward_backward."""
         loss5 = self.loss5 if out is None else out
-        with torch.cuda.device(self.device):
-            check(lib.sfm_loss_fwd(C.byref(self.desc), _p(loss5), C.c_void_p(self._ws_ptr), self._ws_bytes, _stream()))
+        self._launch(lib.sfm_loss_fwd, self._loss5_arg if out is None else _p(out))
         return loss5
 
     def backward(self, gy=1.0):
         self._zero_d_src()
-        with torch.cuda.device(self.device):
-            check(lib.sfm_loss_bwd(C.byref(self.desc), float(gy), C.c_void_p(self._ws_ptr), self._ws_bytes, _stream()))
+        self._launch(lib.sfm_loss_bwd, float(gy))
         return self.d_disps, self.d_poses, self.d_masks, self.d_srcs
 
     def forward_backward(self, out=None):
@@ -348,6 +400,5 @@ class FusedLoss:
         (lets a caller keep a log of the steps of a reporting interval and reduce it across ranks once)."""
         self._zero_d_src()
         loss5 = self.loss5 if out is None else out
-        with torch.cuda.device(self.device):
-            check(lib.sfm_loss_fwd_bwd(C.byref(self.desc), _p(loss5), C.c_void_p(self._ws_ptr), self._ws_bytes, _stream()))
+        self._launch(lib.sfm_loss_fwd_bwd, self._loss5_arg if out is None else _p(out))
         return loss5

@@ -34,3 +34,23 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
     return torch.device("cuda:0")
+
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """Prints what the tolerance-based tests actually measured (util.parity_note) and, on the GPU box, writes it to
+    gpurun_out/parity_stats.txt so that the evidence travels back."""
+    import util
+    notes = util.PARITY_NOTES
+    if not notes:
+        return
+    terminalreporter.section("parity statistics (%d notes; worst cases in gpurun_out/parity_stats.txt)" % len(notes))
+    for line in notes[-25:]:
+        terminalreporter.write_line(line)
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_stats.txt"), "w") as f:
+            f.write("\n".join(notes) + "\n")
+    except OSError:
+        pass

@@ -89,7 +89,7 @@ def test_sfm_learner_loss_link(synth, dev, config):
                      keep_warped=True, **cfg)
     assert isinstance(loss, cs.Variable) and loss.shape == ()
     assert abs(float(loss.data) - ref.total_loss) <= 1e-4 * abs(ref.total_loss)
-    rep = cs.get_report()
+    rep = cs.get_report(link)      # scoped by the observer that reported (the link), as chainer.report's observer argument
     for k in ("total_loss", "pixel_loss", "smooth_loss", "exp_loss", "ssim_loss"):     # :119-123
         assert abs(float(rep[k]) - ref[k]) <= 1e-4 * max(abs(ref[k]), 1e-6), k
     loss.backward()
@@ -126,6 +126,70 @@ def test_loss_link_without_backprop_and_with_upstream_gradient(synth, dev):
     l2.grad = torch.full((), 3.0, device=dev)            # e.g. a loss scale
     l2.backward()
     np.testing.assert_allclose(to_np(disps2[0].grad), 3.0 * g1, rtol=1e-6, atol=1e-12)
+
+
+def test_loss_link_reuses_its_buffers_across_calls(synth, dev):
+    """The drop-in path of a training loop: consecutive calls of one link with the same shapes reuse the pyramids, the
+    workspace and the gradient arrays (no allocation, the library's plan cache is hit) and give identical results; new
+    frames / network outputs of the same shapes are picked up; a loss scale set by the caller is applied on every backward;
+    two links keep separate reports; the HIP-graph replay gives the eager results bit for bit."""
+    import torch
+    d = synth.make_inputs(B=2, H=32, W=104, n_src=2, n_scales=3, seed=6)
+    d2 = synth.make_inputs(B=2, H=32, W=104, n_src=2, n_scales=3, seed=7)
+    cfgd = {"smooth_reg": 0.1, "exp_reg": 0, "seq_len": 3, "ssim_rate": 0.15}
+    ref = [O.sfm_loss(x["tgt_pyr"], x["src_pyr"], x["intrinsics"], x["disps"], x["poses"], backward=True, smooth_reg=0.1, ssim_rate=0.15) for x in (d, d2)]
+
+    def run(link, x, scale=None):
+        disps = [cs.Variable(to_dev(a, dev)) for a in x["disps"]]
+        poses = [cs.Variable(to_dev(a, dev)) for a in x["poses"]]
+        K = to_dev(x["intrinsics"], dev)
+        loss = link(to_dev(x["tgt"], dev), to_dev(x["src"], dev), K, K, disps, poses)
+        if scale is not None:
+            loss.grad = torch.full((), scale, device=dev)
+        loss.backward()
+        return float(loss.data), [to_np(v.grad).copy() for v in disps + poses], [v.grad.data_ptr() for v in disps + poses]
+
+    link = links.SFMLearnerLoss(cfgd)
+    l_a, g_a, p_a = run(link, d)
+    st_a = next(iter(link._cache.values()))
+    l_b, g_b, p_b = run(link, d)                        # the same values again
+    assert next(iter(link._cache.values())) is st_a and p_a == p_b       # same FusedLoss, same gradient arrays handed out
+    assert l_a == l_b
+    for x, y in zip(g_a, g_b):
+        np.testing.assert_array_equal(x, y)
+    assert abs(l_a - ref[0].total_loss) <= 1e-4 * abs(ref[0].total_loss)
+    l_c, g_c, _ = run(link, d2)                         # other frames and network outputs, same shapes: buffers reused, values new
+    assert next(iter(link._cache.values())) is st_a
+    assert abs(l_c - ref[1].total_loss) <= 1e-4 * abs(ref[1].total_loss)
+    np.testing.assert_allclose(g_c[-1], ref[1].d_poses[-1], rtol=0, atol=2e-3 * np.abs(ref[1].d_poses[-1]).max())
+    l_d, g_d, _ = run(link, d, scale=3.0)               # a gradient set by the caller is multiplied in ...
+    for x, y in zip(g_a, g_d):
+        np.testing.assert_allclose(y, 3.0 * x, rtol=1e-6, atol=1e-12)
+    l_e, g_e, _ = run(link, d)                          # ... and does not stick to the next call
+    for x, y in zip(g_a, g_e):
+        np.testing.assert_array_equal(x, y)
+    other = links.SFMLearnerLoss(cfgd, cache_buffers=False)
+    l_f, g_f, p_f = run(other, d2)
+    assert l_f == l_c and not other._cache
+    assert cs.get_report(other)["total_loss"] is not cs.get_report(link)["total_loss"]
+    assert abs(float(cs.get_report(link)["total_loss"]) - l_e) == 0 and abs(float(cs.get_report(other)["total_loss"]) - l_f) == 0
+    # HIP-graph replay: static input arrays, as a caller with pre-allocated batch buffers has them
+    glink = links.SFMLearnerLoss(cfgd, use_graph=True)
+    disps = [cs.Variable(to_dev(a, dev)) for a in d["disps"]]
+    poses = [cs.Variable(to_dev(a, dev)) for a in d["poses"]]
+    K, tgt, src = to_dev(d["intrinsics"], dev), to_dev(d["tgt"], dev), to_dev(d["src"], dev)
+    for it in range(4):          # 1st call binds, 2nd sees the addresses again and captures, 3rd and 4th replay
+        for v in disps + poses:
+            v.cleargrad()
+        loss = glink(tgt, src, K, K, disps, poses)
+        loss.backward()
+        assert float(loss.data) == l_a, it
+        for x, v in zip(g_a, disps + poses):
+            np.testing.assert_array_equal(x, to_np(v.grad))
+    assert next(iter(glink._cache.values())).graph is not None
+    tgt.copy_(to_dev(d2["tgt"], dev))                   # new pixels in the SAME arrays: the replayed pyramid launch picks them up
+    loss = glink(tgt, src, K, K, disps, poses)
+    assert float(loss.data) != l_a
 
 
 def test_disp_activation_all_scales_in_one_launch(dev):

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import sfm_oracle as O
-from test_loss_gpu import CONFIGS, KEYS, _bind, _check_grads, _check_losses, _oracle
+from test_loss_gpu import CONFIGS, _bind, _check_grads, _check_losses, _oracle
 from util import to_np
 
 pytestmark = pytest.mark.gpu
@@ -110,72 +110,49 @@ def test_high_resolution_config5_shape(ops, synth, dev):
 
 
 def _random_cases(n, seed=2024):
+    """Ragged shapes (odd sizes, partial strips and chunks), batch sizes on both sides of the XCD-striping threshold, every
+    source count and loss mode.  The smallest scale keeps at least 12 x 24 pixels: below that a single knife-edge pixel is
+    percents of every quantity compared and the comparison says nothing (the degenerate sizes are covered, with the plain
+    criteria, by test_shapes_at_the_boundaries)."""
     rng = np.random.RandomState(seed)
     cases = []
     names = sorted(CONFIGS)
     for k in range(n):
         n_scales = int(rng.randint(1, 4))
-        H = int(rng.randint(3 << (n_scales - 1), 80))
-        W = int(rng.randint(3 << (n_scales - 1), 200))
+        H = int(rng.randint(12 << (n_scales - 1), 97))
+        W = int(rng.randint(24 << (n_scales - 1), 201))
         cases.append((int(rng.randint(1, 11)), H, W, int(rng.randint(1, 5)), n_scales, names[int(rng.randint(len(names)))], int(rng.randint(1 << 30))))
     return cases
 
 
-# SFM_SWEEP_N widens the sweep for a soak run (round 1: 3000 cases, all green)
+# SFM_SWEEP_N widens the sweep for a soak run
 @pytest.mark.parametrize("B,H,W,n_src,n_scales,cfg_name,seed", _random_cases(int(os.environ.get("SFM_SWEEP_N", "16"))))
 def test_random_shapes_and_modes(ops, synth, dev, B, H, W, n_src, n_scales, cfg_name, seed):
-    """a seeded sweep over ragged shapes (odd sizes, partial strips and chunks), batch sizes on both sides of the
-    XCD-striping threshold, source counts and every loss mode"""
+    """A seeded sweep; every case is judged by the SAME criteria as the fixed-shape tests (_check_losses, _check_grads: loss
+    1e-4, gradients 2e-3 element-wise + relative L2, knife share capped).  A pixel on the strict `-1 < x < 1` test of
+    transform.py:129 may be sampled in one fp32 evaluation and exactly 0 in the other; it can move the loss by at most
+    (6 + 3) / (3 B h w).  Inputs where such pixels could move the loss by more than a fifth of its tolerance (small images
+    only), or whose knife-edge pixels exceed the cap, are re-drawn with the next seed -- counted and reported."""
+    from test_loss_gpu import knife_cap
+    from util import dilate, parity_note
     cfg = CONFIGS[cfg_name]
-    d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=n_scales, seed=seed % 10000, with_masks=True)
-    ref = _oracle(d, cfg)
-    fl = _bind(ops, dev, d, cfg, layout="hwc" if seed % 2 else "planar")     # both image layouts take part in the sweep
-    # Pixels on the strict `-1 < x < 1` test of transform.py:129 may be sampled in one fp32 evaluation and exactly 0 in
-    # the other.  In the small images of this sweep ONE such pixel is visible in the loss (11x15 px, B=2: 1/990 of the
-    # mean) and in its sample's pose gradient (58x25: 2.4 % of a translation component), so the sweep counts them and
-    # allows for what they can move: <= 6 in sum_c |e_c| plus <= 3 in the SSIM term per pixel, over B*3*h*w.
-    flips = [(ref["margin"][s_] < 2e-5) for s_ in range(n_scales)]
-    slack = sum(float(f.sum()) * 3.0 / (B * f.shape[-2] * f.shape[-1]) for f in flips)
-
-    def check_losses(loss5):
-        got = to_np(loss5)
-        for k, name in enumerate(KEYS):
-            want = ref[name]
-            assert abs(got[k] - want) <= 1e-4 * max(abs(want), 1e-6) + slack, (name, got[k], want, slack)
-
-    check_losses(fl.forward())
-    check_losses(fl.forward_backward())
-    try:
-        _check_grads(fl, ref, n_src, check_mask=bool(cfg.get("exp_reg")))
-    except AssertionError:
-        # Second opinion from the fp64 oracle.  (a) A pixel whose gradient is ill-conditioned in fp32 (far points:
-        # d_disp = -gD / disp^2 amplifies the rounding of the sampling coordinates) exceeds the flat tolerance in BOTH
-        # fp32 evaluations: the kernel may be off by the flat tolerance or three times the fp32 oracle's own error.
-        # (b) Knife-edge pixels are excluded from the element-wise comparisons of d_disp and d_mask, and the samples
-        # that contain a flipped pixel from the comparison of d_pose.  (3000-case run, SFM_SWEEP_N=3000: 1 % of the
-        # cases come here; every one of them is one of these two situations.)
-        from test_loss_gpu import GRAD_TOL, _knife
-        ref64 = O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], d["masks"], backward=True,
-                           dtype=np.float64, **cfg)
-
-        def judged(g, w32, w64, knife, what, flat=GRAD_TOL):
-            g = to_np(g).astype(np.float64)
-            tol = np.maximum(flat * np.abs(w64).max(), 3.0 * np.abs(w32 - w64))
-            bad = np.abs(g - w64) > tol
-            if knife is not None:
-                bad &= ~np.broadcast_to(knife, g.shape)
-            assert not bad.any(), (what, int(bad.sum()))
-
+    for attempt in range(8):
+        d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=n_scales, seed=(seed + attempt) % 10000, with_masks=True)
+        ref = _oracle(d, cfg)
+        flips = sum(int((ref["margin"][s_] < 2e-5).sum()) for s_ in range(n_scales))
+        flip_reach = sum(float((ref["margin"][s_] < 2e-5).sum()) * 3.0 / (B * ref["margin"][s_].shape[-2] * ref["margin"][s_].shape[-1])
+                         for s_ in range(n_scales))
+        over = False
         for s_ in range(n_scales):
-            knife = _knife(ref, s_, n_src)
-            judged(fl.d_disps[s_], ref["d_disps"][s_], ref64["d_disps"][s_], knife, "d_disp[%d]" % s_)
-            if cfg.get("exp_reg"):
-                judged(fl.d_masks[s_], ref["d_masks"][s_], ref64["d_masks"][s_], knife, "d_mask[%d]" % s_)
-        flipped = np.zeros(B, bool)
-        for f in flips:
-            flipped |= f.reshape(B, -1).any(axis=1)
-        # the other knife-edge classes (bilinear cell boundaries, kinks of |.| and of the SSIM clip) move single pixels'
-        # gradients too: a pose gradient of a small image is granted a few pixels' worth, 64 / (H W) of its maximum
-        for i in range(n_src):
-            judged(fl.d_poses[i], ref["d_poses"][i], ref64["d_poses"][i], flipped[:, None], "d_pose[%d]" % i,
-                   flat=max(GRAD_TOL, 64.0 / (H * W)))
+            m = dilate((ref["clip_margin"][s_] < 5e-5).any(axis=1), 1) | (ref["cell_margin"][s_] < 1e-4).any(axis=1) | (ref["abs_margin"][s_] < 3e-5).any(axis=1)
+            over |= m.mean() > 0.8 * knife_cap(m.size)
+        if flip_reach <= 2e-5 and not over:
+            break
+    else:
+        pytest.fail("no admissible input in 8 draws")
+    parity_note("sweep case B=%d %dx%d n_src=%d scales=%d %s: input re-drawn %d times; %d pixels on the (-1,1) test, reach %.1e of the loss" % (
+        B, H, W, n_src, n_scales, cfg_name, attempt, flips, flip_reach))
+    fl = _bind(ops, dev, d, cfg, layout="hwc" if seed % 2 else "planar")     # both image layouts take part in the sweep
+    _check_losses(fl.forward(), ref)
+    _check_losses(fl.forward_backward(), ref)
+    _check_grads(fl, ref, n_src, check_mask=bool(cfg.get("exp_reg")), what="sweep %s %dx%d" % (cfg_name, H, W))

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from oracle import sfm_oracle as O
-from util import assert_close_masked, dilate, to_dev, to_np
+from util import assert_close_masked, dilate, parity_note, to_dev, to_np
 
 pytestmark = pytest.mark.gpu
 
@@ -44,7 +44,17 @@ def _check_losses(loss5, ref):
         assert abs(got[k] - want) <= LOSS_RTOL * max(abs(want), 1e-6), (name, got[k], want)
 
 
-def _knife(ref, s, n_src, thr=2e-5, cell_thr=3e-4, abs_thr=5e-5, clip_thr=1e-4):
+KNIFE_CAP_LARGE, KNIFE_CAP_SMALL, KNIFE_SMALL_PX = 0.01, 0.05, 20000
+L2_TOL = 1e-4      # relative L2 error of a gradient array outside knife pixels (next to the element-wise max criterion)
+
+
+def knife_cap(n_px):
+    """Largest share of a scale's pixels that may be excluded from ELEMENT-WISE gradient comparisons: 1 % at image sizes of
+    the BASELINE configs; 5 % for the small images of the shape tests, where a handful of dilated pixels is already percents."""
+    return KNIFE_CAP_LARGE if n_px >= KNIFE_SMALL_PX else KNIFE_CAP_SMALL
+
+
+def _knife(ref, s, n_src, thr=2e-5, cell_thr=1e-4, abs_thr=3e-5, clip_thr=5e-5, what=""):
     """Pixels of scale s where the reference's function itself is discontinuous in (disp, pose), so that two
     fp32 evaluations of it may legitimately land on different sides; excluded from ELEMENT-WISE gradient
     comparisons (never from the loss comparison), each class with the footprint it can influence:
@@ -54,25 +64,41 @@ def _knife(ref, s, n_src, thr=2e-5, cell_thr=3e-4, abs_thr=5e-5, clip_thr=1e-4):
         partials of that window switch on/off -> 3x3 footprint;
       * the sample within `cell_thr` px of a cell boundary of the bilinear lattice (dI^/du jumps) and
         0 < |I^ - I| < `abs_thr` (kink of F.absolute, models/base_model.py:95): the pixel itself.
-    The excluded share is asserted to stay small, so the exclusion cannot hide a real error."""
+    The excluded share is reported (parity_note) and asserted to stay below knife_cap, so the exclusion cannot hide a
+    real error."""
     flip = (ref["margin"][s] < thr).any(axis=1)
     clip = (ref["clip_margin"][s] < clip_thr).any(axis=1)
     own = (ref["cell_margin"][s] < cell_thr).any(axis=1) | (ref["abs_margin"][s] < abs_thr).any(axis=1)
     m = dilate(flip, 2) | dilate(clip, 1) | own
-    # (images of a few hundred pixels: a handful of dilated knife-edge pixels is a large share of the image)
-    assert m.mean() <= max(0.03 * n_src, 120.0 / m[0].size), "too many knife-edge pixels (%g): the exclusion would hide real errors" % m.mean()
+    share, cap = float(m.mean()), knife_cap(m.size)
+    parity_note("knife %s scale %d (%d px, %d src): excluded %.3f%% (cap %.0f%%): %d flip, %d clip, %d cell/abs pixels" % (
+        what, s, m.size, n_src, 100 * share, 100 * cap, int(flip.sum()), int(clip.sum()), int(own.sum())))
+    assert share <= cap, "too many knife-edge pixels (%.3f%% > %.0f%%): the exclusion would hide real errors" % (100 * share, 100 * cap)
     return m[:, None]                                 # (B,1,h,w)
 
 
-def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=True):
+def rel_l2(got, want, knife=None):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    keep = np.ones(got.shape, bool) if knife is None else ~np.broadcast_to(knife, got.shape)
+    return float(np.sqrt((((got - want) * keep) ** 2).sum()) / max(np.sqrt(((want * keep) ** 2).sum()), 1e-30))
+
+
+def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=True, what=""):
+    worst = 0.0
     for s, (g, w) in enumerate(zip(fl.d_disps, ref["d_disps"])):
-        assert_close_masked(to_np(g), w, GRAD_TOL, _knife(ref, s, n_src), what="d_disp[%d]" % s)
+        knife = _knife(ref, s, n_src, what=what)
+        assert_close_masked(to_np(g), w, GRAD_TOL, knife, what="d_disp[%d]" % s)
+        l2 = rel_l2(to_np(g), w, knife)
+        worst = max(worst, l2)
+        assert l2 <= L2_TOL, ("d_disp[%d]: relative L2 error %.2e outside knife pixels" % (s, l2))
+        if check_mask:
+            assert_close_masked(to_np(fl.d_masks[s]), ref["d_masks"][s], GRAD_TOL, what="d_mask[%d]" % s)
+            l2m = rel_l2(to_np(fl.d_masks[s]), ref["d_masks"][s])
+            assert l2m <= L2_TOL, ("d_mask[%d]: relative L2 error %.2e" % (s, l2m))
     for i, (g, w) in enumerate(zip(fl.d_poses, ref["d_poses"]) if check_pose else ()):
         # a flipped knife-edge pixel moves a pose gradient by ~1/(#pixels): covered by the tolerance
         assert_close_masked(to_np(g), w, GRAD_TOL, what="d_pose[%d]" % i)
-    if check_mask:
-        for s, (g, w) in enumerate(zip(fl.d_masks, ref["d_masks"])):
-            assert_close_masked(to_np(g), w, GRAD_TOL, what="d_mask[%d]" % s)
+    parity_note("grads %s: worst relative L2 of d_disp outside knife pixels %.2e (tol %.0e)" % (what, worst, L2_TOL))
     if check_src:
         for s, (g, w) in enumerate(zip(fl.d_srcs, ref["d_srcs"])):
             # scatter targets of knife-edge pixels: compare in aggregate
@@ -177,26 +203,41 @@ def test_batch_shard_is_additive(ops, synth, dev):
     np.testing.assert_allclose(tot, lf, rtol=1e-5)
 
 
-@pytest.mark.parametrize("cfg_name,B,H,W,n_src", [("l1_smooth", 8, 128, 416, 2), ("ssim_smooth", 4, 128, 416, 2)])
-def test_baseline_configs_vs_oracle(ops, synth, dev, cfg_name, B, H, W, n_src):
-    """BASELINE.json cfg2 (B=8, L1 + smoothness) and cfg3's loss mode at a batch the oracle
-    finishes in seconds, full 128x416 resolution, 4 scales."""
+@pytest.mark.parametrize("cfg_name,B,H,W,n_src,n_scales", [
+    ("l1", 1, 128, 416, 2, 1),             # BASELINE cfg1: the CPU reference's own case (1 snippet, 1 scale, L1 only), on the HIP path
+    ("l1_smooth", 8, 128, 416, 2, 4),      # BASELINE cfg2 at full size
+    ("ssim_smooth", 4, 128, 416, 2, 4),    # cfg3's live loss mode (2nd-order smoothness), full resolution, oracle-sized batch
+    ("edge_aware", 4, 128, 416, 2, 4),     # BASELINE cfg3 AS WRITTEN: L1 + SSIM + EDGE-AWARE smoothness (base_model.py:144-155)
+])
+@pytest.mark.parametrize("layout", ["planar", "hwc"])
+def test_baseline_configs_vs_oracle(ops, synth, dev, cfg_name, B, H, W, n_src, n_scales, layout):
+    """BASELINE.json configs at full 128x416 resolution against the oracle, at batches the oracle finishes in seconds."""
     cfg = CONFIGS[cfg_name]
-    d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=4, seed=1)
+    d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=n_scales, seed=1)
     ref = _oracle(d, cfg)
-    fl = _bind(ops, dev, d, cfg)
+    fl = _bind(ops, dev, d, cfg, layout=layout)
     _check_losses(fl.forward(), ref)
     _check_losses(fl.forward_backward(), ref)
-    _check_grads(fl, ref, n_src)
+    _check_grads(fl, ref, n_src, what="%s B=%d %dx%d %s" % (cfg_name, B, H, W, layout))
 
 
-def test_full_size_properties(ops, synth, dev):
-    """cfg3 at full size (B=32): size-independent properties instead of an oracle run --
-    determinism (bitwise), fused == separate, finite outputs, and loss(identical images) == 0."""
+@pytest.mark.parametrize("cfg_name,B,H,W,n_src", [
+    ("ssim_smooth", 32, 128, 416, 2),     # BASELINE cfg3 / cfg4's per-GPU share, live smoothness form
+    ("edge_aware", 32, 128, 416, 2),      # BASELINE cfg3 as written (edge-aware smoothness)
+    ("ssim_smooth", 8, 256, 832, 4),      # BASELINE cfg5, 5-frame snippet = 4 sources
+    ("ssim_smooth", 8, 256, 832, 2),      # BASELINE cfg5 as parenthesised (2 source views)
+])
+def test_full_size_properties(ops, synth, dev, cfg_name, B, H, W, n_src):
+    """BASELINE configs at their FULL batch: size-independent properties instead of an oracle run --
+      * determinism: two runs agree bit for bit (loss and every gradient);
+      * fused launch == separate forward / backward launches;
+      * batch additivity: the loss is the sum of the two half-batch losses with norm_B = B, and every sample's
+        gradients are those the half-batch run gives it -- which ties the full batch to the oracle-checked small batches;
+      * hwc layout == planar layout; everything finite."""
     import torch
-    cfg = CONFIGS["ssim_smooth"]
-    d = synth.make_inputs(B=32, H=128, W=416, n_src=2, n_scales=4, seed=1)
-    fl = _bind(ops, dev, d, cfg)
+    cfg = CONFIGS[cfg_name]
+    d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=4, seed=1)
+    fl = _bind(ops, dev, d, cfg, layout="hwc")
     l1 = to_np(fl.forward_backward()).copy()
     g1 = [to_np(t).copy() for t in fl.d_disps + fl.d_poses]
     l2 = to_np(fl.forward_backward()).copy()
@@ -207,6 +248,22 @@ def test_full_size_properties(ops, synth, dev):
         assert np.isfinite(a).all()
     lf = to_np(fl.forward())
     np.testing.assert_allclose(lf, l1, rtol=2e-5)
+    fl.backward(1.0)
+    for a, t in zip(g1, fl.d_disps + fl.d_poses):
+        np.testing.assert_allclose(to_np(t), a, rtol=0, atol=2e-5 * np.abs(a).max())
+    # the two halves of the batch, normalised by the full batch
+    tot = np.zeros(5)
+    for lo in (0, B // 2):
+        sl = slice(lo, lo + B // 2)
+        part = dict(d, tgt_pyr=[a[sl] for a in d["tgt_pyr"]], src_pyr=[a[sl] for a in d["src_pyr"]], intrinsics=d["intrinsics"][sl],
+                    disps=[a[sl] for a in d["disps"]], poses=[a[sl] for a in d["poses"]])
+        sh = _bind(ops, dev, part, cfg, norm_B=B, layout="planar")
+        tot += to_np(sh.forward_backward()).astype(np.float64)
+        for s in range(4):
+            np.testing.assert_allclose(to_np(sh.d_disps[s]), g1[s][sl], rtol=0, atol=2e-5 * np.abs(g1[s]).max())
+        for i in range(n_src):
+            np.testing.assert_allclose(to_np(sh.d_poses[i]), g1[4 + i][sl], rtol=0, atol=2e-5 * np.abs(g1[4 + i]).max())
+    np.testing.assert_allclose(tot, l1.astype(np.float64), rtol=2e-5)
     torch.cuda.synchronize()
 
 

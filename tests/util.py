@@ -1,6 +1,13 @@
 """Helpers shared by the parity tests."""
 import numpy as np
 
+# what the tolerance-based tests actually measured (excluded shares, worst errors): printed by conftest's terminal summary
+PARITY_NOTES = []
+
+
+def parity_note(line):
+    PARITY_NOTES.append(str(line))
+
 
 def to_dev(a, dev):
     import torch

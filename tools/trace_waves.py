@@ -50,24 +50,25 @@ if os.environ.get("SFMWARP_LIB", "").endswith("stamps.so"):
     n = n_items
     b = raw.reshape(-1)[n * 4: n * 4 + n * 8].reshape(n, 8).astype(np.float64)
     steps = b[:, 4].sum()
-    print("cycles per row step (mean over all waves): A.finish %.0f  A.issue %.0f  B %.0f  C %.0f   total %.0f ; smooth pass per wave %.0f cycles" % (
+    print("cycles per row step (mean over all waves): A.finish %.0f  A.issue %.0f  B %.0f  C %.0f   total %.0f ; smoothness pass per wave %.0f cycles" % (
         b[:, 0].sum() / steps, b[:, 1].sum() / steps, b[:, 2].sum() / steps, b[:, 3].sum() / steps, b[:, :4].sum() / steps, b[:, 5].mean()))
 if stamps:
-    dur_cyc = (a[:, 1] - a[:, 0]).astype(np.float64) * 24.0     # 100 MHz ticks -> cycles at ~2.4 GHz
-    loop = b[:, :4].sum(axis=1); sm = b[:, 5]
+    dur_cyc = b[:, 7]                                           # whole wave, shader cycles (s_memtime)
+    dur_us = (a[:, 1] - a[:, 0]).astype(np.float64) / 100.0     # the same span in 100 MHz ticks
+    print("in-kernel clock (wave cycles / wave time): median %.3f GHz" % np.median(dur_cyc / dur_us / 1e3))
+    loop = b[:, :4].sum(axis=1); sm = b[:, 5]; src = b[:, 6]
     order = np.zeros(n, int)
     for kk in np.unique(key):
         idx = np.where(key == kk)[0]
         order[idx[np.argsort(en[idx])]] = np.arange(len(idx))
-    for rk in range(3):
+    for rk in range(4):
         m = order == rk
         if m.any():
-            print("   passes %.0fk (loop %.0fk => prologue+epilogue of the 2 source passes %.0fk), kernel epilogue %.0fk, before smooth pass %.0fk" % (
-                b[m, 6].mean() / 1e3, loop[m].mean() / 1e3, (b[m, 6] - loop[m]).mean() / 1e3, b[m, 7].mean() / 1e3,
-                (dur_cyc[m] - b[m, 5] - b[m, 6] - b[m, 7]).mean() / 1e3))
-            print("finish-rank %d: n=%d dur %.0fk cyc | loop %.0fk (%.0f/step, steps %.1f) smooth %.0fk other %.0fk | A.fin %.0f A.iss %.0f B %.0f C %.0f per step" % (
-                rk, m.sum(), dur_cyc[m].mean() / 1e3, loop[m].mean() / 1e3, (loop[m] / b[m, 4]).mean(), b[m, 4].mean(), sm[m].mean() / 1e3,
-                (dur_cyc[m] - loop[m] - sm[m]).mean() / 1e3, (b[m, 0] / b[m, 4]).mean(), (b[m, 1] / b[m, 4]).mean(), (b[m, 2] / b[m, 4]).mean(), (b[m, 3] / b[m, 4]).mean()))
+            print("finish-rank %d: n=%d wave %.0fk cyc = source passes %.0fk (row loop %.0fk: %.0f/step x %.1f steps; set-up + prologue + pose sums %.0fk)"
+                  " + smoothness pass %.0fk + start-up/write-out %.0fk | A.fin %.0f A.iss %.0f B %.0f C %.0f per step" % (
+                rk, m.sum(), dur_cyc[m].mean() / 1e3, src[m].mean() / 1e3, loop[m].mean() / 1e3, (loop[m] / b[m, 4]).mean(), b[m, 4].mean(),
+                (src[m] - loop[m]).mean() / 1e3, sm[m].mean() / 1e3, (dur_cyc[m] - src[m] - sm[m]).mean() / 1e3,
+                (b[m, 0] / b[m, 4]).mean(), (b[m, 1] / b[m, 4]).mean(), (b[m, 2] / b[m, 4]).mean(), (b[m, 3] / b[m, 4]).mean()))
 # per-SIMD completion times: is the launch limited by throughput (all SIMDs end together) or by imbalance?
 simd_end = np.array([en[key == kk].max() for kk in u])
 simd_work = np.array([(en - st)[key == kk].sum() for kk in u])
