@@ -130,29 +130,30 @@ def _random_cases(n, seed=2024):
 def test_random_shapes_and_modes(ops, synth, dev, B, H, W, n_src, n_scales, cfg_name, seed):
     """A seeded sweep; every case is judged by the SAME criteria as the fixed-shape tests (_check_losses, _check_grads: loss
     1e-4, gradients 2e-3 element-wise + relative L2, knife share capped).  A pixel on the strict `-1 < x < 1` test of
-    transform.py:129 may be sampled in one fp32 evaluation and exactly 0 in the other; it can move the loss by at most
-    (6 + 3) / (3 B h w).  Inputs where such pixels could move the loss by more than a fifth of its tolerance (small images
-    only), or whose knife-edge pixels exceed the cap, are re-drawn with the next seed -- counted and reported."""
+    transform.py:129 may be sampled in one fp32 evaluation and exactly 0 in the other; it can move a loss term by at most
+    (6 + 3) / (3 B h w).  The pixels within 8e-6 of that test (20 ulp of the normalised coordinate) are COUNTED, what they can move is added to the loss tolerance,
+    and inputs where that exceeds 5e-4 (the loss terms are O(1)) or whose knife-edge pixels exceed the cap are re-drawn with
+    the next seed -- all of it reported (gpurun_out/parity_stats.txt)."""
     from test_loss_gpu import knife_cap
     from util import dilate, parity_note
     cfg = CONFIGS[cfg_name]
     for attempt in range(8):
         d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=n_scales, seed=(seed + attempt) % 10000, with_masks=True)
         ref = _oracle(d, cfg)
-        flips = sum(int((ref["margin"][s_] < 2e-5).sum()) for s_ in range(n_scales))
-        flip_reach = sum(float((ref["margin"][s_] < 2e-5).sum()) * 3.0 / (B * ref["margin"][s_].shape[-2] * ref["margin"][s_].shape[-1])
+        flips = sum(int((ref["margin"][s_] < 8e-6).sum()) for s_ in range(n_scales))
+        flip_reach = sum(float((ref["margin"][s_] < 8e-6).sum()) * 3.0 / (B * ref["margin"][s_].shape[-2] * ref["margin"][s_].shape[-1])
                          for s_ in range(n_scales))
         over = False
         for s_ in range(n_scales):
             m = dilate((ref["clip_margin"][s_] < 5e-5).any(axis=1), 1) | (ref["cell_margin"][s_] < 1e-4).any(axis=1) | (ref["abs_margin"][s_] < 3e-5).any(axis=1)
             over |= m.mean() > 0.8 * knife_cap(m.size)
-        if flip_reach <= 2e-5 and not over:
+        if flip_reach <= 5e-4 and not over:
             break
     else:
         pytest.fail("no admissible input in 8 draws")
     parity_note("sweep case B=%d %dx%d n_src=%d scales=%d %s: input re-drawn %d times; %d pixels on the (-1,1) test, reach %.1e of the loss" % (
         B, H, W, n_src, n_scales, cfg_name, attempt, flips, flip_reach))
     fl = _bind(ops, dev, d, cfg, layout="hwc" if seed % 2 else "planar")     # both image layouts take part in the sweep
-    _check_losses(fl.forward(), ref)
-    _check_losses(fl.forward_backward(), ref)
+    _check_losses(fl.forward(), ref, slack=flip_reach)
+    _check_losses(fl.forward_backward(), ref, slack=flip_reach)
     _check_grads(fl, ref, n_src, check_mask=bool(cfg.get("exp_reg")), what="sweep %s %dx%d" % (cfg_name, H, W))

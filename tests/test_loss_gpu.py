@@ -37,11 +37,13 @@ def _bind(ops, dev, d, cfg, norm_B=None, want_d_src=False, layout="planar"):
     return fl
 
 
-def _check_losses(loss5, ref):
+def _check_losses(loss5, ref, slack=0.0):
+    """`slack`: absolute allowance for pixels that sit on the strict `-1 < x < 1` test (only the random sweep passes one:
+    counted, bounded and reported there); 0 everywhere else."""
     got = to_np(loss5)
     for k, name in enumerate(KEYS):
         want = ref[name]
-        assert abs(got[k] - want) <= LOSS_RTOL * max(abs(want), 1e-6), (name, got[k], want)
+        assert abs(got[k] - want) <= LOSS_RTOL * max(abs(want), 1e-6) + slack, (name, got[k], want, slack)
 
 
 KNIFE_CAP_LARGE, KNIFE_CAP_SMALL, KNIFE_SMALL_PX = 0.01, 0.05, 20000
@@ -54,7 +56,7 @@ def knife_cap(n_px):
     return KNIFE_CAP_LARGE if n_px >= KNIFE_SMALL_PX else KNIFE_CAP_SMALL
 
 
-def _knife(ref, s, n_src, thr=2e-5, cell_thr=1e-4, abs_thr=3e-5, clip_thr=5e-5, what=""):
+def _knife(ref, s, n_src, thr=8e-6, cell_thr=1e-4, abs_thr=3e-5, clip_thr=5e-5, what=""):
     """Pixels of scale s where the reference's function itself is discontinuous in (disp, pose), so that two
     fp32 evaluations of it may legitimately land on different sides; excluded from ELEMENT-WISE gradient
     comparisons (never from the loss comparison), each class with the footprint it can influence:
