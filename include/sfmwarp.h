@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SFM_ABI_VERSION 2
+#define SFM_ABI_VERSION 3
 
 #define SFM_OK 0
 #define SFM_ERR_NULL (-1)      /* a required pointer is NULL                       */
@@ -157,6 +157,12 @@ int sfm_loss_fwd_bwd(const SfmLossDesc *desc, float *loss5, void *ws, size_t ws_
  * hipEvent_t handles on its stream immediately before and after its main kernel, then forgets
  * them.  NULL disables. */
 int sfm_loss_profile_events(void *ev_start, void *ev_stop);
+/* Host-side only (no device needed): the work decomposition the library chooses for `desc` and the entry point given by
+ * (grad, loss) = (0,1) sfm_loss_fwd, (1,0) sfm_loss_bwd, (1,1) sfm_loss_fwd_bwd.  out[0] = wavefront items of the launch; then
+ * per scale four ints: strips, row chunks per strip, rows of a chunk, items per sample (n_out >= 1 + 4 * n_scales).  For tests
+ * and tuning; nothing is launched. */
+int sfm_loss_plan_info(const SfmLossDesc *desc, int grad, int loss, int *out, int n_out);
+
 /* Diagnostics: the NEXT sfm_loss_* call of this thread makes every wavefront of its main kernel
  * write {start, end (100 MHz realtime counter), HW_ID, XCC_ID} as 4 x uint64 per work item into
  * buf (device memory, 32 bytes * number of items; items <= workspace_bytes / 64). NULL disables. */

@@ -16,7 +16,7 @@ import torch  # noqa: F401
 
 SFM_MAX_SCALES = 8
 SFM_MAX_SRC = 8
-SFM_ABI_VERSION = 2
+SFM_ABI_VERSION = 3
 SFM_LAYOUT_PLANAR, SFM_LAYOUT_HWC = 0, 1
 
 SMOOTH_NONE, SMOOTH_SECOND_ORDER, SMOOTH_EDGE_AWARE = 0, 1, 2
@@ -63,6 +63,7 @@ SYMBOLS = {
     "sfm_loss_fwd": (_I, [C.POINTER(SfmLossDesc), _FP, _V, _Z, _V]),
     "sfm_loss_bwd": (_I, [C.POINTER(SfmLossDesc), C.c_float, _V, _Z, _V]),
     "sfm_loss_fwd_bwd": (_I, [C.POINTER(SfmLossDesc), _FP, _V, _Z, _V]),
+    "sfm_loss_plan_info": (_I, [C.POINTER(SfmLossDesc), _I, _I, C.POINTER(C.c_int), _I]),
     "sfm_loss_profile_events": (_I, [_V, _V]),
     "sfm_loss_debug_trace": (_I, [_V]),
     "sfm_resize_fwd": (_I, [_FP, _FP, _I, _I, _I, _I, _I, _I, _V]),
@@ -86,11 +87,13 @@ def _load():
             "or `make -C sfm-learner-chainer_amd/csrc`. There is no CPU fallback." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
+        if os.environ.get("SFMWARP_ALLOW_OLD_ABI") and not hasattr(lib, name):
+            continue                # development only: A/B runs against a library built from an older commit
         fn = getattr(lib, name)     # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
     got = lib.sfm_abi_version()
-    if got != SFM_ABI_VERSION:
+    if got != SFM_ABI_VERSION and not os.environ.get("SFMWARP_ALLOW_OLD_ABI"):
         raise ImportError("libsfmwarp.so has ABI version %d, this package expects %d" % (got, SFM_ABI_VERSION))
     return lib
 

@@ -223,6 +223,21 @@ __device__ __forceinline__ Tap2 load_tap2(const float* p) { return *reinterpret_
 #endif
 
 // ------------------------------------------------------------------------------------------
+// Per-lane accesses to a wave-uniform array: base pointer (uniform, SGPR pair) + zero-extended 32-bit BYTE offset (VGPR).
+// Written this way the backend selects the `global_load/store ... v_off, s[base:base+1]` addressing form: no 64-bit per-lane
+// address is ever formed (a v_lshl_add_u64 per access otherwise) and nothing 64-bit and lane-variant is hoisted out of the row
+// loops to be spilled around them.  The arrays indexed like this are single planes / images: far below 4 GiB.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T ld_off(const float* base, const unsigned byte_off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ float ldf(const float* base, const unsigned idx) { return ld_off<float>(base, idx * 4u); }
+__device__ __forceinline__ void stf(float* base, const unsigned idx, const float v) {
+  *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + idx * 4u) = v;
+}
+
+// ------------------------------------------------------------------------------------------
 // The per-pixel projection + sampling coordinates shared by every kernel.
 //
 // Restates models/transform.py:105-108 (pixel2cam), :122-131 (cam2pixel incl. the x2 rule) and

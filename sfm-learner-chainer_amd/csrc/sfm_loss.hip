@@ -44,6 +44,11 @@ struct ScaleArgs {
   float c_dx2, c_dy2, c_dxy;   // smooth_reg / 2^s / element count         base_model.py:76,184-185
   float c_ex, c_ey;            // the same for the edge-aware form         base_model.py:154-155
   float c_exp;                 // exp_reg / (norm_B * h * w)               base_model.py:105,167
+  // uniform factors of the backward, products with the upstream gradient gy (set_gy): kept as kernel arguments so that they
+  // are scalar operands -- computed in the kernel they would be wave-uniform values held in vector registers
+  float k_pix;                 // gy (1-alpha) inv_cnt          dL/d(sum |e|)        base_model.py:111,117
+  float kq;                    // -gy alpha inv_cnt / 2         -1/2 dL/d(sum ssim)  base_model.py:115,117,142
+  float k_exp;                 // gy c_exp                                            base_model.py:105,167
 };
 
 struct LossArgs {
@@ -122,17 +127,16 @@ __device__ __forceinline__ void smooth2_pass(const LossArgs& A, const ScaleArgs&
   const unsigned xc = (unsigned)min(max(x, 0), w - 1);
   // always a load, from a row clamped into the image (a load under a branch would make the compiler drain every
   // outstanding load at the join); values of rows outside the image only feed terms that are masked out
-  auto ldrow = [&](int r) -> float { return dplane[(unsigned)min(max(r, 0), h - 1) * (unsigned)w + xc]; };
+  auto ldrow = [&](int r) -> float { return ldf(dplane, (unsigned)min(max(r, 0), h - 1) * (unsigned)w + xc); };
   // loop-invariant coefficients pinned in vector registers (the scalar file is full)
   float c_dx2 = S.c_dx2, c_dy2 = S.c_dy2, c_dxy = S.c_dxy, gyv = A.gy;
   asm volatile("" : "+v"(c_dx2), "+v"(c_dy2), "+v"(c_dxy), "+v"(gyv));
-  // rows a, a+1 in registers, a+2 arriving; loads run three rows ahead of their use
-  float d0 = xin ? ldrow(y0 - 2) : 0.f, dp1 = xin ? ldrow(y0 - 1) : 0.f;
-  float q1 = ldrow(y0), q2 = ldrow(y0 + 1), q3 = ldrow(y0 + 2);
   float s2y_m1 = 0.f, s2y_m2 = 0.f, txy_m1 = 0.f;   // anchored signs of rows a-1, a-2
-  for (int a = y0 - 2; a < y1; ++a) {
-    const float dp2 = xin ? q1 : 0.f;
-    q1 = q2; q2 = q3; q3 = ldrow(a + 5);
+  // one row of the walk: d0, dp1 = rows a, a+1 (masked), q = row a+2 as loaded (masked in place); afterwards the register of
+  // row a receives row a+5
+  auto row = [&](const int a, float& d0, float& dp1, float& q) {
+    q = xin ? q : 0.f;
+    const float dp2 = q;
     const float dxr0 = from_right(d0) - d0;        // dx(a,x)
     const float dx2 = from_right(dxr0) - dxr0;     // dx2(a,x)
     const float dy0 = dp1 - d0, dy1 = dp2 - dp1;   // dy(a,x), dy(a+1,x)
@@ -140,6 +144,7 @@ __device__ __forceinline__ void smooth2_pass(const LossArgs& A, const ScaleArgs&
     const float dxrp = from_right(dp1) - dp1;      // dx(a+1,x)
     const float dxdy0 = dxrp - dxr0;               // dxdy(a,x) = dx(a+1,x) - dx(a,x)
     const float dydx0 = from_right(dy0) - dy0;     // dydx(a,x) = dy(a,x+1) - dy(a,x)
+    d0 = ldrow(a + 5);                             // the register of row a is free now
     const bool va = a >= 0, va2 = va && a <= h - 3, va1 = va && a <= h - 2;   // uniform
     if (LOSS) {
       if (a >= y0) {
@@ -163,7 +168,18 @@ __device__ __forceinline__ void smooth2_pass(const LossArgs& A, const ScaleArgs&
       }
       s2y_m2 = s2y_m1; s2y_m1 = s2y; txy_m1 = txy;
     }
-    d0 = dp1; dp1 = dp2;
+  };
+  // The rows a .. a+4 of the column live in five registers used in rotation (the body is instantiated five times: no register
+  // is moved, so the wait for a load sits where its value is first used, three rows later; a rotation through moves made
+  // every row wait for the load it had just issued).
+  float r0 = xin ? ldrow(y0 - 2) : 0.f, r1 = xin ? ldrow(y0 - 1) : 0.f;
+  float r2 = ldrow(y0), r3 = ldrow(y0 + 1), r4 = ldrow(y0 + 2);
+  for (int a = y0 - 2; a < y1; a += 5) {
+    row(a, r0, r1, r2);
+    if (a + 1 < y1) row(a + 1, r1, r2, r3);
+    if (a + 2 < y1) row(a + 2, r2, r3, r4);
+    if (a + 3 < y1) row(a + 3, r3, r4, r0);
+    if (a + 4 < y1) row(a + 4, r4, r0, r1);
   }
 }
 
@@ -183,9 +199,9 @@ __device__ __forceinline__ void smooth_edge_pass(const LossArgs& A, const ScaleA
   float qd1 = 0.f, qd2 = 0.f, qi1[3] = {0.f, 0.f, 0.f}, qi2[3] = {0.f, 0.f, 0.f};
   auto ldrow = [&](int r, float& d, float* im) {   // always loads, from a row clamped into the image (see smooth2_pass)
     const unsigned o = (unsigned)min(max(r, 0), h - 1) * (unsigned)w + xc;
-    d = dplane[o];
+    d = ldf(dplane, o);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) im[c] = HWC ? tplane[3u * o + c] : tplane[c * P + o];
+    for (int c = 0; c < 3; ++c) im[c] = HWC ? ldf(tplane, 3u * o + c) : ldf(tplane + c * P, o);
   };
   ldrow(y0 - 1, qd1, qi1);
   ldrow(y0, qd2, qi2);
@@ -334,20 +350,24 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
     typedef const __attribute__((address_space(4))) Geom* GeomConstPtr;
     GeomConstPtr gp = (GeomConstPtr)(uintptr_t)(A.geom + ((size_t)(b * A.n_scales + s) * A.n_src + i));
     const float xf = (float)x;
+    C.gp = gp;
+    C.x0 = x - lane;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       C.M1[k] = gp->M[k * 3 + 1];
       C.P3[k] = gp->P[k * 4 + 3];
-      C.K1[k] = gp->Kinv[k * 3 + 1];
       C.mx[k] = fmaf(gp->M[k * 3 + 0], xf, gp->M[k * 3 + 2]);
-      C.kx[k] = fmaf(gp->Kinv[k * 3 + 0], xf, gp->Kinv[k * 3 + 2]);
       C.tp[k] = S.tgt + ((size_t)b * 3 + k) * P;
       C.sp[k] = S.src + (((size_t)b * A.n_src + i) * 3 + k) * P;
     }
-    C.k_pix = A.gy * (1.0f - A.alpha) * S.inv_cnt;
-    C.kq = -0.5f * A.gy * A.alpha * S.inv_cnt;
-    C.k_exp = A.gy * S.c_exp;
-    C.h = h; C.w = w; C.y0 = y0; C.y1 = y1;
+    C.k_pix = S.k_pix;
+    C.kq = S.kq;
+    C.k_exp = S.k_exp;
+    // (the chunk's rows pass through an opaque register once per phase: what depends on them is recomputed per pass instead of
+    // being hoisted out of the phase loop and carried -- spilled -- across every pass)
+    int y0p = y0, y1p = y1;
+    asm volatile("" : "+s"(y0p), "+s"(y1p));
+    C.h = h; C.w = w; C.y0 = y0p; C.y1 = y1p;
     C.dp = S.disp + (size_t)b * P;
     C.dsp = (GRAD && S.d_src) ? S.d_src + ((size_t)b * A.n_src + i) * 3 * P : nullptr;
     C.mp = EXPL ? S.mlog + ((size_t)b * A.n_src + i) * P : nullptr;
@@ -373,7 +393,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
   if (GRAD) {
     if (outl) {
       float* o = S.d_disp + (size_t)b * P;
-      for (int q = y0; q < y1; ++q) o[q * w + x] = gacc[(q - y0) * 64 + lane];
+      for (int q = y0; q < y1; ++q) stf(o, (unsigned)(q * w + x), gacc[(q - y0) * 64 + lane]);
     }
   }
   if (A.trace && lane == 0) {   // timing-only diagnostics; never read by any kernel
@@ -381,7 +401,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
     o[0] = t_start;
     o[1] = __builtin_amdgcn_s_memrealtime();
     o[2] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
-    o[3] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+    o[3] = (__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) & 0xf) | ((unsigned long long)blockIdx.x << 8);   // HW_REG_XCC_ID, workgroup
 #ifdef SFM_STAMPS
     if constexpr (SSIM) {
       unsigned long long* q = A.trace + (size_t)A.items * 4 + (size_t)item * 8;
@@ -618,6 +638,8 @@ static long long max_items(const SfmLossDesc* d, int sw) {
   return items;
 }
 
+static void set_gy(struct Plan& p, const float gy);
+
 // validates the descriptor and lays out items + workspace for the given mode
 static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_outputs, float gy, Plan& p) {
   if (!d) return fail(SFM_ERR_NULL, "sfm_loss: NULL descriptor");
@@ -707,6 +729,7 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
     S.c_exp = (float)((double)d->exp_reg / (nb * h * w));
   }
   A.items = items;
+  set_gy(p, gy);
   // The workspace layout does not depend on the chunking (nor on the device): the two partial-sum arrays are placed
   // and sized for the largest item count any chunking can produce.
   const size_t cap = (size_t)max_items(d, sw);
@@ -716,6 +739,17 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
   p.off_gpm = align_up(p.off_loss + cap * 4 * sizeof(float), 256);
   p.total = align_up(p.off_gpm + cap * d->n_src * 12 * sizeof(float), 256);
   return SFM_OK;
+}
+
+static void set_gy(Plan& p, const float gy) {
+  LossArgs& A = p.args;
+  A.gy = gy;
+  for (int s = 0; s < A.n_scales; ++s) {
+    ScaleArgs& S = A.sc[s];
+    S.k_pix = gy * (1.0f - A.alpha) * S.inv_cnt;
+    S.kq = -0.5f * gy * A.alpha * S.inv_cnt;
+    S.k_exp = gy * S.c_exp;
+  }
 }
 
 static void bind_workspace(Plan& p, void* ws) {
@@ -780,7 +814,7 @@ static int cached_plan(const SfmLossDesc* d, bool grad, bool loss, float gy, Pla
     CachedPlan& c = g_plans[k];
     if (c.valid && c.grad == grad && c.loss == loss && c.device == dev && memcmp(&c.desc, d, sizeof(SfmLossDesc)) == 0) {
       out = c.plan;
-      out.args.gy = gy;
+      set_gy(out, gy);
       return SFM_OK;
     }
   }
@@ -838,6 +872,19 @@ size_t sfm_loss_workspace_bytes(const SfmLossDesc* desc) {
     if (p.total > total) total = p.total;
   }
   return total;
+}
+
+int sfm_loss_plan_info(const SfmLossDesc* desc, int grad, int loss, int* out, int n_out) {
+  sfm::Plan p;
+  if (int e = sfm::make_plan(desc, grad != 0, loss != 0, false, 1.f, p)) return e;
+  if (!out || n_out < 1 + 4 * desc->n_scales) return sfm::fail(SFM_ERR_NULL, "sfm_loss_plan_info: out needs 1 + 4 * n_scales ints");
+  out[0] = p.args.items;
+  for (int s = 0; s < desc->n_scales; ++s) {
+    const sfm::ScaleArgs& S = p.args.sc[s];
+    int* o = out + 1 + 4 * s;
+    o[0] = S.strips; o[1] = S.chunks; o[2] = S.chunk_rows; o[3] = S.tiles;
+  }
+  return SFM_OK;
 }
 
 int sfm_loss_debug_trace(void* buf) {

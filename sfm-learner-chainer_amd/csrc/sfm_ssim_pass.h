@@ -22,7 +22,7 @@ namespace sfm {
 
 #ifdef SFM_STAMPS   // diagnostic build only: cycle stamps around the stages of a row step (never in the product build)
 #define SFM_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-struct Stamps { unsigned long long a_fin, a_iss, b, c, steps; };
+struct Stamps { unsigned long long a_fin, a_iss, b, c, steps; };   // quad passes: cycles waited for start-S, start-G, finish-S, finish-G; steps = loop cycles
 __device__ Stamps g_dummy_stamps;
 #define SFM_STAMPS_ARG , Stamps& st
 #define SFM_STAMPS_PASS , st
@@ -34,7 +34,9 @@ __device__ Stamps g_dummy_stamps;
 
 struct SsimCtx {
   // uniform (SGPR)
-  float M1[3], P3[3], K1[3];
+  float M1[3], P3[3];
+  const __attribute__((address_space(4))) Geom* gp;   // the geometry entry of this (sample, scale, source): read again by pose_sums_expand
+  int x0;               // column of lane 0 (uniform); the lane's column is x0 + lane
   float k_pix;   // dL/d(sum |e|)        = gy (1-alpha) / (norm_B 3 h w)   base_model.py:111,117
   float kq;      // -1/2 dL/d(sum ssim)  = -gy alpha / (2 norm_B 3 h w)    base_model.py:115,117,142
   int h, w, y0, y1;
@@ -48,7 +50,7 @@ struct SsimCtx {
   size_t P;
   ScaleConst sc;
   // per lane
-  float mx[3], kx[3];   // M[k][0] x + M[k][2],  Kinv[j][0] x + Kinv[j][2]
+  float mx[3];          // M[k][0] x + M[k][2]
   unsigned xc;          // column, clamped into the image (address-safe for halo lanes)
   bool xin;             // column inside the image
   float outf;           // 1 for an output lane, else 0
@@ -175,6 +177,8 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
   }
 #else
   if constexpr (HWC) {
+    // (plain pointer arithmetic here: the two horizontally adjacent taps of a row are then fetched as ONE 24-byte access,
+    // dwordx4 + dwordx2; four separate 12-byte loads per row step cost the gather path 40 % more time per step at 256x832)
     const float* q = C.sp[0] + 3u * off;
     const unsigned w3 = 3u * (unsigned)C.w;
     const Rgb T0 = load_rgb(q), T1 = load_rgb(q + 3), B0 = load_rgb(q + w3), B1 = load_rgb(q + w3 + 3);
@@ -184,13 +188,17 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
   } else {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
+#ifdef SFM_TAP_DWORDS
       const Tap2 t = load_tap2(C.sp[c] + off), b = load_tap2(C.sp[c] + off + (unsigned)C.w);
+#else
+      const Tap2 t = ld_off<Tap2>(C.sp[c], 4u * off), b = ld_off<Tap2>(C.sp[c], 4u * (off + (unsigned)C.w));
+#endif
       ps.ta[c] = t.a; ps.tb[c] = t.b; ps.ba[c] = b.a; ps.bb[c] = b.b;
-      ps.it[c] = C.tp[c][offt];
+      ps.it[c] = ldf(C.tp[c], offt);
     }
   }
 #endif
-  if (C.mp != nullptr) ps.lg = C.mp[offt];
+  if (C.mp != nullptr) ps.lg = ldf(C.mp, offt);
 }
 
 // stage A, second half: bilinear value and derivatives from the gathered taps
@@ -238,7 +246,7 @@ __device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& 
   else (void)__hip_atomic_fetch_add(ga, gdisp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
   // dL/dPm[k][j] = sum over pixels of gq_k * c_j with c = D * (K1 y + kx) (the back-projected point), c_3 = 1.  The ray
   // is linear in the row, so a lane only accumulates  A_k = sum gq_k D,  B_k = sum y gq_k D,  C_k = sum gq_k  (9 values
-  // instead of 12) and expands them once per pass: gpm[k][j] = K1[j] B_k + kx[j] A_k   (pose_sums_expand)
+  // instead of 12) and expands them once per pass: gpm[k][j] = K1[j] B_k + kx[j] A_k, K1 = Kinv[:,1], kx = Kinv[:,0] x + Kinv[:,2]   (pose_sums_expand)
   const float t0 = gq0 * s2.D, t1 = gq1 * s2.D, t2 = gq2 * s2.D;
   gpm[0] += t0; gpm[1] += t1; gpm[2] += t2;
   gpm[3] = fmaf(yf, t0, gpm[3]); gpm[4] = fmaf(yf, t1, gpm[4]); gpm[5] = fmaf(yf, t2, gpm[5]);
@@ -259,17 +267,43 @@ __device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& 
   }
 }
 
-// the 12 sums of dL/dPm of this (wave, source) from the 9 per-lane accumulators of geometry_backward
+// the 12 sums of dL/dPm of this (wave, source) from the 9 per-lane accumulators of geometry_backward.
+// The twelve wave reductions run in LOCKSTEP (stage by stage over all twelve values): twelve independent DPP adds per stage
+// instead of twelve dependent chains of six (each link of a chain waits for the previous one; 2.7-3.9k cycles per pass in
+// profiles/r02_wave_stage_stamps.txt).  Same adds in the same order per value: the sums are bit-identical to wave_sum's.
 __device__ __forceinline__ void pose_sums_expand(const SsimCtx& C, const float* acc, float* gpm_out) {
+  // K1[j] = Kinv[j][1], kx[j] = Kinv[j][0] x + Kinv[j][2]: only needed here, so neither lives through the row loop
+  const float xf = (float)(C.x0 + C.lane);
+  float K1[3], kx[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    K1[j] = C.gp->Kinv[j * 3 + 1];
+    kx[j] = fmaf(C.gp->Kinv[j * 3 + 0], xf, C.gp->Kinv[j * 3 + 2]);
+  }
+  float v[12];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const float v = wave_sum(fmaf(C.K1[j], acc[3 + k], C.kx[j] * acc[k]));
-      if (C.lane == 0) gpm_out[k * 4 + j] = v;
-    }
-    const float v = wave_sum(acc[6 + k]);
-    if (C.lane == 0) gpm_out[k * 4 + 3] = v;
+    for (int j = 0; j < 3; ++j) v[k * 4 + j] = fmaf(K1[j], acc[3 + k], kx[j] * acc[k]);
+    v[k * 4 + 3] = acc[6 + k];
+  }
+#define SFM_DPP_STAGE(ctrl, rmask)                                                                                              \
+  _Pragma("unroll") for (int i = 0; i < 12; ++i)                                                                                \
+      v[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[i]), ctrl, rmask, 0xf, true));  \
+  __builtin_amdgcn_sched_barrier(0)
+  SFM_DPP_STAGE(0x111, 0xf);   // row_shr:1
+  SFM_DPP_STAGE(0x112, 0xf);   // row_shr:2
+  SFM_DPP_STAGE(0x114, 0xf);   // row_shr:4
+  SFM_DPP_STAGE(0x118, 0xf);   // row_shr:8   -> lane 15 of every row of 16 holds the row sum
+  SFM_DPP_STAGE(0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+  SFM_DPP_STAGE(0x143, 0xc);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+#undef SFM_DPP_STAGE
+  // lane 63 holds the twelve totals: it writes them (three 16-byte stores)
+  if (C.lane == 63) {
+    float4* o = reinterpret_cast<float4*>(gpm_out);
+    o[0] = make_float4(v[0], v[1], v[2], v[3]);
+    o[1] = make_float4(v[4], v[5], v[6], v[7]);
+    o[2] = make_float4(v[8], v[9], v[10], v[11]);
   }
 }
 
@@ -319,6 +353,37 @@ __device__ __forceinline__ void ssim_stage_c(const T a2, const T a1, const T a0,
   q1 = g * dv;
 }
 
+// Stage B at centre row rb (rows rb-1, rb, rb+1 in s2, s1, s0): SSIM value and, with GRAD, the horizontal 3-sums of its
+// partials into g0.  `count` = whether the row's loss terms belong to this wave (a halo row gets weight 0 -- branch-free: a
+// branch here would split the block and un-fold the DPP adds).
+template <bool GRAD, bool LOSS>
+__device__ __forceinline__ void ssim_stage_b_row(const SsimCtx& C, const RowS& s2, const RowS& s1, const RowS& s0, RowG& g0,
+                                                 const bool count, float& acc_pix, float& acc_ssim) {
+  float ssum = 0.f;
+  const float kq_nm = C.kq * s1.nm;   // kappa before the clip test; s1.nm is 0 outside the image and on masked pixels (:114)
+  ssim_stage_b<GRAD, LOSS>(s2.ih.p, s1.ih.p, s0.ih.p, s2.it.p, s1.it.p, s0.it.p, kq_nm, g0.a.p, g0.b.p, g0.e.p, ssum);
+  ssim_stage_b<GRAD, LOSS>(s2.ih.s, s1.ih.s, s0.ih.s, s2.it.s, s1.it.s, s0.it.s, kq_nm, g0.a.s, g0.b.s, g0.e.s, ssum);
+  if (LOSS) {
+    const float wgt = count ? s1.nm * C.outf : 0.f;
+    acc_ssim = fmaf(ssum, wgt, acc_ssim);                            // base_model.py:114-115
+    const float e1 = vabs_sum(s1.ih.p - s1.it.p) + vabs_sum(s1.ih.s - s1.it.s);   // :95
+    acc_pix = fmaf(e1, wgt, acc_pix);                                // :98-100,:111
+  }
+}
+
+// Stage C at row rc (the row in s2; partials of the rows rc-1, rc, rc+1 in g2, g1, g0): dL/dI^ -> dL/d(u,v) -> dL/dq -> d_depth
+// tile and the sums of dL/dPm.
+__device__ __forceinline__ void ssim_stage_c_row(const SsimCtx& C, const int rc, const RowS& s2, const RowG& g2, const RowG& g1,
+                                                 const RowG& g0, float* gacc, const bool first, float* gpm) {
+  const float kpn = C.k_pix * s2.nm;
+  f2 gp, q0p, q1p;
+  float gs, q0s, q1s;
+  ssim_stage_c(g2.a.p, g1.a.p, g0.a.p, g2.b.p, g1.b.p, g0.b.p, g2.e.p, g1.e.p, g0.e.p, s2.ih.p, s2.it.p, s2.du.p, s2.dv.p, kpn, gp, q0p, q1p);
+  ssim_stage_c(g2.a.s, g1.a.s, g0.a.s, g2.b.s, g1.b.s, g0.b.s, g2.e.s, g1.e.s, g0.e.s, s2.ih.s, s2.it.s, s2.du.s, s2.dv.s, kpn, gs, q0s, q1s);
+  const float gI[3] = {gp.x, gp.y, gs};
+  geometry_backward(C, s2, rc, vhadd(q0p) + q0s, vhadd(q1p) + q1s, gI, gacc, first, gpm);
+}
+
 template <bool GRAD, bool LOSS, bool HWC>
 __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const int r, const int rend, Pipe& ps, float& disp_next,
                                               RowS& s0, const RowS& s1, const RowS& s2,
@@ -336,7 +401,7 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const int r, con
   SFM_STAMP(t1);
   const int rn = r + 1, rnn = r + 2;
   if ((unsigned)rn < (unsigned)rend) issue_row<HWC>(C, rn, disp_next, ps);     // rend = min(last row of the pass + 1, h) > 0
-  if ((unsigned)rnn < (unsigned)rend) disp_next = C.dp[(unsigned)rnn * (unsigned)w + C.xc];
+  if ((unsigned)rnn < (unsigned)rend) disp_next = ldf(C.dp, (unsigned)rnn * (unsigned)w + C.xc);
   SFM_STAMP(t2);
 
   // ---------------- B: SSIM at row r-1 ----------------
@@ -349,16 +414,7 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const int r, con
 #else
   if (rb >= C.y0 - (GRAD ? 1 : 0)) {
 #endif
-    float ssum = 0.f;
-    const float kq_nm = C.kq * s1.nm;   // kappa before the clip test; s1.nm is 0 outside the image and on masked pixels (:114)
-    ssim_stage_b<GRAD, LOSS>(s2.ih.p, s1.ih.p, s0.ih.p, s2.it.p, s1.it.p, s0.it.p, kq_nm, g0.a.p, g0.b.p, g0.e.p, ssum);
-    ssim_stage_b<GRAD, LOSS>(s2.ih.s, s1.ih.s, s0.ih.s, s2.it.s, s1.it.s, s0.it.s, kq_nm, g0.a.s, g0.b.s, g0.e.s, ssum);
-    if (LOSS) {   // branch-free: a halo row simply gets weight 0 (a branch here would split the block and un-fold the DPP adds)
-      const float wgt = ((unsigned)(rb - C.y0) < (unsigned)(C.y1 - C.y0)) ? s1.nm * C.outf : 0.f;
-      acc_ssim = fmaf(ssum, wgt, acc_ssim);                            // base_model.py:114-115
-      const float e1 = vabs_sum(s1.ih.p - s1.it.p) + vabs_sum(s1.ih.s - s1.it.s);   // :95
-      acc_pix = fmaf(e1, wgt, acc_pix);                                // :98-100,:111
-    }
+    ssim_stage_b_row<GRAD, LOSS>(C, s2, s1, s0, g0, (unsigned)(rb - C.y0) < (unsigned)(C.y1 - C.y0), acc_pix, acc_ssim);
   }
 
   SFM_STAMP(t3);
@@ -370,13 +426,7 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const int r, con
 #else
     if ((unsigned)(rc - C.y0) < (unsigned)(C.y1 - C.y0)) {
 #endif
-      const float kpn = C.k_pix * s2.nm;
-      f2 gp, q0p, q1p;
-      float gs, q0s, q1s;
-      ssim_stage_c(g2.a.p, g1.a.p, g0.a.p, g2.b.p, g1.b.p, g0.b.p, g2.e.p, g1.e.p, g0.e.p, s2.ih.p, s2.it.p, s2.du.p, s2.dv.p, kpn, gp, q0p, q1p);
-      ssim_stage_c(g2.a.s, g1.a.s, g0.a.s, g2.b.s, g1.b.s, g0.b.s, g2.e.s, g1.e.s, g0.e.s, s2.ih.s, s2.it.s, s2.du.s, s2.dv.s, kpn, gs, q0s, q1s);
-      const float gI[3] = {gp.x, gp.y, gs};
-      geometry_backward(C, s2, rc, vhadd(q0p) + q0s, vhadd(q1p) + q1s, gI, gacc, first, gpm);
+      ssim_stage_c_row(C, rc, s2, g2, g1, g0, gacc, first, gpm);
     }
   }
   SFM_STAMP(t4);
@@ -406,8 +456,8 @@ __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, 
   Pipe ps;
   float disp_next = 1.f;
   // prologue: row rbeg in flight, disparity of row rbeg+1 loaded
-  if (rbeg >= 0 && rbeg < C.h) issue_row<HWC>(C, rbeg, C.dp[(unsigned)rbeg * (unsigned)C.w + C.xc], ps);
-  if (rbeg + 1 >= 0 && rbeg + 1 < C.h) disp_next = C.dp[(unsigned)(rbeg + 1) * (unsigned)C.w + C.xc];
+  if (rbeg >= 0 && rbeg < C.h) issue_row<HWC>(C, rbeg, ldf(C.dp, (unsigned)rbeg * (unsigned)C.w + C.xc), ps);
+  if (rbeg + 1 >= 0 && rbeg + 1 < C.h) disp_next = ldf(C.dp, (unsigned)(rbeg + 1) * (unsigned)C.w + C.xc);
   for (int r = rbeg; r < rend; r += 3) {
     ssim_row_step<GRAD, LOSS, HWC>(C, r, rload, ps, disp_next, S0, S2, S1, G0, G2, G1, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
     if (r + 1 < rend)
@@ -430,14 +480,14 @@ __device__ __forceinline__ void l1_source_pass(const SsimCtx& C, float* gacc, co
   ps.lg = 0.f;
   float disp_next = 1.f;
   const int rbeg = C.y0, rend = C.y1;    // rows of a chunk are always inside the image
-  issue_row<HWC>(C, rbeg, C.dp[(unsigned)rbeg * (unsigned)C.w + C.xc], ps);
-  if (rbeg + 1 < rend) disp_next = C.dp[(unsigned)(rbeg + 1) * (unsigned)C.w + C.xc];
+  issue_row<HWC>(C, rbeg, ldf(C.dp, (unsigned)rbeg * (unsigned)C.w + C.xc), ps);
+  if (rbeg + 1 < rend) disp_next = ldf(C.dp, (unsigned)(rbeg + 1) * (unsigned)C.w + C.xc);
   for (int r = rbeg; r < rend; ++r) {
     RowS s0;
     finish_row(C, ps, s0);
     const float lg = ps.lg;
     if (r + 1 < rend) issue_row<HWC>(C, r + 1, disp_next, ps);
-    disp_next = C.dp[(unsigned)min(r + 2, C.h - 1) * (unsigned)C.w + C.xc];
+    disp_next = ldf(C.dp, (unsigned)min(r + 2, C.h - 1) * (unsigned)C.w + C.xc);
     float sgm = 1.f;
     if (EXPL) {
       sgm = rcp(1.0f + __expf(-lg));                                  // F.sigmoid, base_model.py:107
@@ -454,7 +504,7 @@ __device__ __forceinline__ void l1_source_pass(const SsimCtx& C, float* gacc, co
       const float gq1 = vhadd(gp * s0.dv.p) + gs * s0.dv.s;
       if (EXPL) {
         // d/dlogit of (1-alpha) mean(err sigmoid) + exp_reg mean(softplus(-logit))
-        if (C.outf != 0.f) C.dmp[(unsigned)r * (unsigned)C.w + C.xc] = C.k_pix * e1 * sgm * (1.f - sgm) + C.k_exp * (sgm - 1.f);
+        if (C.outf != 0.f) stf(C.dmp, (unsigned)r * (unsigned)C.w + C.xc, C.k_pix * e1 * sgm * (1.f - sgm) + C.k_exp * (sgm - 1.f));
       }
       geometry_backward(C, s0, r, gq0, gq1, gI, gacc, first, gpm);
     }

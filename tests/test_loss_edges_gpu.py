@@ -93,20 +93,15 @@ def test_extreme_disparities(ops, synth, dev):
 
 
 def test_high_resolution_config5_shape(ops, synth, dev):
-    """BASELINE.json configs[4]: 256x832, 4 scales, 5-frame snippet (4 sources), at B=1"""
+    """BASELINE.json configs[4]: 256x832, 4 scales, 5-frame snippet (4 sources), at B=1.  d_pose sums 283k signed per-pixel
+    terms whose magnitudes exceed the sum by orders of magnitude, so fp32 evaluations of the SAME formula differ at the 1e-3
+    level (the fp32 oracle included): where the flat criterion is missed the fp64 oracle decides (_judged64)."""
     d = synth.make_inputs(B=1, H=256, W=832, n_src=4, n_scales=4, seed=1)
     ref = _oracle(d, CFG)
     fl = _bind(ops, dev, d, CFG, layout="hwc")
     _check_losses(fl.forward_backward(), ref)
-    _check_grads(fl, ref, 4, check_pose=False)
-    # d_pose sums 283k signed per-pixel terms whose magnitudes exceed the sum by orders of magnitude, so fp32
-    # evaluations of the SAME formula differ at the 1e-3 level (the fp32 oracle included): judge the kernel
-    # against the fp64 oracle, allowing twice the fp32 oracle's own error
-    ref64 = O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], backward=True, dtype=np.float64, **CFG)
-    for i in range(4):
-        got, w32, w64 = to_np(fl.d_poses[i]).astype(np.float64), ref["d_poses"][i], ref64["d_poses"][i]
-        tol = np.maximum(2e-3 * np.abs(w64).max(), 2 * np.abs(w32 - w64))
-        assert (np.abs(got - w64) <= tol).all(), (i, got, w64, w32)
+    ref64 = lambda: O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], backward=True, dtype=np.float64, **CFG)
+    _check_grads(fl, ref, 4, what="cfg5 B=1", ref64=ref64)
 
 
 def _random_cases(n, seed=2024):
@@ -156,4 +151,6 @@ def test_random_shapes_and_modes(ops, synth, dev, B, H, W, n_src, n_scales, cfg_
     fl = _bind(ops, dev, d, cfg, layout="hwc" if seed % 2 else "planar")     # both image layouts take part in the sweep
     _check_losses(fl.forward(), ref, slack=flip_reach)
     _check_losses(fl.forward_backward(), ref, slack=flip_reach)
-    _check_grads(fl, ref, n_src, check_mask=bool(cfg.get("exp_reg")), what="sweep %s %dx%d" % (cfg_name, H, W))
+    ref64 = lambda: O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], d["masks"], backward=True,
+                               dtype=np.float64, **cfg)
+    _check_grads(fl, ref, n_src, check_mask=bool(cfg.get("exp_reg")), what="sweep %s %dx%d" % (cfg_name, H, W), ref64=ref64)

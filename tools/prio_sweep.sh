@@ -1,8 +1,6 @@
 #!/bin/bash
-# usage: tools/prio_sweep.sh "012,210" "102,210" ... : fused main-kernel time for issue-priority tables (SFM_PRIO_TABLE), 200-step runs, 2 rounds
-for r in 1 2; do
+# usage (GPU box): tools/prio_sweep.sh "012,210" "013,310" ...  -- main-kernel time of the fused cfg3 launch per issue-priority table
+P=sfm-learner-chainer_amd
 for t in "$@"; do
-  out=$(SFM_PRIO_TABLE=$t timeout -k 10 120 python bench.py --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1)
-  echo "$t $(echo "$out" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print("ms_step=%.4f"%d["ms_per_step"], "main_us=%.2f" % (d["kernel_ms"]["fused_main"]*1e3))')"
-done
+  echo "$t $(SFM_PRIO_TABLE=$t timeout -k 10 120 python tools/ab_inproc.py --rounds 5 --iters 30 $P/libsfmwarp.so 2>&1 | tail -1 | sed 's/.*main kernel us: //')"
 done

@@ -7,7 +7,8 @@ PKG = "sfm-learner-chainer_amd"
 ops = importlib.import_module(PKG + ".ops"); synth = importlib.import_module(PKG + ".synth")
 mode = sys.argv[1] if len(sys.argv) > 1 else "fused"
 dev = torch.device("cuda:0")
-d = synth.make_inputs(B=32, H=128, W=416, n_src=2, n_scales=4, seed=1)
+TB, TH, TW, TS = [int(v) for v in os.environ.get("SFM_TRACE_SHAPE", "32,128,416,2").split(",")]
+d = synth.make_inputs(B=TB, H=TH, W=TW, n_src=TS, n_scales=4, seed=1)
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 layout = os.environ.get("SFM_LAYOUT", "hwc")
 cv = (lambda a: ops.to_hwc(t(a))) if layout == "hwc" else t
@@ -23,13 +24,24 @@ nz = int((raw != 0).any(axis=1).sum())
 if os.environ.get("SFM_TRACE_DUMP"):
     np.save(os.environ["SFM_TRACE_DUMP"], raw[:nz])
 stamps = os.environ.get("SFMWARP_LIB", "").endswith("stamps.so")
-n_items = nz // 3 if stamps else nz
+SW = int(os.environ.get('SFM_STAMP_WORDS', '12'))
+n_items = int(os.environ['SFM_TRACE_ITEMS']) if 'SFM_TRACE_ITEMS' in os.environ else (nz // (1 + SW // 4) if stamps else nz)
 a = raw[:n_items]
 t0 = a[:, 0].min()
 st = (a[:, 0] - t0) / 100.0; en = (a[:, 1] - t0) / 100.0   # microseconds
-hw = a[:, 2]; xcc = a[:, 3] & 0xf
+hw = a[:, 2]; xcc = a[:, 3] & 0xf; wg = (a[:, 3] >> 8) & 0xffffffff; wv = (a[:, 3] >> 40) & 0xff
 simd = (hw >> 4) & 3; cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
 key = xcc * 100000 + se * 10000 + sh * 1000 + cu * 10 + simd
+if os.environ.get("SFM_TRACE_PLACEMENT"):
+    cukey = xcc * 100000 + se * 10000 + sh * 1000 + cu * 10
+    for x in range(1):
+        m = xcc == x
+        print("XCD %d: workgroup (loc = blockIdx >> 3) -> CU placement, first 12 CUs:" % x)
+        for ck in np.unique(cukey[m])[:12]:
+            mm = m & (cukey == ck)
+            locs = sorted(set((wg[mm] >> 3).tolist()))
+            print("   CU", ck, "locs", locs, "waves per SIMD", np.bincount(simd[mm], minlength=4).tolist(),
+                  " wave->simd of first wg", [(int(w_), int(s_)) for w_, s_ in zip(wv[mm & ((wg >> 3) == locs[0])], simd[mm & ((wg >> 3) == locs[0])])])
 print("items", len(a), "kernel span %.1f us" % en.max(), " wave duration: mean %.1f  min %.1f  max %.1f us" % ((en - st).mean(), (en - st).min(), (en - st).max()))
 print("start times: p50 %.1f p90 %.1f p99 %.1f max %.1f us" % tuple(np.percentile(st, [50, 90, 99, 100])))
 u, cnt = np.unique(key, return_counts=True)
@@ -48,11 +60,30 @@ late = st > 5
 print("waves starting after 5us: %d ; their mean duration %.1f ; early waves mean duration %.1f" % (late.sum(), (en - st)[late].mean() if late.any() else 0, (en - st)[~late].mean()))
 if os.environ.get("SFMWARP_LIB", "").endswith("stamps.so"):
     n = n_items
-    b = raw.reshape(-1)[n * 4: n * 4 + n * 8].reshape(n, 8).astype(np.float64)
-    steps = b[:, 4].sum()
-    print("cycles per row step (mean over all waves): A.finish %.0f  A.issue %.0f  B %.0f  C %.0f   total %.0f ; smoothness pass per wave %.0f cycles" % (
+    b = raw.reshape(-1)[n * 4: n * 4 + n * SW].reshape(n, SW).astype(np.float64)
+    steps = max(b[:, 4].sum(), 1.0)
+    if os.environ.get("SFM_QUAD_STAMPS", "1") != "1": print("cycles per row step (mean over all waves): A.finish %.0f  A.issue %.0f  B %.0f  C %.0f   total %.0f ; smoothness pass per wave %.0f cycles" % (
         b[:, 0].sum() / steps, b[:, 1].sum() / steps, b[:, 2].sum() / steps, b[:, 3].sum() / steps, b[:, :4].sum() / steps, b[:, 5].mean()))
-if stamps:
+if stamps and os.environ.get("SFM_QUAD_STAMPS", "1") == "1":
+    # quad kernels: b[:,0..3] = cycles waited for the partner at start-S, start-G, finish-S, finish-G; b[:,4] = steady loops
+    dur_cyc = b[:, 7]
+    dur_us = (a[:, 1] - a[:, 0]).astype(np.float64) / 100.0
+    print("in-kernel clock: median %.3f GHz" % np.median(dur_cyc / dur_us / 1e3))
+    order = np.zeros(n, int)
+    for kk in np.unique(key):
+        idx = np.where(key == kk)[0]
+        order[idx[np.argsort(en[idx])]] = np.arange(len(idx))
+    big = dur_cyc > np.percentile(dur_cyc, 30)          # the waves of the two large scales
+    for rk in range(3):
+        m = (order == rk) & big
+        if m.any():
+            print("finish-rank %d: n=%d wave %.0fk cyc = source passes %.0fk [steady loops %.0fk; waits: start-S %.1fk start-G %.1fk finish-S %.1fk finish-G %.1fk; "
+                  "head %.1fk finish %.1fk pose sums %.1fk set-up %.1fk] + smoothness %.0fk + start-up/write-out %.0fk" % (
+                rk, m.sum(), dur_cyc[m].mean() / 1e3, b[m, 6].mean() / 1e3, b[m, 4].mean() / 1e3, b[m, 0].mean() / 1e3, b[m, 1].mean() / 1e3,
+                b[m, 2].mean() / 1e3, b[m, 3].mean() / 1e3, (b[m, 8] - b[m, 0] - b[m, 1]).mean() / 1e3, (b[m, 9] - b[m, 2] - b[m, 3]).mean() / 1e3, b[m, 10].mean() / 1e3,
+                (b[m, 6] - b[m, 4] - b[m, 8] - b[m, 9] - b[m, 10]).mean() / 1e3, b[m, 5].mean() / 1e3,
+                (dur_cyc[m] - b[m, 5] - b[m, 6]).mean() / 1e3))
+elif stamps:
     dur_cyc = b[:, 7]                                           # whole wave, shader cycles (s_memtime)
     dur_us = (a[:, 1] - a[:, 0]).astype(np.float64) / 100.0     # the same span in 100 MHz ticks
     print("in-kernel clock (wave cycles / wave time): median %.3f GHz" % np.median(dur_cyc / dur_us / 1e3))
