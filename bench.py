@@ -509,8 +509,8 @@ def main():
                                           "bytes_per_launch_fetch_x2": round(kv["hbm_bytes_fetch_x2"]),
                                           "source": "profiles/%s_summary.json (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes; "
                                                     "KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md, uncalibrated for 4-12 B/lane loads)" % tag}
-                        if "SQ_INSTS_VALU" in kv.get("pmc", {}):
-                            valu = float(kv["pmc"]["SQ_INSTS_VALU"])
+                        if "SQ_INSTS_VALU" in kv.get("counters_per_launch", {}):
+                            valu = float(kv["counters_per_launch"]["SQ_INSTS_VALU"])
         except Exception:
             traffic = traffic_detail = valu = None
         roofline = {

@@ -9,7 +9,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 raw = os.path.join(ROOT, "gpurun_out", "profiles_raw", tag)
 out = os.path.join(ROOT, "profiles")
 os.makedirs(out, exist_ok=True)
@@ -63,8 +63,9 @@ for k in main:
     summary["kernels"].setdefault(k, {}).update(t)
 json.dump(summary, open(os.path.join(out, "%s_summary.json" % tag), "w"), indent=1, sort_keys=True)
 with open(os.path.join(out, "%s_summary.md" % tag), "w") as f:
-    f.write("# rocprofv3 summary %s\n\ncommand: `python bench.py --steps 50 --warmup 10 --mode %s` under `rocprofv3 --kernel-trace --stats` "
-            "(kernel durations) and separate `--pmc` passes (counters)\n\n" % (tag, bench["config"]["mode"]))
+    f.write("# rocprofv3 summary %s\n\ncommand: `python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --mode %s` under "
+            "`rocprofv3 --kernel-trace --stats` (kernel durations; %d blocks of 20 timed steps) and separate `--pmc` passes (counters, 6-step runs)\n\n" % (
+                tag, bench["config"]["mode"], bench.get("timing", {}).get("blocks", 1)))
     f.write("bench line inside the profiler: value %.0f %s, %.4f ms/step, dominant kernel %.2f us by HIP events\n\n" % (
         bench["value"], bench["unit"], bench["ms_per_step"], bench["roofline"]["kernel_ms"] * 1e3))
     f.write("| kernel | calls | avg us | % |\n|---|---|---|---|\n")
