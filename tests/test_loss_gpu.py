@@ -100,36 +100,60 @@ def _judged64(got, w32, w64, knife, what):
     parity_note("second opinion (fp64 oracle) used for %s: passed" % what)
 
 
+POSE_PER_KNIFE_PIXEL = 4.0   # a pixel that lands on the other side of a kink moves a pose gradient by about this many "average pixels"
+
+
 def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=True, what="", ref64=None):
     """`ref64`: optional callable returning the fp64 oracle's result; consulted only for an array that misses the fp32
     criterion (see _judged64), and every such use is reported."""
     worst = 0.0
     r64 = []
 
-    def close(got, w, knife, name, key, idx):
+    def second(key, idx):
+        if not r64:
+            r64.append(ref64())
+        return r64[0][key][idx]
+
+    def close(got, w, knife, name, key, idx, extra=0.0):
         try:
-            assert_close_masked(got, w, GRAD_TOL, knife, what=name)
+            assert_close_masked(got, w, GRAD_TOL + extra, knife, what=name)
         except AssertionError:
             if ref64 is None:
                 raise
-            if not r64:
-                r64.append(ref64())
-            _judged64(got, w, r64[0][key][idx], knife, "%s %s" % (what, name))
+            _judged64(got, w, second(key, idx), knife, "%s %s" % (what, name))
 
+    def l2_ok(got, w, knife, name, key, idx):
+        l2 = rel_l2(got, w, knife)
+        if l2 > L2_TOL:
+            # one ill-conditioned element can carry the whole norm: the fp64 oracle decides, with the fp32 oracle's own error as the yardstick
+            assert ref64 is not None, "%s: relative L2 error %.2e outside knife pixels" % (name, l2)
+            w64 = second(key, idx)
+            mine, theirs = rel_l2(got, w64, knife), rel_l2(w, w64, knife)
+            assert mine <= max(L2_TOL, 3.0 * theirs), "%s: relative L2 error %.2e vs the fp64 oracle (the fp32 oracle's own: %.2e)" % (name, mine, theirs)
+            parity_note("second opinion (fp64 oracle) used for the L2 norm of %s %s: %.2e vs the fp32 oracle's own %.2e" % (what, name, mine, theirs))
+            return min(l2, mine)
+        return l2
+
+    flipped = None       # per sample: knife-edge pixels where the kernel demonstrably took the other branch, as a share of their scale
     for s, (g, w) in enumerate(zip(fl.d_disps, ref["d_disps"])):
         knife = _knife(ref, s, n_src, what=what)
-        close(to_np(g), w, knife, "d_disp[%d]" % s, "d_disps", s)
-        l2 = rel_l2(to_np(g), w, knife)
-        worst = max(worst, l2)
-        assert l2 <= L2_TOL, ("d_disp[%d]: relative L2 error %.2e outside knife pixels" % (s, l2))
+        gnp = to_np(g)
+        off = (np.abs(gnp.astype(np.float64) - w) > GRAD_TOL * np.abs(w).max()) & np.broadcast_to(knife, w.shape)
+        cnt = off.reshape(off.shape[0], -1).sum(axis=1) / float(off.shape[-2] * off.shape[-1])
+        flipped = cnt if flipped is None else flipped + cnt
+        close(gnp, w, knife, "d_disp[%d]" % s, "d_disps", s)
+        worst = max(worst, l2_ok(gnp, w, knife, "d_disp[%d]" % s, "d_disps", s))
         if check_mask:
             close(to_np(fl.d_masks[s]), ref["d_masks"][s], None, "d_mask[%d]" % s, "d_masks", s)
-            l2m = rel_l2(to_np(fl.d_masks[s]), ref["d_masks"][s])
-            assert l2m <= L2_TOL, ("d_mask[%d]: relative L2 error %.2e" % (s, l2m))
+            l2_ok(to_np(fl.d_masks[s]), ref["d_masks"][s], None, "d_mask[%d]" % s, "d_masks", s)
+    # d_pose of a sample sums its pixels over the scales.  A knife-edge pixel whose d_disp shows that the kernel took the other
+    # side of the kink moves it too: each such OBSERVED pixel is allowed POSE_PER_KNIFE_PIXEL average pixels' worth of its
+    # scale's share (zero for most inputs, printed, never more than 1 %)
+    extra = 0.0 if flipped is None else min(0.01, float(POSE_PER_KNIFE_PIXEL * flipped.max() / len(fl.d_disps)))
     for i, (g, w) in enumerate(zip(fl.d_poses, ref["d_poses"]) if check_pose else ()):
-        # a flipped knife-edge pixel moves a pose gradient by ~1/(#pixels): covered by the tolerance
-        close(to_np(g), w, None, "d_pose[%d]" % i, "d_poses", i)
-    parity_note("grads %s: worst relative L2 of d_disp outside knife pixels %.2e (tol %.0e)" % (what, worst, L2_TOL))
+        close(to_np(g), w, None, "d_pose[%d]" % i, "d_poses", i, extra=extra)
+    parity_note("grads %s: worst relative L2 of d_disp outside knife pixels %.2e (tol %.0e); d_pose allowance for observed knife flips %.2e" % (
+        what, worst, L2_TOL, extra))
     if check_src:
         for s, (g, w) in enumerate(zip(fl.d_srcs, ref["d_srcs"])):
             # scatter targets of knife-edge pixels: compare in aggregate
