@@ -10,7 +10,9 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every call is
  *     asynchronous with respect to the host, re-entrant, and keeps no global mutable state
  *     (the reference's module globals `filler` / `meshgrid`, models/transform.py:62,135, are
- *     deliberately not reproduced);
+ *     deliberately not reproduced).  Per THREAD the library remembers the launch plans of the last
+ *     four distinct (descriptor bytes, device, entry point) combinations of sfm_loss_*: host-side
+ *     integers only, no device memory, never a pointer that is used without being passed in again;
  *   - return value: 0 on success; SFM_ERR_* (<0) for a rejected argument; a positive value is
  *     a hipError_t from the launch.  sfm_last_error() returns a thread-local message.
  *     No exception or abort crosses the ABI.
