@@ -141,6 +141,23 @@ __device__ __forceinline__ void zero(RowS& s) {
   s.U = s.V = s.D = s.nm = 0.f;
 }
 __device__ __forceinline__ void zero(RowG& s) { s.a = s.b = s.e = ch3_zero(); }
+// The same zeros, but produced by instructions the compiler must leave where they are written.  The ring slot of a row
+// outside the image is zero; written as plain assignments, LLVM materialises the 16 zeros in FRONT of the (wave-uniform)
+// branch that separates such rows from ordinary ones, i.e. 16 v_mov per row step of every row (5 % of the vector
+// instructions of a step), for a case that only the top and bottom chunks of an image ever see.
+__device__ __forceinline__ float opaque_zero() {
+  float z;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+  return z;
+}
+__device__ __forceinline__ Ch3 ch3_opaque_zero() {
+  const float a = opaque_zero(), b = opaque_zero(), c = opaque_zero();
+  return ch3(a, b, c);
+}
+__device__ __forceinline__ void zero_rare(RowS& s) {
+  s.ih = ch3_opaque_zero(); s.it = ch3_opaque_zero(); s.du = ch3_opaque_zero(); s.dv = ch3_opaque_zero();
+  s.U = opaque_zero(); s.V = opaque_zero(); s.D = opaque_zero(); s.nm = opaque_zero();
+}
 
 // stage A, first half: project row r and issue its loads (row r is inside the image)
 // three consecutive floats with one 12-byte load; only 4-byte alignment is guaranteed
@@ -397,7 +414,7 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const int r, con
   // ---------------- A: finish row r, put row r+1 in flight ----------------
   // (range tests as ONE unsigned compare each: the row step runs at the issue limit of its wave, scalar instructions included)
   if ((unsigned)r < (unsigned)h) finish_row(C, ps, s0);
-  else zero(s0);
+  else zero_rare(s0);
   SFM_STAMP(t1);
   const int rn = r + 1, rnn = r + 2;
   if ((unsigned)rn < (unsigned)rend) issue_row<HWC>(C, rn, disp_next, ps);     // rend = min(last row of the pass + 1, h) > 0
