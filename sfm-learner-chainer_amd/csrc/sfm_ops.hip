@@ -320,31 +320,57 @@ __global__ void sampler_fwd_kernel(const float* __restrict__ x, const float* __r
   }
 }
 
+// gx is a scatter: every output pixel adds to its four taps.  In a warp field most pixels have the next lane's cell right
+// beside their own (same tap row, next tap column), so the right-hand taps of lane l and the left-hand taps of lane l+1
+// are the same two addresses: lane l takes the neighbour's share along (DPP shift) and the neighbour skips those two
+// atomics.  Half the atomics on smooth grids, the same number on random ones; which lanes pair up depends only on the
+// grid, not on timing.
+__device__ __forceinline__ int int_from_left(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ int int_from_right(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x130, 0xf, 0xf, true); }
+
 __global__ void sampler_bwd_kernel(const float* __restrict__ x, const float* __restrict__ grid, const float* __restrict__ gy,
                                    float* __restrict__ ggrid, float* __restrict__ gx, int C, int H, int W, int oP) {
   const int n = blockIdx.y;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= oP) return;
+  const int jj = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = jj < oP;          // no early exit: the lanes of a wave exchange values below
+  const int j = valid ? jj : oP - 1;
+  const int lane = threadIdx.x & 63;
   const PadTap t = pad_taps(grid[((size_t)n * 2 + 0) * oP + j], grid[((size_t)n * 2 + 1) * oP + j], H, W);
+  const int u = t.u0, v = t.v0;
+  // pairing: my right-hand column is the neighbour's left-hand column, in the same pair of rows
+  const int nu = int_from_right(u), nv = int_from_right(v), nvalid = int_from_right(valid ? 1 : 0);
+  const bool take_right = (gx != nullptr) && valid && lane != 63 && nvalid != 0 && nv == v && nu == u + 1;
+  const bool skip_left = int_from_left(take_right ? 1 : 0) != 0;     // lane 0 receives 0
+  const bool in_u0 = u >= 1 && u <= W, in_u1 = u + 1 >= 1 && u + 1 <= W;
+  const bool in_v0 = v >= 1 && v <= H, in_v1 = v + 1 >= 1 && v + 1 <= H;
   float gu = 0.f, gv = 0.f;
   for (int c = 0; c < C; ++c) {
     const float* img = x + ((size_t)n * C + c) * H * W;
-    const float g = gy[((size_t)n * C + c) * oP + j];
-    const float x1 = pad_read(img, t.v0, t.u0, H, W), x2 = pad_read(img, t.v0, t.u0 + 1, H, W);
-    const float x3 = pad_read(img, t.v0 + 1, t.u0, H, W), x4 = pad_read(img, t.v0 + 1, t.u0 + 1, H, W);
+    const float g = valid ? gy[((size_t)n * C + c) * oP + j] : 0.f;
+    const float x1 = pad_read(img, v, u, H, W), x2 = pad_read(img, v, u + 1, H, W);
+    const float x3 = pad_read(img, v + 1, u, H, W), x4 = pad_read(img, v + 1, u + 1, H, W);
     gu += g * (-t.wy0 * x1 + t.wy0 * x2 - t.wy1 * x3 + t.wy1 * x4);
     gv += g * (-t.wx0 * x1 - t.wx1 * x2 + t.wx0 * x3 + t.wx1 * x4);
-    if (gx) {
+    if (gx) {   // uniform
       float* o = gx + ((size_t)n * C + c) * H * W;
-      const int u = t.u0, v = t.v0;
-      if (u >= 1 && u <= W && v >= 1 && v <= H) atomicAdd(o + (v - 1) * W + (u - 1), g * t.wx0 * t.wy0);
-      if (u + 1 >= 1 && u + 1 <= W && v >= 1 && v <= H) atomicAdd(o + (v - 1) * W + u, g * t.wx1 * t.wy0);
-      if (u >= 1 && u <= W && v + 1 >= 1 && v + 1 <= H) atomicAdd(o + v * W + (u - 1), g * t.wx0 * t.wy1);
-      if (u + 1 >= 1 && u + 1 <= W && v + 1 >= 1 && v + 1 <= H) atomicAdd(o + v * W + u, g * t.wx1 * t.wy1);
+      const float a00 = g * t.wx0 * t.wy0, a10 = g * t.wx0 * t.wy1;
+      float a01 = g * t.wx1 * t.wy0, a11 = g * t.wx1 * t.wy1;
+      const float n00 = from_right(a00), n10 = from_right(a10);   // the neighbour's left-hand shares
+      if (take_right) { a01 += n00; a11 += n10; }
+      if (valid) {
+        if (!skip_left) {
+          if (in_u0 && in_v0) atomicAdd(o + (v - 1) * W + (u - 1), a00);
+          if (in_u0 && in_v1) atomicAdd(o + v * W + (u - 1), a10);
+        }
+        if (in_u1 && in_v0) atomicAdd(o + (v - 1) * W + u, a01);
+        if (in_u1 && in_v1) atomicAdd(o + v * W + u, a11);
+      }
     }
   }
-  ggrid[((size_t)n * 2 + 0) * oP + j] = t.ok_u ? gu * ((float)(W - 1) * 0.5f) : 0.f;
-  ggrid[((size_t)n * 2 + 1) * oP + j] = t.ok_v ? gv * ((float)(H - 1) * 0.5f) : 0.f;
+  if (valid) {
+    ggrid[((size_t)n * 2 + 0) * oP + j] = t.ok_u ? gu * ((float)(W - 1) * 0.5f) : 0.f;
+    ggrid[((size_t)n * 2 + 1) * oP + j] = t.ok_v ? gv * ((float)(H - 1) * 0.5f) : 0.f;
+  }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -126,6 +126,29 @@ def test_normalized_sampler_fwd_bwd(ops, dev, shape):
     np.testing.assert_allclose(to_np(gx), wgx, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 16, 52), (1, 2, 37, 70), (3, 3, 128, 416)])
+def test_normalized_sampler_bwd_on_warp_fields(ops, dev, shape):
+    """The grids this sampler sees in the path (models/transform.py:189): the identity lattice plus a smooth displacement.
+    Here most lanes share a tap column with their neighbour and sampler_bwd merges the two contributions before the atomic
+    add: row ends, image borders (the zero-pad ring) and the last, partial wavefront of a plane are all in these cases."""
+    N, C, H, W = shape
+    rng = np.random.RandomState(6)
+    x = rng.uniform(-1, 1, size=(N, C, H, W)).astype(np.float32)
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    grid = np.empty((N, 2, H, W), np.float32)
+    for n in range(N):
+        fu = 3.0 * np.sin(yy / 7.0 + n) + 2.0 * np.cos(xx / 11.0) + 0.37 - 1.5 * n      # a few pixels, leaves the image at the borders
+        fv = 2.0 * np.cos(yy / 5.0) - 1.5 * np.sin(xx / 9.0 + n) + 0.61
+        grid[n, 0] = (xx + fu) / (W - 1) * 2 - 1
+        grid[n, 1] = (yy + fv) / (H - 1) * 2 - 1
+    gy = rng.normal(size=(N, C, H, W)).astype(np.float32)
+    wgx, wgg = O.spatial_transformer_sampler_backward(x, grid, gy)
+    gx, gg = ops.sampler_bwd(to_dev(x, dev), to_dev(grid, dev), to_dev(gy, dev))
+    # (ggrid is the image gradient times (W-1)/2: a difference of cancelling products, scaled up)
+    np.testing.assert_allclose(to_np(gg), wgg, rtol=1e-4, atol=1e-5 * np.abs(wgg).max())
+    np.testing.assert_allclose(to_np(gx), wgx, rtol=1e-4, atol=2e-5)
+
+
 def test_interp_equals_normalized_sampler_in_range(ops, dev):
     """SURVEY.md §8(c) pin (4): A8 == A8' on in-range coordinates after normalise -> pixel."""
     rng = np.random.RandomState(3)
