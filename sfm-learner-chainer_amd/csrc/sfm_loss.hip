@@ -103,9 +103,10 @@ __global__ void geom_kernel(const LossArgs A) {
 // ------------------------------------------------------------------------------------------
 // smoothness passes (one per wave, before the sources)
 // ------------------------------------------------------------------------------------------
-// the wave-private d_disp tile: the first contribution of a wave is a plain store, later ones are LDS adds
+// the wave-private d_disp tile: the first contribution of a wave is a plain store, later ones read-add-write
+// (see geometry_backward: ds_add_f32 is the slower way)
 __device__ __forceinline__ void tile_put(float* p, const float v, const bool add) {
-  if (add) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  if (add) *p = *p + v;
   else *p = v;
 }
 

@@ -257,10 +257,10 @@ __device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& 
   const float gD = fmaf(gq0, a0, fmaf(gq1, a1, gq2 * a2));
   const float gdisp = -gD * s2.D * s2.D;                         // d(1/d) = -1/d^2, base_model.py:60
   float* ga = gacc + (rc - C.y0) * 64 + C.lane;
-  // the tile is private to this wave: a plain store for the first contribution, then LDS adds without return value
-  // (ds_add_f32: nothing to wait for, unlike a read-modify-write through a register)
+  // the tile is private to this wave: a plain store for the first contribution, then read-add-write through a register
+  // (an LDS add without return value, ds_add_f32, has nothing to wait for but costs the launch 3 % at cfg3: it is a slow LDS op)
   if (first) *ga = gdisp;
-  else (void)__hip_atomic_fetch_add(ga, gdisp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  else *ga = *ga + gdisp;
   // dL/dPm[k][j] = sum over pixels of gq_k * c_j with c = D * (K1 y + kx) (the back-projected point), c_3 = 1.  The ray
   // is linear in the row, so a lane only accumulates  A_k = sum gq_k D,  B_k = sum y gq_k D,  C_k = sum gq_k  (9 values
   // instead of 12) and expands them once per pass: gpm[k][j] = K1[j] B_k + kx[j] A_k, K1 = Kinv[:,1], kx = Kinv[:,0] x + Kinv[:,2]   (pose_sums_expand)
