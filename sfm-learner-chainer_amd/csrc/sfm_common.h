@@ -277,7 +277,11 @@ __device__ __forceinline__ Proj project_q(const float q0, const float q1, const 
   o.rz = rcp(z);
   o.U = div_r(q0, z, o.rz);                                     // transform.py:124
   o.V = div_r(q1, z, o.rz);                                     // transform.py:125
-  o.inview = (o.U > 0.0f) && (o.U < sc.wm1) && (o.V > 0.0f) && (o.V < sc.hm1);
+  // 0 < U < W-1 and 0 < V < H-1 as two sign tests: U (W-1-U) > 0 holds exactly for the finite U strictly inside (the
+  // difference is exact near W-1, the product cannot underflow for U > 1e-36, and NaN / infinities fail) -- two compares and one
+  // scalar AND instead of four compares chained through the exec mask
+  const float su = o.U * (sc.wm1 - o.U), sv = o.V * (sc.hm1 - o.V);
+  o.inview = (su > 0.0f) & (sv > 0.0f);
   const float uf = floorf(o.U), vf = floorf(o.V);
   o.fu = o.U - uf;
   o.fv = o.V - vf;

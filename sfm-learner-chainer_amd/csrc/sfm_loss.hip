@@ -27,7 +27,7 @@
 
 namespace sfm {
 
-constexpr int MAX_CHUNK_ROWS = 32;
+constexpr int MAX_CHUNK_ROWS = 28;   // + 4 halo rows = the 32 steps a pass can have (StepMasks)
 constexpr int MIN_CHUNK_ROWS = 4;
 constexpr int WAVES_PER_BLOCK = 1;   // independent wavefronts; grouped only so that a CU is filled with few workgroups
 

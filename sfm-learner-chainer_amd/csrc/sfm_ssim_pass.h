@@ -401,49 +401,69 @@ __device__ __forceinline__ void ssim_stage_c_row(const SsimCtx& C, const int rc,
   geometry_backward(C, s2, rc, vhadd(q0p) + q0s, vhadd(q1p) + q1s, gI, gacc, first, gpm);
 }
 
+// Which stages run on which step of a pass, as bit k of one 32-bit word per question (a pass has at most 32 steps): every
+// question is an interval of steps, the words are built once per pass, and a step asks with one s_bitcmp + branch.  (Asked
+// with row arithmetic -- add, compare, select, branch per question -- the six questions were a quarter of the scalar
+// instructions of a step, and a scalar instruction costs a wave as much issue time as a DPP add: profiles/r02_op_cost_microbench.txt.)
+struct StepMasks {
+  unsigned fin;    // row r of the step is inside the image: its gathers are in flight and are finished now
+  unsigned iss;    // row r+1 is fetched by this pass: put it in flight
+  unsigned b;      // stage B runs (centre row r-1)
+  unsigned cnt;    // ... and its loss terms belong to this wave (centre row inside the chunk)
+  unsigned c;      // stage C runs (row r-2 inside the chunk)
+};
+__device__ __forceinline__ unsigned step_range(int lo, int hi) {   // bits lo .. hi-1, clamped to 0 .. 32
+  lo = min(max(lo, 0), 32);
+  hi = min(max(hi, lo), 32);
+  const unsigned long long one = 1ull;
+  return (unsigned)(((one << hi) - 1ull) & ~((one << lo) - 1ull));
+}
+__device__ __forceinline__ bool step_bit(const unsigned m, const int k) { return ((m >> k) & 1u) != 0u; }
+
 template <bool GRAD, bool LOSS, bool HWC>
-__device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const int r, const int rend, Pipe& ps, float& disp_next,
+__device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const StepMasks& M, const int k, const int r, Pipe& ps, float& disp_next,
                                               RowS& s0, const RowS& s1, const RowS& s2,
                                               RowG& g0, const RowG& g1, const RowG& g2, float* gacc, const bool first,
                                               float& acc_pix, float& acc_ssim, float* gpm SFM_STAMPS_ARG) {
-  const int h = C.h, w = C.w;
+  const int w = C.w;
 #ifdef SFM_STAMPS
   unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
 #endif
   SFM_STAMP(t0);
   // ---------------- A: finish row r, put row r+1 in flight ----------------
-  // (range tests as ONE unsigned compare each: the row step runs at the issue limit of its wave, scalar instructions included)
-  if ((unsigned)r < (unsigned)h) finish_row(C, ps, s0);
-  else zero_rare(s0);
+  // (the arithmetic always runs -- on whatever the tap registers hold when the row lies outside the image -- and the rare case
+  // overwrites the slot: an if / else costs five more scalar instructions per step than an if)
+  finish_row(C, ps, s0);
+  if (!step_bit(M.fin, k)) zero_rare(s0);
   SFM_STAMP(t1);
-  const int rn = r + 1, rnn = r + 2;
-  if ((unsigned)rn < (unsigned)rend) issue_row<HWC>(C, rn, disp_next, ps);     // rend = min(last row of the pass + 1, h) > 0
-  if ((unsigned)rnn < (unsigned)rend) disp_next = ldf(C.dp, (unsigned)rnn * (unsigned)w + C.xc);
+  if (step_bit(M.iss, k)) {
+    issue_row<HWC>(C, r + 1, disp_next, ps);
+    // the disparity of the row after that; on the last fetched row of the pass the prefetch reads the image's last row again
+    disp_next = ldf(C.dp, (unsigned)min(r + 2, C.h - 1) * (unsigned)w + C.xc);
+  }
   SFM_STAMP(t2);
 
   // ---------------- B: SSIM at row r-1 ----------------
   // The first two steps of a pass only fill the ring: their centre rows lie above every row whose SSIM value
   // (forward) or SSIM partials (gradient, one more row) anything will read, so the whole stage is skipped
   // (wave-uniform branch).
-  const int rb = r - 1;
 #ifdef SFM_ABLATE_NO_B   // timing experiment only (wrong values)
   if (false) {
 #else
-  if (rb >= C.y0 - (GRAD ? 1 : 0)) {
+  if (step_bit(M.b, k)) {
 #endif
-    ssim_stage_b_row<GRAD, LOSS>(C, s2, s1, s0, g0, (unsigned)(rb - C.y0) < (unsigned)(C.y1 - C.y0), acc_pix, acc_ssim);
+    ssim_stage_b_row<GRAD, LOSS>(C, s2, s1, s0, g0, step_bit(M.cnt, k), acc_pix, acc_ssim);
   }
 
   SFM_STAMP(t3);
   // ---------------- C: gradients at row r-2 ----------------
   if (GRAD) {
-    const int rc = r - 2;
 #ifdef SFM_ABLATE_NO_C   // timing experiment only (wrong values)
     if (false) {
 #else
-    if ((unsigned)(rc - C.y0) < (unsigned)(C.y1 - C.y0)) {
+    if (step_bit(M.c, k)) {
 #endif
-      ssim_stage_c_row(C, rc, s2, g2, g1, g0, gacc, first, gpm);
+      ssim_stage_c_row(C, r - 2, s2, g2, g1, g0, gacc, first, gpm);
     }
   }
   SFM_STAMP(t4);
@@ -472,15 +492,25 @@ __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, 
   RowG G0, G1, G2;
   Pipe ps;
   float disp_next = 1.f;
-  // prologue: row rbeg in flight, disparity of row rbeg+1 loaded
+  // step k handles row r = rbeg + k: which stages it runs (see StepMasks)
+  const int n = rend - rbeg, R = C.y1 - C.y0;
+  StepMasks M;
+  M.fin = step_range(-rbeg, C.h - rbeg);
+  M.iss = step_range(-rbeg - 1, rload - rbeg - 1);
+  M.b = step_range(HS + 1 - (GRAD ? 1 : 0), n);
+  M.cnt = step_range(HS + 1, HS + 1 + R);
+  M.c = step_range(HS + 2, HS + 2 + R);
+  // prologue: row rbeg in flight, and the disparity of the first row the loop will put in flight (row rbeg + 1, or row 0 for
+  // the chunk at the top of the image: the steps before it fetch nothing and leave disp_next alone)
   if (rbeg >= 0 && rbeg < C.h) issue_row<HWC>(C, rbeg, ldf(C.dp, (unsigned)rbeg * (unsigned)C.w + C.xc), ps);
-  if (rbeg + 1 >= 0 && rbeg + 1 < C.h) disp_next = ldf(C.dp, (unsigned)(rbeg + 1) * (unsigned)C.w + C.xc);
-  for (int r = rbeg; r < rend; r += 3) {
-    ssim_row_step<GRAD, LOSS, HWC>(C, r, rload, ps, disp_next, S0, S2, S1, G0, G2, G1, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
-    if (r + 1 < rend)
-      ssim_row_step<GRAD, LOSS, HWC>(C, r + 1, rload, ps, disp_next, S1, S0, S2, G1, G0, G2, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
-    if (r + 2 < rend)
-      ssim_row_step<GRAD, LOSS, HWC>(C, r + 2, rload, ps, disp_next, S2, S1, S0, G2, G1, G0, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
+  disp_next = ldf(C.dp, (unsigned)min(max(rbeg + 1, 0), C.h - 1) * (unsigned)C.w + C.xc);
+  for (int k = 0; k < n; k += 3) {
+    const int r = rbeg + k;
+    ssim_row_step<GRAD, LOSS, HWC>(C, M, k, r, ps, disp_next, S0, S2, S1, G0, G2, G1, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
+    if (k + 1 < n)
+      ssim_row_step<GRAD, LOSS, HWC>(C, M, k + 1, r + 1, ps, disp_next, S1, S0, S2, G1, G0, G2, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
+    if (k + 2 < n)
+      ssim_row_step<GRAD, LOSS, HWC>(C, M, k + 2, r + 2, ps, disp_next, S2, S1, S0, G2, G1, G0, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
   }
   if (GRAD) pose_sums_expand(C, gpm, gpm_out);
 }
