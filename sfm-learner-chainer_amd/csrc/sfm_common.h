@@ -282,11 +282,11 @@ __device__ __forceinline__ Proj project_q(const float q0, const float q1, const 
   // scalar AND instead of four compares chained through the exec mask
   const float su = o.U * (sc.wm1 - o.U), sv = o.V * (sc.hm1 - o.V);
   o.inview = (su > 0.0f) & (sv > 0.0f);
-  const float uf = floorf(o.U), vf = floorf(o.V);
-  o.fu = o.U - uf;
-  o.fv = o.V - vf;
-  o.u0 = o.inview ? (int)uf : 0;     // in view => uf in [0, W-2]
-  o.v0 = o.inview ? (int)vf : 0;
+  // in view => U, V > 0: the fraction is v_fract (= U - floor(U), the same value) and the cell index the truncating conversion
+  o.fu = __builtin_amdgcn_fractf(o.U);
+  o.fv = __builtin_amdgcn_fractf(o.V);
+  o.u0 = o.inview ? (int)o.U : 0;     // in view => in [0, W-2]
+  o.v0 = o.inview ? (int)o.V : 0;
   return o;
 }
 

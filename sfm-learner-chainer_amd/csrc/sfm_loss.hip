@@ -377,6 +377,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
     C.sc = sc;
     C.xc = (unsigned)min(max(x, 0), w - 1);
     C.xin = xin;
+    C.xinf = xin ? 1.f : 0.f;
     C.outf = outl ? 1.f : 0.f;
     C.lane = lane;
     float* gpm_out = GRAD ? A.part_gpm + ((size_t)item * A.n_src + i) * 12 : nullptr;
