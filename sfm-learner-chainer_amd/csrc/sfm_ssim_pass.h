@@ -102,8 +102,14 @@ __device__ __forceinline__ void hsum3_group(T& a, T& b, T& c) {
   a = add_right(la, a); b = add_right(lb, b); c = add_right(lc, c);
   __builtin_amdgcn_sched_barrier(0);
 }
-__device__ __forceinline__ float vclamp01_sum(f2 e) { return fminf(fmaxf(e.x, 0.f), 1.f) + fminf(fmaxf(e.y, 0.f), 1.f); }
-__device__ __forceinline__ float vclamp01_sum(float e) { return fminf(fmaxf(e, 0.f), 1.f); }
+// clip((1 - S) / 2, 0, 1) as one multiply-add with the clamp output modifier (the compiler folds the scalar form by itself;
+// for the packed pair it splits the clamp off into two v_max, so that one is written out)
+__device__ __forceinline__ float half_one_minus_clamped(float S) { return fminf(fmaxf(fmaf(S, -0.5f, 0.5f), 0.f), 1.f); }
+__device__ __forceinline__ f2 half_one_minus_clamped(f2 S) {
+  f2 r;
+  asm("v_pk_fma_f32 %0, %1, 0.5, 0.5 op_sel_hi:[1,0,0] neg_lo:[1,0,0] neg_hi:[1,0,0] clamp" : "=v"(r) : "v"(S));
+  return r;
+}
 // v where 0 < e < 1, else 0   (F.clip backward)
 __device__ __forceinline__ f2 vsel_open01(f2 e, f2 v) {
   const f2 t = e * (1.f - e);
@@ -347,8 +353,10 @@ __device__ __forceinline__ void ssim_stage_b(const T x2, const T x1, const T x0,
   const T D2 = (Sqq * 9.f + C2) - sq;
   const T rD = vrcp(D1 * D2);
   const T Sv = N1 * N2 * rD;                                        // base_model.py:140
-  const T e = Sv * -0.5f + 0.5f;                                    // (1 - SSIM) / 2, base_model.py:142
-  if (LOSS) ssum += vclamp01_sum(e);
+  // (1 - SSIM) / 2 clipped to [0, 1] (base_model.py:142) in ONE instruction: the clamp rides on the multiply-add as its output
+  // modifier.  The clip's backward mask 0 < e < 1 is taken from the clipped value, which is strictly inside exactly when e is.
+  const T e = half_one_minus_clamped(Sv);
+  if (LOSS) ssum += vhadd(e);
   if (GRAD) {
     const T kap = vsel_open01(e, rD * kq_nm);                       // kappa / (D1 D2); F.clip backward: 0 < e < 1
     const T u3 = vfma(-(Sv * Sx), D2 - D1, Sy * (N2 - N1));
