@@ -1,33 +1,110 @@
 #!/usr/bin/env python3
-"""Run under torch.distributed.run (any N): cost of the per-step all-reduce of the five scalars, sync vs async."""
-import importlib, sys, os, time
-import numpy as np, torch, torch.distributed as dist
+"""Cost of the per-step collective of bench.py's N > 1 path, measured on ONE GPU (world size 1, RCCL):
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 tools/allreduce_overhead.py
+Prints ms per step of: the steps alone; steps + one async all-reduce of the 5 scalars per step (what bench.py times);
+the host time of the all_reduce call by itself; and the same collective issued through a pre-captured HIP graph if the
+stack allows capturing it."""
+import importlib, os, sys, time
+import numpy as np, torch
+import torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-ops = importlib.import_module("sfm-learner-chainer_amd.ops"); synth = importlib.import_module("sfm-learner-chainer_amd.synth")
-rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
-torch.cuda.set_device(local); dev = torch.device("cuda", local)
-dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-d = synth.make_inputs(B=32, H=128, W=416, n_src=2, n_scales=4, seed=1 + rank)
-t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-fl = ops.FusedLoss(smooth_reg=0.1, ssim_rate=0.15).bind([t(a) for a in d["tgt_pyr"]], [t(a) for a in d["src_pyr"]], t(d["intrinsics"]), [t(a) for a in d["disps"]], [t(a) for a in d["poses"]], norm_B=32 * world)
-slots = [torch.zeros(5, device=dev) for _ in range(4)]
-def run(mode, n=200):
-    works = [None] * 4
-    for it in range(n + 20):
-        if it == 20:
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-        k = it % 4
-        if works[k] is not None: works[k].wait(); works[k] = None
-        fl.forward_backward(out=slots[k])
-        if mode == "sync": dist.all_reduce(slots[k])
-        elif mode == "async": works[k] = dist.all_reduce(slots[k], async_op=True)
-        elif mode == "every8" and it % 8 == 7: dist.all_reduce(slots[k])
-    t_issue = (time.perf_counter() - t0) / n
+bench = importlib.import_module("bench")
+PKG = "sfm-learner-chainer_amd"
+ops = importlib.import_module(PKG + ".ops"); synth = importlib.import_module(PKG + ".synth")
+dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+torch.cuda.set_device(dev)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29513")
+dist.init_process_group("nccl", rank=int(os.environ.get("RANK", 0)), world_size=int(os.environ.get("WORLD_SIZE", 1)), device_id=dev)
+R = bench.Runner(torch, np, ops, synth, dev, "cfg3", "hwc", "fused", 0, seed=1, norm_scale=dist.get_world_size())
+K = 200
+log = torch.zeros((K, 5), dtype=torch.float32, device=dev)
+rows = [log[k] for k in range(K)]
+
+
+def timed(fn, reps=5):
+    out = []
+    for _ in range(reps):
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter(); fn(); torch.cuda.synchronize()
+        out.append((time.perf_counter() - t0) / K * 1e3)
+    return float(np.median(out))
+
+
+def plain():
+    for k in range(K):
+        R.step(out=rows[k])
+
+
+def per_step():
+    works = []
+    for k in range(K):
+        R.step(out=rows[k])
+        works.append(dist.all_reduce(rows[k], async_op=True))
     for w in works:
-        if w is not None: w.wait()
+        w.wait()
+
+
+def host_only():
+    t0 = time.perf_counter()
+    works = [dist.all_reduce(rows[k], async_op=True) for k in range(K)]
+    t = (time.perf_counter() - t0) / K * 1e6
+    for w in works:
+        w.wait()
+    return t
+
+
+def per_step_sync():
+    for k in range(K):
+        R.step(out=rows[k])
+        dist.all_reduce(rows[k])
+
+
+side = torch.cuda.Stream()
+
+
+def per_step_side():
+    cur = torch.cuda.current_stream()
+    works = []
+    for k in range(K):
+        R.step(out=rows[k])
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            works.append(dist.all_reduce(rows[k], async_op=True))
+    for w in works:
+        w.wait()
+    cur.wait_stream(side)
+
+
+for _ in range(2):
+    plain(); per_step(); per_step_sync(); per_step_side()
+print("steps + blocking all-reduce every step %.4f ms/step" % timed(per_step_sync))
+print("steps + all-reduce issued from a side stream %.4f ms/step" % timed(per_step_side))
+print("steps alone                         %.4f ms/step" % timed(plain))
+print("steps + async all-reduce every step %.4f ms/step" % timed(per_step))
+torch.cuda.synchronize()
+print("host time of one all_reduce call    %.1f us" % host_only())
+t0 = time.perf_counter()
+for k in range(K):
+    R.step(out=rows[k])
+host_step = (time.perf_counter() - t0) / K * 1e6
+torch.cuda.synchronize()
+print("host time of one step's launches    %.1f us" % host_step)
+try:
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        R.step(out=rows[0]); dist.all_reduce(rows[0])
     torch.cuda.synchronize()
-    return t_issue * 1e6, (time.perf_counter() - t0) / n * 1e6
-for mode in ("none", "sync", "async", "every8", "none"):
-    ti, tw = run(mode)
-    if rank == 0: print("%-7s host issue %.1f us/step, wall %.1f us/step" % (mode, ti, tw))
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        R.step(out=rows[0])
+        dist.all_reduce(rows[0])
+    torch.cuda.synchronize()
+
+    def graphed():
+        for k in range(K):
+            g.replay()
+    graphed()
+    print("step + all-reduce replayed from a HIP graph %.4f ms/step" % timed(graphed))
+except Exception as e:
+    print("graph capture of the collective not available here: %s: %s" % (type(e).__name__, str(e).splitlines()[0][:160]))
 dist.destroy_process_group()
