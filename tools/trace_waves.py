@@ -24,7 +24,7 @@ nz = int((raw != 0).any(axis=1).sum())
 if os.environ.get("SFM_TRACE_DUMP"):
     np.save(os.environ["SFM_TRACE_DUMP"], raw[:nz])
 stamps = os.environ.get("SFMWARP_LIB", "").endswith("stamps.so")
-SW = int(os.environ.get('SFM_STAMP_WORDS', '12'))
+SW = int(os.environ.get('SFM_STAMP_WORDS', '8'))
 n_items = int(os.environ['SFM_TRACE_ITEMS']) if 'SFM_TRACE_ITEMS' in os.environ else (nz // (1 + SW // 4) if stamps else nz)
 a = raw[:n_items]
 t0 = a[:, 0].min()
@@ -62,9 +62,9 @@ if os.environ.get("SFMWARP_LIB", "").endswith("stamps.so"):
     n = n_items
     b = raw.reshape(-1)[n * 4: n * 4 + n * SW].reshape(n, SW).astype(np.float64)
     steps = max(b[:, 4].sum(), 1.0)
-    if os.environ.get("SFM_QUAD_STAMPS", "1") != "1": print("cycles per row step (mean over all waves): A.finish %.0f  A.issue %.0f  B %.0f  C %.0f   total %.0f ; smoothness pass per wave %.0f cycles" % (
+    if os.environ.get("SFM_QUAD_STAMPS", "0") != "1": print("cycles per row step (mean over all waves): A.finish %.0f  A.issue %.0f  B %.0f  C %.0f   total %.0f ; smoothness pass per wave %.0f cycles" % (
         b[:, 0].sum() / steps, b[:, 1].sum() / steps, b[:, 2].sum() / steps, b[:, 3].sum() / steps, b[:, :4].sum() / steps, b[:, 5].mean()))
-if stamps and os.environ.get("SFM_QUAD_STAMPS", "1") == "1":
+if stamps and os.environ.get("SFM_QUAD_STAMPS", "0") == "1":
     # quad kernels: b[:,0..3] = cycles waited for the partner at start-S, start-G, finish-S, finish-G; b[:,4] = steady loops
     dur_cyc = b[:, 7]
     dur_us = (a[:, 1] - a[:, 0]).astype(np.float64) / 100.0
