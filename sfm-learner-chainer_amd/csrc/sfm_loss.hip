@@ -185,58 +185,80 @@ __device__ __forceinline__ void smooth2_pass(const LossArgs& A, const ScaleArgs&
 }
 
 // edge-aware first-order, models/base_model.py:144-155 (commented out at :78-80 in the reference)
+//   x term anchored at (q,x):  c_ex |d(q,x+1) - d(q,x)| wx(q,x),   wx = exp(-|mean_c (I(q,x+1) - I(q,x))|)
+//   y term anchored at (q,x):  c_ey |d(q+1,x) - d(q,x)| wy(q,x),   wy = exp(-|mean_c (I(q+1,x) - I(q,x))|)
+// The gradient at (q,x) gathers the signed weights of the two terms it takes part in on each axis:
+//   c_ex [tx(q,x-1) - tx(q,x)] + c_ey [sy(q-1,x) - sy(q,x)],   tx = sign(d_dx) wx,  sy = sign(d_dy) wy.
+// sy(q-1) is carried from the previous row (it is not recomputed from a third image row), and the rows q .. q+3 of the
+// column (disparity + three channels each) live in four register sets used in rotation, as in smooth2_pass.
+struct EdgeRow {
+  float d, i[3];
+};
+
 template <bool GRAD, bool LOSS, bool HWC>
 __device__ __forceinline__ void smooth_edge_pass(const LossArgs& A, const ScaleArgs& S, const float* __restrict__ dplane,
                                                  const float* __restrict__ tplane, int lane, int x, bool xin, bool outl, int y0,
                                                  int y1, float* gacc, float& acc_sm, const bool add) {
   const int h = S.h, w = S.w;
   const size_t P = (size_t)h * w;
-  float dm1 = 0.f, d0 = 0.f, dp1 = 0.f;
-  float im1[3] = {0.f, 0.f, 0.f}, i0[3] = {0.f, 0.f, 0.f}, ip1[3] = {0.f, 0.f, 0.f};
   const bool vx1 = xin && (x <= w - 2);
   const float third = 1.0f / 3.0f;
-  // rows are loaded two steps ahead of their use
   const unsigned xc = (unsigned)min(max(x, 0), w - 1);
-  float qd1 = 0.f, qd2 = 0.f, qi1[3] = {0.f, 0.f, 0.f}, qi2[3] = {0.f, 0.f, 0.f};
-  auto ldrow = [&](int r, float& d, float* im) {   // always loads, from a row clamped into the image (see smooth2_pass)
-    const unsigned o = (unsigned)min(max(r, 0), h - 1) * (unsigned)w + xc;
-    d = ldf(dplane, o);
+  // always a load, from a row clamped into the image (see smooth2_pass); one 12-byte load for the three channels of an HWC pixel
+  auto ldrow = [&](int r, EdgeRow& o) {
+    const unsigned off = (unsigned)min(max(r, 0), h - 1) * (unsigned)w + xc;
+    o.d = ldf(dplane, off);
+    if constexpr (HWC) {
+      const Rgb t = ld_off<Rgb>(tplane, 12u * off);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) im[c] = HWC ? ldf(tplane, 3u * o + c) : ldf(tplane + c * P, o);
+      for (int c = 0; c < 3; ++c) o.i[c] = t.c[c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) o.i[c] = ldf(tplane + c * P, off);
+    }
   };
-  ldrow(y0 - 1, qd1, qi1);
-  ldrow(y0, qd2, qi2);
-  for (int r = y0 - 1; r < y1 + 1; ++r) {
-    dm1 = d0; d0 = dp1; dp1 = xin ? qd1 : 0.f;
+  auto mask = [&](EdgeRow& o) {   // halo lanes outside the image carry zeros
+    o.d = xin ? o.d : 0.f;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { im1[c] = i0[c]; i0[c] = ip1[c]; ip1[c] = xin ? qi1[c] : 0.f; qi1[c] = qi2[c]; }
-    qd1 = qd2;
-    ldrow(r + 2, qd2, qi2);
-    const int q = r - 1;
-    if (q < y0) continue;
-    // x term anchored at (q,x)
-    float mx = 0.f, my0 = 0.f, mym1 = 0.f;
+    for (int c = 0; c < 3; ++c) o.i[c] = xin ? o.i[c] : 0.f;
+  };
+  float sy_prev = 0.f;   // sy of the row above
+  // one row of the walk: c0 = row q (masked), c1 = row q+1 as loaded (masked in place); afterwards the registers of row q
+  // receive row q+4
+  auto row = [&](const int q, EdgeRow& c0, EdgeRow& c1) {
+    mask(c1);
+    float mx = 0.f, my = 0.f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      mx += from_right(i0[c]) - i0[c];
-      my0 += ip1[c] - i0[c];
-      mym1 += i0[c] - im1[c];
+      mx += from_right(c0.i[c]) - c0.i[c];
+      my += c1.i[c] - c0.i[c];
     }
+    const float ddx = from_right(c0.d) - c0.d;   // d_dx(q,x)
+    const float ddy = c1.d - c0.d;               // d_dy(q,x)
+    ldrow(q + 4, c0);                            // the registers of row q are free now
     const float wx = vx1 ? __expf(-fabsf(mx * third)) : 0.f;
-    const float wy0 = (xin && q <= h - 2) ? __expf(-fabsf(my0 * third)) : 0.f;
-    const float wym1 = (xin && q - 1 >= 0) ? __expf(-fabsf(mym1 * third)) : 0.f;
-    const float ddx = from_right(d0) - d0;   // d_dx(q,x)
-    const float ddy0 = dp1 - d0;             // d_dy(q,x)
-    const float ddym1 = d0 - dm1;            // d_dy(q-1,x)
-    if (LOSS) {
-      if (outl) acc_sm += S.c_ex * fabsf(ddx) * wx + S.c_ey * fabsf(ddy0) * wy0;
+    const float wy = (xin && (unsigned)q <= (unsigned)(h - 2)) ? __expf(-fabsf(my * third)) : 0.f;   // 0 <= q <= h-2
+    const float sy = signf(ddy) * wy;
+    if (q >= y0) {
+      if (LOSS) {
+        if (outl) acc_sm += S.c_ex * fabsf(ddx) * wx + S.c_ey * fabsf(ddy) * wy;
+      }
+      if (GRAD) {
+        const float tx = signf(ddx) * wx;
+        const float gx = from_left(tx) - tx;
+        tile_put(gacc + (q - y0) * 64 + lane, A.gy * (S.c_ex * gx + S.c_ey * (sy_prev - sy)), add);
+      }
     }
-    if (GRAD) {
-      const float tx = signf(ddx) * wx;
-      const float gx = from_left(tx) - tx;
-      const float gyv = signf(ddym1) * wym1 - signf(ddy0) * wy0;
-      tile_put(gacc + (q - y0) * 64 + lane, A.gy * (S.c_ex * gx + S.c_ey * gyv), add);
-    }
+    sy_prev = sy;
+  };
+  EdgeRow r0, r1, r2, r3;
+  ldrow(y0 - 1, r0); ldrow(y0, r1); ldrow(y0 + 1, r2); ldrow(y0 + 2, r3);
+  mask(r0);
+  for (int q = y0 - 1; q < y1; q += 4) {   // the first row only produces sy(y0-1)
+    row(q, r0, r1);
+    if (q + 1 < y1) row(q + 1, r1, r2);
+    if (q + 2 < y1) row(q + 2, r2, r3);
+    if (q + 3 < y1) row(q + 3, r3, r0);
   }
 }
 
