@@ -154,3 +154,16 @@ def test_random_shapes_and_modes(ops, synth, dev, B, H, W, n_src, n_scales, cfg_
     ref64 = lambda: O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], d["masks"], backward=True,
                                dtype=np.float64, **cfg)
     _check_grads(fl, ref, n_src, check_mask=bool(cfg.get("exp_reg")), what="sweep %s %dx%d" % (cfg_name, H, W), ref64=ref64)
+
+
+@pytest.mark.parametrize("rows", [4, 28])
+def test_forced_chunk_heights(rows):
+    """The planner's extremes, forced through SFM_CHUNK_ROWS in a child process (the override is read once per process):
+    4-row chunks (more halo rows than rows) and 28-row chunks (32 steps per pass: every bit of the step masks)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, SFM_CHUNK_ROWS=str(rows))
+    r = subprocess.run([sys.executable, os.path.join(here, "forced_chunks_probe.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and ("OK rows=%d" % rows) in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
