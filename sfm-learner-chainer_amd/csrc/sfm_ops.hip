@@ -478,9 +478,22 @@ struct PyramidArgs {
   int n_first, G2;               // pair form only: blockIdx.y < n_first -> first tensor (one image per sample)
   float* y[SFM_MAX_SCALES];      // y[s] for s = 1..n_scales-1 (y[0] unused: scale 0 is the input itself)
   int oH[SFM_MAX_SCALES], oW[SFM_MAX_SCALES];
-  int begin[SFM_MAX_SCALES + 1]; // prefix sums of oH*oW over scales 1..
+  int begin[SFM_MAX_SCALES + 1]; // prefix sums of oH*oW over scales 1..   (HWC forms: of the THREAD counts, scale 0 first)
   int H, W, n_scales;
+  // numpy.linspace(0, W-1, oW)[ox] = ox * step with step = (W-1)/(oW-1) in double (F.resize_images): the quotient is the
+  // same for every pixel of a scale, so the host computes it (a double division is ~40 instructions per thread)
+  double step_u[SFM_MAX_SCALES], step_v[SFM_MAX_SCALES];
+  float inv_oW[SFM_MAX_SCALES];  // 1 / oW, for the row of a flat index (corrected to the exact quotient in the kernel)
+  int quads0;                    // HWC forms: threads of scale 0, four pixels each (ceil(H W / 4))
 };
+
+static void pyramid_steps(PyramidArgs& A) {
+  for (int s = 0; s < A.n_scales; ++s) {
+    A.step_u[s] = A.oW[s] > 1 ? (double)(A.W - 1) / (double)(A.oW[s] - 1) : 0.0;
+    A.step_v[s] = A.oH[s] > 1 ? (double)(A.H - 1) / (double)(A.oH[s] - 1) : 0.0;
+    A.inv_oW[s] = 1.0f / (float)A.oW[s];
+  }
+}
 
 __global__ void pyramid_fwd_kernel(const PyramidArgs A) {
 #pragma clang fp contract(off)
@@ -494,8 +507,8 @@ __global__ void pyramid_fwd_kernel(const PyramidArgs A) {
   const int jj = j - A.begin[s];
   const int oW = A.oW[s], oH = A.oH[s], H = A.H, W = A.W;
   const int oy = jj / oW, ox = jj - oy * oW;
-  const float u = oW > 1 ? (float)((double)ox * ((double)(W - 1) / (double)(oW - 1))) : 0.f;
-  const float v = oH > 1 ? (float)((double)oy * ((double)(H - 1) / (double)(oH - 1))) : 0.f;
+  const float u = (float)((double)ox * A.step_u[s]);
+  const float v = (float)((double)oy * A.step_v[s]);
   const int u0 = min(max((int)floorf(u), 0), max(W - 2, 0)), v0 = min(max((int)floorf(v), 0), max(H - 2, 0));
   const int u1 = min(u0 + 1, W - 1), v1 = min(v0 + 1, H - 1);
   const float wu1 = u - (float)u0, wv1 = v - (float)v0;
@@ -509,6 +522,10 @@ __global__ void pyramid_fwd_kernel(const PyramidArgs A) {
 // The same pyramid, pixel-interleaved (SFM_LAYOUT_HWC): x (N,3G,H,W) -> y[s] (N,G,h_s,w_s,3), s = 0..S-1.  One thread
 // per output pixel computes the three channels with one set of weights; per channel the arithmetic is that of
 // pyramid_fwd_kernel, so the values agree bit for bit.  Scale 0 is a copy.
+struct __attribute__((packed, aligned(4))) Float3 {   // one pixel-interleaved texel: written with one 12-byte store
+  float c[3];
+};
+
 template <bool PAIR>
 __global__ void pyramid_hwc_fwd_kernel(const PyramidArgs A) {
 #pragma clang fp contract(off)
@@ -516,36 +533,78 @@ __global__ void pyramid_hwc_fwd_kernel(const PyramidArgs A) {
   const float* xin = A.x;
   float* const* yout = A.y;
   if (PAIR && ng >= A.n_first) { ng -= A.n_first; xin = A.x2; yout = A.y2; }   // block-uniform
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= A.begin[A.n_scales]) return;
-  int s = 0;
-#pragma unroll
-  for (int k = 1; k < SFM_MAX_SCALES; ++k)
-    if (k < A.n_scales && j >= A.begin[k]) s = k;
-  const int jj = j - A.begin[s];
-  const int oW = A.oW[s], oH = A.oH[s], H = A.H, W = A.W;
+  const int H = A.H, W = A.W;
   const size_t P = (size_t)H * W;
   const float* img = xin + (size_t)ng * 3 * P;
-  float* out = yout[s] + ((size_t)ng * oH * oW + jj) * 3;
-  if (s == 0) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) out[c] = img[c * P + jj];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= A.begin[A.n_scales]) return;
+  // scale 0 is a transposition (planar -> pixel-interleaved): four consecutive pixels per thread.  A block that lies wholly
+  // inside scale 0 (uniform test) goes through LDS: 16-byte loads from the three planes, and 16-byte stores whose addresses
+  // are consecutive ACROSS the lanes (a lane writing its own 48 bytes makes every store instruction touch each cache line
+  // of the span for a third of its bytes).  Blocks at the end of the range and unaligned tensors go pixel by pixel.
+  __shared__ float4 stage[3 * 256];
+  const int jb = blockIdx.x * blockDim.x;   // first thread of the block
+  const bool block_vec = (jb + (int)blockDim.x <= A.quads0) && ((size_t)(jb + (int)blockDim.x) * 4 <= P) && (P % 4 == 0) &&
+                         blockDim.x == 256 && ((((uintptr_t)xin) | ((uintptr_t)yout[0])) % 16 == 0);
+  if (block_vec) {
+    const size_t p0 = (size_t)j * 4;
+    const float4 r = *reinterpret_cast<const float4*>(img + p0), g = *reinterpret_cast<const float4*>(img + P + p0),
+                 bl = *reinterpret_cast<const float4*>(img + 2 * P + p0);
+    const int t = threadIdx.x;
+    stage[3 * t + 0] = make_float4(r.x, g.x, bl.x, r.y);
+    stage[3 * t + 1] = make_float4(g.y, bl.y, r.z, g.z);
+    stage[3 * t + 2] = make_float4(bl.z, r.w, g.w, bl.w);
+    __syncthreads();
+    float4* o = reinterpret_cast<float4*>(yout[0] + ((size_t)ng * P + (size_t)jb * 4) * 3);   // 768 float4 per block
+    o[t] = stage[t];
+    o[t + 256] = stage[t + 256];
+    o[t + 512] = stage[t + 512];
     return;
   }
-  const int oy = jj / oW, ox = jj - oy * oW;
-  const float u = oW > 1 ? (float)((double)ox * ((double)(W - 1) / (double)(oW - 1))) : 0.f;
-  const float v = oH > 1 ? (float)((double)oy * ((double)(H - 1) / (double)(oH - 1))) : 0.f;
+  if (j < A.quads0) {
+    const size_t p0 = (size_t)j * 4;
+    {
+      for (size_t q = p0; q < p0 + 4 && q < P; ++q) {
+        Float3 t;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t.c[c] = img[c * P + q];
+        *reinterpret_cast<Float3*>(yout[0] + ((size_t)ng * P + q) * 3) = t;
+      }
+    }
+    return;
+  }
+  int s = 1;
+#pragma unroll
+  for (int k = 2; k < SFM_MAX_SCALES; ++k)
+    if (k < A.n_scales && j >= A.begin[k]) s = k;
+  const int jj = j - A.begin[s];
+  const int oW = A.oW[s], oH = A.oH[s];
+  // row and column of the flat index: estimate with the reciprocal, then make it exact
+  int oy, ox;
+  if (jj < (1 << 22)) {   // the estimate is within one of the quotient while the index is exact in a float
+    oy = (int)((float)jj * A.inv_oW[s]);
+    ox = jj - oy * oW;
+    if (ox < 0) { --oy; ox += oW; }
+    else if (ox >= oW) { ++oy; ox -= oW; }
+  } else {
+    oy = jj / oW;
+    ox = jj - oy * oW;
+  }
+  const float u = (float)((double)ox * A.step_u[s]);
+  const float v = (float)((double)oy * A.step_v[s]);
   const int u0 = min(max((int)floorf(u), 0), max(W - 2, 0)), v0 = min(max((int)floorf(v), 0), max(H - 2, 0));
   const int u1 = min(u0 + 1, W - 1), v1 = min(v0 + 1, H - 1);
   const float wu1 = u - (float)u0, wv1 = v - (float)v0;
   const float wu0 = 1.0f - wu1, wv0 = 1.0f - wv1;
+  Float3 t;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float* pl = img + c * P;
     const float top = pl[v0 * W + u0] * wu0 + pl[v0 * W + u1] * wu1;
     const float bot = pl[v1 * W + u0] * wu0 + pl[v1 * W + u1] * wu1;
-    out[c] = top * wv0 + bot * wv1;
+    t.c[c] = top * wv0 + bot * wv1;
   }
+  *reinterpret_cast<Float3*>(yout[s] + ((size_t)ng * oH * oW + jj) * 3) = t;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -772,6 +831,7 @@ int sfm_pyramid_fwd(const float* x, float* const* y, int N, int C, int H, int W,
     SFM_REQUIRE(A.oH[s] >= 1 && A.oW[s] >= 1, SFM_ERR_SHAPE, "sfm_pyramid_fwd: scale %d is empty", s);
     A.begin[s + 1] = A.begin[s] + A.oH[s] * A.oW[s];
   }
+  pyramid_steps(A);
   const int total = A.begin[n_scales];
   hipLaunchKernelGGL(pyramid_fwd_kernel, dim3((total + 255) / 256, N * C), dim3(256), 0, (hipStream_t)stream, A);
   return check_launch("sfm_pyramid_fwd");
@@ -792,8 +852,11 @@ int sfm_pyramid_hwc_fwd(const float* x, float* const* y, int N, int G, int H, in
     A.oW[s] = W >> s;
     SFM_REQUIRE(A.oH[s] >= 1 && A.oW[s] >= 1, SFM_ERR_SHAPE, "sfm_pyramid_hwc_fwd: scale %d is empty", s);
     SFM_REQUIRE((long long)A.begin[s] + (long long)A.oH[s] * A.oW[s] < (1ll << 31), SFM_ERR_SHAPE, "sfm_pyramid_hwc_fwd: image too large");
-    A.begin[s + 1] = A.begin[s] + A.oH[s] * A.oW[s];
+    // threads: scale 0 four pixels each, the other scales one pixel each
+    A.begin[s + 1] = A.begin[s] + (s == 0 ? (A.oH[0] * A.oW[0] + 3) / 4 : A.oH[s] * A.oW[s]);
   }
+  A.quads0 = A.begin[1];
+  pyramid_steps(A);
   const int total = A.begin[n_scales];
   hipLaunchKernelGGL(pyramid_hwc_fwd_kernel<false>, dim3((total + 255) / 256, N * G), dim3(256), 0, (hipStream_t)stream, A);
   return check_launch("sfm_pyramid_hwc_fwd");
@@ -817,8 +880,11 @@ int sfm_pyramid_pair_hwc_fwd(const float* tgt, const float* src, float* const* y
     A.oW[s] = W >> s;
     SFM_REQUIRE(A.oH[s] >= 1 && A.oW[s] >= 1, SFM_ERR_SHAPE, "sfm_pyramid_pair_hwc_fwd: scale %d is empty", s);
     SFM_REQUIRE((long long)A.begin[s] + (long long)A.oH[s] * A.oW[s] < (1ll << 31), SFM_ERR_SHAPE, "sfm_pyramid_pair_hwc_fwd: image too large");
-    A.begin[s + 1] = A.begin[s] + A.oH[s] * A.oW[s];
+    // threads: scale 0 four pixels each, the other scales one pixel each
+    A.begin[s + 1] = A.begin[s] + (s == 0 ? (A.oH[0] * A.oW[0] + 3) / 4 : A.oH[s] * A.oW[s]);
   }
+  A.quads0 = A.begin[1];
+  pyramid_steps(A);
   const int total = A.begin[n_scales];
   hipLaunchKernelGGL(pyramid_hwc_fwd_kernel<true>, dim3((total + 255) / 256, N * (1 + n_src)), dim3(256), 0, (hipStream_t)stream, A);
   return check_launch("sfm_pyramid_pair_hwc_fwd");
