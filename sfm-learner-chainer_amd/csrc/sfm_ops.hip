@@ -522,6 +522,9 @@ __global__ void pyramid_fwd_kernel(const PyramidArgs A) {
 // The same pyramid, pixel-interleaved (SFM_LAYOUT_HWC): x (N,3G,H,W) -> y[s] (N,G,h_s,w_s,3), s = 0..S-1.  One thread
 // per output pixel computes the three channels with one set of weights; per channel the arithmetic is that of
 // pyramid_fwd_kernel, so the values agree bit for bit.  Scale 0 is a copy.
+struct __attribute__((packed, aligned(4))) Pair2 {    // two horizontally adjacent pixels of a plane
+  float a, b;
+};
 struct __attribute__((packed, aligned(4))) Float3 {   // one pixel-interleaved texel: written with one 12-byte store
   float c[3];
 };
@@ -597,12 +600,23 @@ __global__ void pyramid_hwc_fwd_kernel(const PyramidArgs A) {
   const float wu1 = u - (float)u0, wv1 = v - (float)v0;
   const float wu0 = 1.0f - wu1, wv0 = 1.0f - wv1;
   Float3 t;
+  if (W >= 2) {   // u1 = u0 + 1: the two taps of a row with one 8-byte load
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const float* pl = img + c * P;
-    const float top = pl[v0 * W + u0] * wu0 + pl[v0 * W + u1] * wu1;
-    const float bot = pl[v1 * W + u0] * wu0 + pl[v1 * W + u1] * wu1;
-    t.c[c] = top * wv0 + bot * wv1;
+    for (int c = 0; c < 3; ++c) {
+      const float* pl = img + c * P;
+      const Pair2 a = *reinterpret_cast<const Pair2*>(pl + v0 * W + u0), b = *reinterpret_cast<const Pair2*>(pl + v1 * W + u0);
+      const float top = a.a * wu0 + a.b * wu1;
+      const float bot = b.a * wu0 + b.b * wu1;
+      t.c[c] = top * wv0 + bot * wv1;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* pl = img + c * P;
+      const float top = pl[v0 * W + u0] * wu0 + pl[v0 * W + u1] * wu1;
+      const float bot = pl[v1 * W + u0] * wu0 + pl[v1 * W + u1] * wu1;
+      t.c[c] = top * wv0 + bot * wv1;
+    }
   }
   *reinterpret_cast<Float3*>(yout[s] + ((size_t)ng * oH * oW + jj) * 3) = t;
 }
