@@ -15,8 +15,9 @@
 //   * the 3x3 SSIM pools and their transposes are separable sums over those two,
 //   * depth gradients of all sources are summed in a wave-private LDS tile and d_disp is
 //     written exactly once, coalesced; the 12 sums of dL/dPm are reduced in-wavefront.
-// All scales, sources and samples of a step are covered by ONE launch; a second tiny launch
-// reduces the per-wave partials in a fixed order (bitwise reproducible) and finishes d_pose.
+// All scales, sources and samples of a step are covered by ONE launch of loss_kernel, between two tiny ones:
+// geom_kernel builds the geometry table of every (sample, scale, source) first, finalize_kernel reduces the
+// per-wave partials in a fixed order (bitwise reproducible) and finishes d_pose.
 #include <stdlib.h>
 #include <string.h>
 
