@@ -31,6 +31,7 @@ namespace sfm {
 constexpr int MAX_CHUNK_ROWS = 28;   // + 4 halo rows = the 32 steps a pass can have (StepMasks)
 constexpr int MIN_CHUNK_ROWS = 4;
 constexpr int WAVES_PER_BLOCK = 1;   // independent wavefronts; grouped only so that a CU is filled with few workgroups
+constexpr int N_CLASSES = 3;         // chunk-height classes of a plan = the most co-resident waves of a SIMD the planner ranks
 
 struct ScaleArgs {
   const float* tgt;
@@ -40,7 +41,11 @@ struct ScaleArgs {
   float* d_disp;
   float* d_mask;
   float* d_src;
-  int h, w, strips, chunks, tiles, item_begin, chunk_rows;
+  int h, w, strips, tiles, item_begin;
+  // Row chunks of a strip in up to three CLASSES of different height (plan_chunks): class k holds cls_n[k] consecutive
+  // chunks of cls_h[k] rows starting at row cls_y[k] (the last one clipped at cls_yend[k]); its tiles are numbered from
+  // cls_t[k] within the scale.  A uniform chunking is one class.
+  int cls_n[N_CLASSES], cls_h[N_CLASSES], cls_y[N_CLASSES], cls_yend[N_CLASSES], cls_t[N_CLASSES];
   float inv_cnt;               // 1 / (norm_B * 3 * h * w)                 base_model.py:111,115
   float c_dx2, c_dy2, c_dxy;   // smooth_reg / 2^s / element count         base_model.py:76,184-185
   float c_ex, c_ey;            // the same for the edge-aware form         base_model.py:154-155
@@ -287,33 +292,43 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
   // speed, never the result (the partial sums are indexed by the item id, not by the block).
   static_assert(WAVES_PER_BLOCK == 1, "item mapping assumes one wavefront per workgroup");
   const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
-  int s = 0, b, t;
+  // Order of the items of an XCD (or, with fewer than 8 samples, of the whole launch): class-major, then scale, sample, tile.
+  // The dispatcher fills the SIMDs of an XCD round by round, so the first round of workgroups -- the oldest wave of every SIMD --
+  // gets the chunks of class 0, the second round those of class 1, ... (plan_chunks sizes the classes for that).
+  int nb, rem, b0, bstep;
   if (A.B >= 8) {
-    const int nb = (A.B - xcd + 7) >> 3;          // samples owned by this XCD
-    int rem = loc;
-    bool found = false;
+    nb = (A.B - xcd + 7) >> 3;          // samples owned by this XCD
+    rem = loc; b0 = xcd; bstep = 8;
+  } else {
+    nb = A.B;
+    rem = xcd * (int)(gridDim.x >> 3) + loc; b0 = 0; bstep = 1;
+  }
+  int s = 0, kc = 0;
+  bool found = false;
 #pragma unroll
-    for (int k = 0; k < SFM_MAX_SCALES; ++k) {
-      if (k < A.n_scales && !found) {
-        const int cnt = nb * A.sc[k].tiles;
-        if (rem < cnt) { s = k; found = true; }
+  for (int k = 0; k < N_CLASSES; ++k) {
+#pragma unroll
+    for (int q = 0; q < SFM_MAX_SCALES; ++q) {
+      if (q < A.n_scales && !found) {
+        const int cnt = nb * A.sc[q].strips * A.sc[q].cls_n[k];
+        if (rem < cnt) { s = q; kc = k; found = true; }
         else rem -= cnt;
       }
     }
-    if (!found) return;   // whole wavefront leaves; no block-level synchronisation anywhere in this kernel
-    const int bl = rem / A.sc[s].tiles;
-    t = rem - bl * A.sc[s].tiles;
-    b = xcd + 8 * bl;
-  } else {
-    const int per = (int)(gridDim.x >> 3);
-    const int it = xcd * per + loc;
-    if (it >= A.items) return;
-#pragma unroll
-    for (int k = 1; k < SFM_MAX_SCALES; ++k)
-      if (k < A.n_scales && it >= A.sc[k].item_begin) s = k;
-    const int idx = it - A.sc[s].item_begin;
-    b = idx / A.sc[s].tiles;
-    t = idx - b * A.sc[s].tiles;
+  }
+  if (!found) return;   // whole wavefront leaves; no block-level synchronisation anywhere in this kernel
+  int b, t, y0, y1, strip;
+  {
+    const ScaleArgs& Sd = A.sc[s];
+    const int per_b = Sd.strips * Sd.cls_n[kc];
+    const int bl = rem / per_b;
+    const int tt = rem - bl * per_b;
+    const int chunk = tt / Sd.strips;
+    strip = tt - chunk * Sd.strips;
+    b = b0 + bstep * bl;
+    t = Sd.cls_t[kc] + tt;
+    y0 = Sd.cls_y[kc] + chunk * Sd.cls_h[kc];
+    y1 = min(y0 + Sd.cls_h[kc], Sd.cls_yend[kc]);
   }
   const ScaleArgs& S = A.sc[s];
   const int item = S.item_begin + b * S.tiles + t;
@@ -326,15 +341,11 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
   // the oldest during the second, and the waves of a SIMD finish closer together.  Only ever affects speed.
   const int prio_rank = min((int)(blockIdx.x >> 3) / A.simds_per_xcd, A.prio_top);
   set_issue_prio((int)((A.prio_tab >> (2 * prio_rank)) & 3u));
-  const int chunk = t / S.strips;
-  const int strip = t - chunk * S.strips;
   const int h = S.h, w = S.w;
   const int lane = threadIdx.x & 63;
   const int x = strip * HH::SW - HH::HL + lane;
   const bool xin = (x >= 0) && (x < w);
   const bool outl = (lane >= HH::HL) && (lane < 64 - HH::HR) && (x < w);
-  const int y0 = chunk * S.chunk_rows;
-  const int y1 = min(y0 + S.chunk_rows, h);
   const ScaleConst sc = make_scale_const(h, w);
   const size_t P = (size_t)h * w;
 
@@ -589,6 +600,8 @@ struct Tuning {
   int rows_list[SFM_MAX_SCALES] = {0};      // SFM_CHUNK_ROWS_LIST: chunk height per scale, "13,13,16,8"
   bool has_prio = false;
   unsigned prio_tab = 0;                    // SFM_PRIO_TABLE: "0123,3210" = levels of ranks 0.. in phase 1, phase 2
+  bool has_class_plan = false;              // SFM_CLASS_PLAN: "3x16+3x12+4x11;2x16+2x12+1x8;1x18+1x14;1x8+1x8" = per scale (';'),
+  int cls_n[SFM_MAX_SCALES][N_CLASSES] = {{0}}, cls_h[SFM_MAX_SCALES][N_CLASSES] = {{0}};   // per class ('+'): chunks x rows
   Tuning() {
     if (const char* e = getenv("SFM_CHUNK_ROWS")) chunk_rows = atoi(e);
     if (const char* rl = getenv("SFM_CHUNK_ROWS_LIST")) {
@@ -605,6 +618,20 @@ struct Tuning {
         else if (*pt >= '0' && *pt <= '3' && r < 4) { prio_tab |= (unsigned)(*pt - '0') << (8 * phase + 2 * r); ++r; }
       }
       has_prio = true;
+    }
+    if (const char* cp = getenv("SFM_CLASS_PLAN")) {
+      int sc = 0, k = 0;
+      while (*cp && sc < SFM_MAX_SCALES) {
+        const int n = atoi(cp);
+        while (*cp && *cp != 'x' && *cp != '+' && *cp != ';') ++cp;
+        int hh = 0;
+        if (*cp == 'x') { ++cp; hh = atoi(cp); }
+        while (*cp && *cp != '+' && *cp != ';') ++cp;
+        if (k < N_CLASSES) { cls_n[sc][k] = n; cls_h[sc][k] = hh; }
+        if (*cp == '+') { ++k; ++cp; }
+        else if (*cp == ';') { ++sc; k = 0; ++cp; }
+      }
+      has_class_plan = true;
     }
   }
 };
@@ -663,6 +690,41 @@ static long long max_items(const SfmLossDesc* d, int sw) {
   return items;
 }
 
+// chunk classes per scale (see ScaleArgs): n[s][k] chunks of h[s][k] rows, class 0 at the top of the image
+struct ChunkPlan {
+  int n[SFM_MAX_SCALES][N_CLASSES];
+  int h[SFM_MAX_SCALES][N_CLASSES];
+};
+
+static ChunkPlan uniform_chunk_plan(const SfmLossDesc* d, const int* rows) {
+  ChunkPlan cp;
+  memset(&cp, 0, sizeof(cp));
+  for (int s = 0; s < d->n_scales; ++s) {
+    cp.h[s][0] = rows[s];
+    cp.n[s][0] = (d->H[s] + rows[s] - 1) / rows[s];
+  }
+  return cp;
+}
+
+// a plan is usable when, per scale, its classes tile the image rows exactly (only the last chunk of a class may be clipped,
+// and only by the end of the image) with heights the kernel supports
+static bool chunk_plan_valid(const SfmLossDesc* d, const ChunkPlan& cp) {
+  for (int s = 0; s < d->n_scales; ++s) {
+    int y = 0;
+    for (int k = 0; k < N_CLASSES; ++k) {
+      if (cp.n[s][k] < 0) return false;
+      if (cp.n[s][k] == 0) continue;
+      if (cp.h[s][k] > MAX_CHUNK_ROWS) return false;
+      if (cp.h[s][k] < MIN_CHUNK_ROWS && cp.h[s][k] < d->H[s]) return false;   // (max_items sizes the workspace for chunks >= MIN_CHUNK_ROWS)
+      if (y >= d->H[s]) return false;                                   // a class that starts below the image
+      if (y + (cp.n[s][k] - 1) * cp.h[s][k] >= d->H[s]) return false;   // a chunk that starts below the image
+      y += cp.n[s][k] * cp.h[s][k];
+    }
+    if (y < d->H[s]) return false;
+  }
+  return true;
+}
+
 static void set_gy(struct Plan& p, const float gy);
 
 // validates the descriptor and lays out items + workspace for the given mode
@@ -716,6 +778,13 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
     A.prio_tab |= (unsigned)r << (2 * r) | (unsigned)(A.prio_top - r) << (8 + 2 * r);
   if (tuning().has_prio) A.prio_tab = tuning().prio_tab;
   plan_chunks(d, sw, 2 * (hs > hm ? hs : hm), slots, rows);
+  ChunkPlan cp = uniform_chunk_plan(d, rows);
+  if (tuning().has_class_plan) {
+    ChunkPlan forced;
+    memcpy(forced.n, tuning().cls_n, sizeof(forced.n));
+    memcpy(forced.h, tuning().cls_h, sizeof(forced.h));
+    if (chunk_plan_valid(d, forced)) cp = forced;
+  }
   int items = 0;
   for (int s = 0; s < d->n_scales; ++s) {
     const int h = d->H[s], w = d->W[s];
@@ -738,9 +807,17 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
     S.h = h;
     S.w = w;
     S.strips = (w + sw - 1) / sw;
-    S.chunk_rows = rows[s];
-    S.chunks = (h + rows[s] - 1) / rows[s];
-    S.tiles = S.strips * S.chunks;
+    int chunks = 0, y = 0;
+    for (int k = 0; k < N_CLASSES; ++k) {
+      S.cls_n[k] = cp.n[s][k];
+      S.cls_h[k] = cp.n[s][k] > 0 ? cp.h[s][k] : 1;
+      S.cls_y[k] = y;
+      S.cls_t[k] = chunks * S.strips;
+      y = y + cp.n[s][k] * cp.h[s][k] < h ? y + cp.n[s][k] * cp.h[s][k] : h;
+      S.cls_yend[k] = y;
+      chunks += cp.n[s][k];
+    }
+    S.tiles = S.strips * chunks;
     S.item_begin = items;
     items += d->B * S.tiles;
     const double nb = (double)d->norm_B;
@@ -907,7 +984,12 @@ int sfm_loss_plan_info(const SfmLossDesc* desc, int grad, int loss, int* out, in
   for (int s = 0; s < desc->n_scales; ++s) {
     const sfm::ScaleArgs& S = p.args.sc[s];
     int* o = out + 1 + 4 * s;
-    o[0] = S.strips; o[1] = S.chunks; o[2] = S.chunk_rows; o[3] = S.tiles;
+    int chunks = 0, rows = 0;
+    for (int k = 0; k < sfm::N_CLASSES; ++k) {
+      chunks += S.cls_n[k];
+      if (S.cls_n[k] > 0 && S.cls_h[k] > rows) rows = S.cls_h[k];
+    }
+    o[0] = S.strips; o[1] = chunks; o[2] = rows; o[3] = S.tiles;
   }
   return SFM_OK;
 }
