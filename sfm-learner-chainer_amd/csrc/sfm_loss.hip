@@ -31,7 +31,6 @@ namespace sfm {
 constexpr int MAX_CHUNK_ROWS = 28;   // + 4 halo rows = the 32 steps a pass can have (StepMasks)
 constexpr int MIN_CHUNK_ROWS = 4;
 constexpr int WAVES_PER_BLOCK = 1;   // independent wavefronts; grouped only so that a CU is filled with few workgroups
-constexpr int N_CLASSES = 3;         // chunk-height classes of a plan = the most co-resident waves of a SIMD the planner ranks
 
 struct ScaleArgs {
   const float* tgt;
@@ -41,11 +40,7 @@ struct ScaleArgs {
   float* d_disp;
   float* d_mask;
   float* d_src;
-  int h, w, strips, tiles, item_begin;
-  // Row chunks of a strip in up to three CLASSES of different height (plan_chunks): class k holds cls_n[k] consecutive
-  // chunks of cls_h[k] rows starting at row cls_y[k] (the last one clipped at cls_yend[k]); its tiles are numbered from
-  // cls_t[k] within the scale.  A uniform chunking is one class.
-  int cls_n[N_CLASSES], cls_h[N_CLASSES], cls_y[N_CLASSES], cls_yend[N_CLASSES], cls_t[N_CLASSES];
+  int h, w, strips, chunks, tiles, item_begin, chunk_rows;
   float inv_cnt;               // 1 / (norm_B * 3 * h * w)                 base_model.py:111,115
   float c_dx2, c_dy2, c_dxy;   // smooth_reg / 2^s / element count         base_model.py:76,184-185
   float c_ex, c_ey;            // the same for the edge-aware form         base_model.py:154-155
@@ -53,7 +48,7 @@ struct ScaleArgs {
   // uniform factors of the backward, products with the upstream gradient gy (set_gy): kept as kernel arguments so that they
   // are scalar operands -- computed in the kernel they would be wave-uniform values held in vector registers
   float k_pix;                 // gy (1-alpha) inv_cnt          dL/d(sum |e|)        base_model.py:111,117
-  float kq;                    // -gy alpha inv_cnt / 2         -1/2 dL/d(sum ssim)  base_model.py:115,117,142
+  float kq;                    // -gy alpha inv_cnt             -dL/d(sum ssim) = 2 kappa of a pixel  base_model.py:115,117,142
   float k_exp;                 // gy c_exp                                            base_model.py:105,167
 };
 
@@ -208,7 +203,7 @@ __device__ __forceinline__ void smooth_edge_pass(const LossArgs& A, const ScaleA
   const int h = S.h, w = S.w;
   const size_t P = (size_t)h * w;
   const bool vx1 = xin && (x <= w - 2);
-  const float third = 1.0f / 3.0f;
+  const float outf = outl ? 1.f : 0.f;
   const unsigned xc = (unsigned)min(max(x, 0), w - 1);
   // always a load, from a row clamped into the image (see smooth2_pass); one 12-byte load for the three channels of an HWC pixel
   auto ldrow = [&](int r, EdgeRow& o) {
@@ -223,43 +218,36 @@ __device__ __forceinline__ void smooth_edge_pass(const LossArgs& A, const ScaleA
       for (int c = 0; c < 3; ++c) o.i[c] = ldf(tplane + c * P, off);
     }
   };
-  auto mask = [&](EdgeRow& o) {   // halo lanes outside the image carry zeros
-    o.d = xin ? o.d : 0.f;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) o.i[c] = xin ? o.i[c] : 0.f;
-  };
+  // No masking of the loaded rows: every load comes from a column clamped into the image, so the values of a halo lane outside
+  // the image are finite copies of the border column, and every term such a lane takes part in carries a zero weight (vx1f, xinf).
+  const float vx1f = vx1 ? 1.f : 0.f, xinf = xin ? 1.f : 0.f;
+  const float KE = -1.44269504088896341f / 3.0f;          // exp(-|s / 3|) = exp2(|s| KE): the mean over the channels folded in
+  float gcx = A.gy * S.c_ex, gcy = A.gy * S.c_ey, cex = S.c_ex, cey = S.c_ey;
+  asm volatile("" : "+v"(gcx), "+v"(gcy), "+v"(cex), "+v"(cey));   // loop-invariant, pinned in vector registers (as in smooth2_pass)
   float sy_prev = 0.f;   // sy of the row above
-  // one row of the walk: c0 = row q (masked), c1 = row q+1 as loaded (masked in place); afterwards the registers of row q
-  // receive row q+4
+  // one row of the walk: c0 = row q, c1 = row q+1; afterwards the registers of row q receive row q+4.  Branch-free up to the
+  // (wave-uniform) test whether the row belongs to the chunk: a lane-variant branch would split the block around the DPP reads.
   auto row = [&](const int q, EdgeRow& c0, EdgeRow& c1) {
-    mask(c1);
-    float mx = 0.f, my = 0.f;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      mx += from_right(c0.i[c]) - c0.i[c];
-      my += c1.i[c] - c0.i[c];
-    }
+    const float sx = ((from_right(c0.i[0]) - c0.i[0]) + (from_right(c0.i[1]) - c0.i[1])) + (from_right(c0.i[2]) - c0.i[2]);
+    const float sy3 = ((c1.i[0] - c0.i[0]) + (c1.i[1] - c0.i[1])) + (c1.i[2] - c0.i[2]);
     const float ddx = from_right(c0.d) - c0.d;   // d_dx(q,x)
     const float ddy = c1.d - c0.d;               // d_dy(q,x)
     ldrow(q + 4, c0);                            // the registers of row q are free now
-    const float wx = vx1 ? __expf(-fabsf(mx * third)) : 0.f;
-    const float wy = (xin && (unsigned)q <= (unsigned)(h - 2)) ? __expf(-fabsf(my * third)) : 0.f;   // 0 <= q <= h-2
-    const float sy = signf(ddy) * wy;
+    const float rowf = ((unsigned)q <= (unsigned)(h - 2)) ? xinf : 0.f;   // 0 <= q <= h-2 (uniform) and the column inside the image
+    const float wx = __builtin_amdgcn_exp2f(fabsf(sx) * KE) * vx1f;
+    const float wy = __builtin_amdgcn_exp2f(fabsf(sy3) * KE) * rowf;
+    const float sy = ksign(wy, ddy);
     if (q >= y0) {
-      if (LOSS) {
-        if (outl) acc_sm += S.c_ex * fabsf(ddx) * wx + S.c_ey * fabsf(ddy) * wy;
-      }
+      if (LOSS) acc_sm = fmaf(outf, fmaf(cex * fabsf(ddx), wx, cey * fabsf(ddy) * wy), acc_sm);
       if (GRAD) {
-        const float tx = signf(ddx) * wx;
-        const float gx = from_left(tx) - tx;
-        tile_put(gacc + (q - y0) * 64 + lane, A.gy * (S.c_ex * gx + S.c_ey * (sy_prev - sy)), add);
+        const float tx = ksign(wx, ddx);
+        tile_put(gacc + (q - y0) * 64 + lane, fmaf(gcy, sy_prev - sy, gcx * (from_left(tx) - tx)), add);
       }
     }
     sy_prev = sy;
   };
   EdgeRow r0, r1, r2, r3;
   ldrow(y0 - 1, r0); ldrow(y0, r1); ldrow(y0 + 1, r2); ldrow(y0 + 2, r3);
-  mask(r0);
   for (int q = y0 - 1; q < y1; q += 4) {   // the first row only produces sy(y0-1)
     row(q, r0, r1);
     if (q + 1 < y1) row(q + 1, r1, r2);
@@ -292,43 +280,33 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
   // speed, never the result (the partial sums are indexed by the item id, not by the block).
   static_assert(WAVES_PER_BLOCK == 1, "item mapping assumes one wavefront per workgroup");
   const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
-  // Order of the items of an XCD (or, with fewer than 8 samples, of the whole launch): class-major, then scale, sample, tile.
-  // The dispatcher fills the SIMDs of an XCD round by round, so the first round of workgroups -- the oldest wave of every SIMD --
-  // gets the chunks of class 0, the second round those of class 1, ... (plan_chunks sizes the classes for that).
-  int nb, rem, b0, bstep;
+  int s = 0, b, t;
   if (A.B >= 8) {
-    nb = (A.B - xcd + 7) >> 3;          // samples owned by this XCD
-    rem = loc; b0 = xcd; bstep = 8;
-  } else {
-    nb = A.B;
-    rem = xcd * (int)(gridDim.x >> 3) + loc; b0 = 0; bstep = 1;
-  }
-  int s = 0, kc = 0;
-  bool found = false;
+    const int nb = (A.B - xcd + 7) >> 3;          // samples owned by this XCD
+    int rem = loc;
+    bool found = false;
 #pragma unroll
-  for (int k = 0; k < N_CLASSES; ++k) {
-#pragma unroll
-    for (int q = 0; q < SFM_MAX_SCALES; ++q) {
-      if (q < A.n_scales && !found) {
-        const int cnt = nb * A.sc[q].strips * A.sc[q].cls_n[k];
-        if (rem < cnt) { s = q; kc = k; found = true; }
+    for (int k = 0; k < SFM_MAX_SCALES; ++k) {
+      if (k < A.n_scales && !found) {
+        const int cnt = nb * A.sc[k].tiles;
+        if (rem < cnt) { s = k; found = true; }
         else rem -= cnt;
       }
     }
-  }
-  if (!found) return;   // whole wavefront leaves; no block-level synchronisation anywhere in this kernel
-  int b, t, y0, y1, strip;
-  {
-    const ScaleArgs& Sd = A.sc[s];
-    const int per_b = Sd.strips * Sd.cls_n[kc];
-    const int bl = rem / per_b;
-    const int tt = rem - bl * per_b;
-    const int chunk = tt / Sd.strips;
-    strip = tt - chunk * Sd.strips;
-    b = b0 + bstep * bl;
-    t = Sd.cls_t[kc] + tt;
-    y0 = Sd.cls_y[kc] + chunk * Sd.cls_h[kc];
-    y1 = min(y0 + Sd.cls_h[kc], Sd.cls_yend[kc]);
+    if (!found) return;   // whole wavefront leaves; no block-level synchronisation anywhere in this kernel
+    const int bl = rem / A.sc[s].tiles;
+    t = rem - bl * A.sc[s].tiles;
+    b = xcd + 8 * bl;
+  } else {
+    const int per = (int)(gridDim.x >> 3);
+    const int it = xcd * per + loc;
+    if (it >= A.items) return;
+#pragma unroll
+    for (int k = 1; k < SFM_MAX_SCALES; ++k)
+      if (k < A.n_scales && it >= A.sc[k].item_begin) s = k;
+    const int idx = it - A.sc[s].item_begin;
+    b = idx / A.sc[s].tiles;
+    t = idx - b * A.sc[s].tiles;
   }
   const ScaleArgs& S = A.sc[s];
   const int item = S.item_begin + b * S.tiles + t;
@@ -341,11 +319,15 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
   // the oldest during the second, and the waves of a SIMD finish closer together.  Only ever affects speed.
   const int prio_rank = min((int)(blockIdx.x >> 3) / A.simds_per_xcd, A.prio_top);
   set_issue_prio((int)((A.prio_tab >> (2 * prio_rank)) & 3u));
+  const int chunk = t / S.strips;
+  const int strip = t - chunk * S.strips;
   const int h = S.h, w = S.w;
   const int lane = threadIdx.x & 63;
   const int x = strip * HH::SW - HH::HL + lane;
   const bool xin = (x >= 0) && (x < w);
   const bool outl = (lane >= HH::HL) && (lane < 64 - HH::HR) && (x < w);
+  const int y0 = chunk * S.chunk_rows;
+  const int y1 = min(y0 + S.chunk_rows, h);
   const ScaleConst sc = make_scale_const(h, w);
   const size_t P = (size_t)h * w;
 
@@ -411,6 +393,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
     C.sc = sc;
     C.xc = (unsigned)min(max(x, 0), w - 1);
     C.xin = xin;
+    C.outb = outl;
     C.xinf = xin ? 1.f : 0.f;
     C.outf = outl ? 1.f : 0.f;
     C.lane = lane;
@@ -600,8 +583,6 @@ struct Tuning {
   int rows_list[SFM_MAX_SCALES] = {0};      // SFM_CHUNK_ROWS_LIST: chunk height per scale, "13,13,16,8"
   bool has_prio = false;
   unsigned prio_tab = 0;                    // SFM_PRIO_TABLE: "0123,3210" = levels of ranks 0.. in phase 1, phase 2
-  bool has_class_plan = false;              // SFM_CLASS_PLAN: "3x16+3x12+4x11;2x16+2x12+1x8;1x18+1x14;1x8+1x8" = per scale (';'),
-  int cls_n[SFM_MAX_SCALES][N_CLASSES] = {{0}}, cls_h[SFM_MAX_SCALES][N_CLASSES] = {{0}};   // per class ('+'): chunks x rows
   Tuning() {
     if (const char* e = getenv("SFM_CHUNK_ROWS")) chunk_rows = atoi(e);
     if (const char* rl = getenv("SFM_CHUNK_ROWS_LIST")) {
@@ -618,20 +599,6 @@ struct Tuning {
         else if (*pt >= '0' && *pt <= '3' && r < 4) { prio_tab |= (unsigned)(*pt - '0') << (8 * phase + 2 * r); ++r; }
       }
       has_prio = true;
-    }
-    if (const char* cp = getenv("SFM_CLASS_PLAN")) {
-      int sc = 0, k = 0;
-      while (*cp && sc < SFM_MAX_SCALES) {
-        const int n = atoi(cp);
-        while (*cp && *cp != 'x' && *cp != '+' && *cp != ';') ++cp;
-        int hh = 0;
-        if (*cp == 'x') { ++cp; hh = atoi(cp); }
-        while (*cp && *cp != '+' && *cp != ';') ++cp;
-        if (k < N_CLASSES) { cls_n[sc][k] = n; cls_h[sc][k] = hh; }
-        if (*cp == '+') { ++k; ++cp; }
-        else if (*cp == ';') { ++sc; k = 0; ++cp; }
-      }
-      has_class_plan = true;
     }
   }
 };
@@ -690,41 +657,6 @@ static long long max_items(const SfmLossDesc* d, int sw) {
   return items;
 }
 
-// chunk classes per scale (see ScaleArgs): n[s][k] chunks of h[s][k] rows, class 0 at the top of the image
-struct ChunkPlan {
-  int n[SFM_MAX_SCALES][N_CLASSES];
-  int h[SFM_MAX_SCALES][N_CLASSES];
-};
-
-static ChunkPlan uniform_chunk_plan(const SfmLossDesc* d, const int* rows) {
-  ChunkPlan cp;
-  memset(&cp, 0, sizeof(cp));
-  for (int s = 0; s < d->n_scales; ++s) {
-    cp.h[s][0] = rows[s];
-    cp.n[s][0] = (d->H[s] + rows[s] - 1) / rows[s];
-  }
-  return cp;
-}
-
-// a plan is usable when, per scale, its classes tile the image rows exactly (only the last chunk of a class may be clipped,
-// and only by the end of the image) with heights the kernel supports
-static bool chunk_plan_valid(const SfmLossDesc* d, const ChunkPlan& cp) {
-  for (int s = 0; s < d->n_scales; ++s) {
-    int y = 0;
-    for (int k = 0; k < N_CLASSES; ++k) {
-      if (cp.n[s][k] < 0) return false;
-      if (cp.n[s][k] == 0) continue;
-      if (cp.h[s][k] > MAX_CHUNK_ROWS) return false;
-      if (cp.h[s][k] < MIN_CHUNK_ROWS && cp.h[s][k] < d->H[s]) return false;   // (max_items sizes the workspace for chunks >= MIN_CHUNK_ROWS)
-      if (y >= d->H[s]) return false;                                   // a class that starts below the image
-      if (y + (cp.n[s][k] - 1) * cp.h[s][k] >= d->H[s]) return false;   // a chunk that starts below the image
-      y += cp.n[s][k] * cp.h[s][k];
-    }
-    if (y < d->H[s]) return false;
-  }
-  return true;
-}
-
 static void set_gy(struct Plan& p, const float gy);
 
 // validates the descriptor and lays out items + workspace for the given mode
@@ -778,13 +710,6 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
     A.prio_tab |= (unsigned)r << (2 * r) | (unsigned)(A.prio_top - r) << (8 + 2 * r);
   if (tuning().has_prio) A.prio_tab = tuning().prio_tab;
   plan_chunks(d, sw, 2 * (hs > hm ? hs : hm), slots, rows);
-  ChunkPlan cp = uniform_chunk_plan(d, rows);
-  if (tuning().has_class_plan) {
-    ChunkPlan forced;
-    memcpy(forced.n, tuning().cls_n, sizeof(forced.n));
-    memcpy(forced.h, tuning().cls_h, sizeof(forced.h));
-    if (chunk_plan_valid(d, forced)) cp = forced;
-  }
   int items = 0;
   for (int s = 0; s < d->n_scales; ++s) {
     const int h = d->H[s], w = d->W[s];
@@ -807,17 +732,9 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
     S.h = h;
     S.w = w;
     S.strips = (w + sw - 1) / sw;
-    int chunks = 0, y = 0;
-    for (int k = 0; k < N_CLASSES; ++k) {
-      S.cls_n[k] = cp.n[s][k];
-      S.cls_h[k] = cp.n[s][k] > 0 ? cp.h[s][k] : 1;
-      S.cls_y[k] = y;
-      S.cls_t[k] = chunks * S.strips;
-      y = y + cp.n[s][k] * cp.h[s][k] < h ? y + cp.n[s][k] * cp.h[s][k] : h;
-      S.cls_yend[k] = y;
-      chunks += cp.n[s][k];
-    }
-    S.tiles = S.strips * chunks;
+    S.chunk_rows = rows[s];
+    S.chunks = (h + rows[s] - 1) / rows[s];
+    S.tiles = S.strips * S.chunks;
     S.item_begin = items;
     items += d->B * S.tiles;
     const double nb = (double)d->norm_B;
@@ -849,7 +766,7 @@ static void set_gy(Plan& p, const float gy) {
   for (int s = 0; s < A.n_scales; ++s) {
     ScaleArgs& S = A.sc[s];
     S.k_pix = gy * (1.0f - A.alpha) * S.inv_cnt;
-    S.kq = -0.5f * gy * A.alpha * S.inv_cnt;
+    S.kq = -gy * A.alpha * S.inv_cnt;
     S.k_exp = gy * S.c_exp;
   }
 }
@@ -984,12 +901,7 @@ int sfm_loss_plan_info(const SfmLossDesc* desc, int grad, int loss, int* out, in
   for (int s = 0; s < desc->n_scales; ++s) {
     const sfm::ScaleArgs& S = p.args.sc[s];
     int* o = out + 1 + 4 * s;
-    int chunks = 0, rows = 0;
-    for (int k = 0; k < sfm::N_CLASSES; ++k) {
-      chunks += S.cls_n[k];
-      if (S.cls_n[k] > 0 && S.cls_h[k] > rows) rows = S.cls_h[k];
-    }
-    o[0] = S.strips; o[1] = chunks; o[2] = rows; o[3] = S.tiles;
+    o[0] = S.strips; o[1] = S.chunks; o[2] = S.chunk_rows; o[3] = S.tiles;
   }
   return SFM_OK;
 }

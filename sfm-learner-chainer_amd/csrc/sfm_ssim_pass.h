@@ -38,7 +38,7 @@ struct SsimCtx {
   const __attribute__((address_space(4))) Geom* gp;   // the geometry entry of this (sample, scale, source): read again by pose_sums_expand
   int x0;               // column of lane 0 (uniform); the lane's column is x0 + lane
   float k_pix;   // dL/d(sum |e|)        = gy (1-alpha) / (norm_B 3 h w)   base_model.py:111,117
-  float kq;      // -1/2 dL/d(sum ssim)  = -gy alpha / (2 norm_B 3 h w)    base_model.py:115,117,142
+  float kq;      // -dL/d(sum ssim)      = -gy alpha / (norm_B 3 h w): 2 kappa of App. A.3   base_model.py:115,117,142
   int h, w, y0, y1;
   const float* tp[3];   // target planes of this sample
   const float* sp[3];   // source planes of this (sample, source)
@@ -53,6 +53,7 @@ struct SsimCtx {
   float mx[3];          // M[k][0] x + M[k][2]
   unsigned xc;          // column, clamped into the image (address-safe for halo lanes)
   bool xin;             // column inside the image
+  bool outb;            // output lane (not halo, inside the image)
   float xinf;           // ... as a factor: 1 or 0 (a multiply issues faster than a select)
   float outf;           // 1 for an output lane, else 0
   int lane;
@@ -71,6 +72,9 @@ struct Ch3 {
 __device__ __forceinline__ Ch3 ch3(float c0, float c1, float c2) { Ch3 r; r.p.x = c0; r.p.y = c1; r.s = c2; return r; }
 __device__ __forceinline__ Ch3 ch3_zero() { return ch3(0.f, 0.f, 0.f); }
 
+template <typename T> __device__ __forceinline__ T T_of(float v);
+template <> __device__ __forceinline__ float T_of<float>(float v) { return v; }
+template <> __device__ __forceinline__ f2 T_of<f2>(float v) { f2 r; r.x = v; r.y = v; return r; }
 __device__ __forceinline__ f2 vfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ float vfma(float a, float b, float c) { return fmaf(a, b, c); }
 __device__ __forceinline__ f2 vrcp(f2 a) { f2 r; r.x = rcp(a.x); r.y = rcp(a.y); return r; }
@@ -102,6 +106,25 @@ __device__ __forceinline__ void hsum3_group(T& a, T& b, T& c) {
   a = add_right(la, a); b = add_right(lb, b); c = add_right(lc, c);
   __builtin_amdgcn_sched_barrier(0);
 }
+// the same for the fields of both channel groups in one run (the scalar group's DPP adds first: its producers are the older ones)
+__device__ __forceinline__ void hsum3_group(f2& a, f2& b, f2& c, f2& d, float& e, float& f, float& g, float& h) {
+  pin(a); pin(b); pin(c); pin(d); pin(e); pin(f); pin(g); pin(h);
+  __builtin_amdgcn_sched_barrier(0);
+  const float le = add_left(e), lf = add_left(f), lg = add_left(g), lh = add_left(h);
+  const f2 la = add_left(a), lb = add_left(b), lc = add_left(c), ld = add_left(d);
+  e = add_right(le, e); f = add_right(lf, f); g = add_right(lg, g); h = add_right(lh, h);
+  a = add_right(la, a); b = add_right(lb, b); c = add_right(lc, c); d = add_right(ld, d);
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void hsum3_group(f2& a, f2& b, f2& c, float& e, float& f, float& g) {
+  pin(a); pin(b); pin(c); pin(e); pin(f); pin(g);
+  __builtin_amdgcn_sched_barrier(0);
+  const float le = add_left(e), lf = add_left(f), lg = add_left(g);
+  const f2 la = add_left(a), lb = add_left(b), lc = add_left(c);
+  e = add_right(le, e); f = add_right(lf, f); g = add_right(lg, g);
+  a = add_right(la, a); b = add_right(lb, b); c = add_right(lc, c);
+  __builtin_amdgcn_sched_barrier(0);
+}
 // clip((1 - S) / 2, 0, 1) as one multiply-add with the clamp output modifier (the compiler folds the scalar form by itself;
 // for the packed pair it splits the clamp off into two v_max, so that one is written out)
 __device__ __forceinline__ float half_one_minus_clamped(float S) { return fminf(fmaxf(fmaf(S, -0.5f, 0.5f), 0.f), 1.f); }
@@ -110,12 +133,6 @@ __device__ __forceinline__ f2 half_one_minus_clamped(f2 S) {
   asm("v_pk_fma_f32 %0, %1, 0.5, 0.5 op_sel_hi:[1,0,0] neg_lo:[1,0,0] neg_hi:[1,0,0] clamp" : "=v"(r) : "v"(S));
   return r;
 }
-// v where 0 < e < 1, else 0   (F.clip backward)
-__device__ __forceinline__ f2 vsel_open01(f2 e, f2 v) {
-  const f2 t = e * (1.f - e);
-  f2 r; r.x = t.x > 0.f ? v.x : 0.f; r.y = t.y > 0.f ? v.y : 0.f; return r;
-}
-__device__ __forceinline__ float vsel_open01(float e, float v) { return (e * (1.f - e) > 0.f) ? v : 0.f; }
 // k * sign(d), sign(0) = 0   (F.absolute backward; k carries the sign of the upstream gradient)
 __device__ __forceinline__ float ksign(float k, float d) {
   return (d != 0.f) ? __uint_as_float(__float_as_uint(k) ^ (__float_as_uint(d) & 0x80000000u)) : 0.f;
@@ -128,7 +145,7 @@ __device__ __forceinline__ float vhadd(float v) { return v; }
 
 struct RowS {            // a warped row as the later stages need it (per lane = per pixel)
   Ch3 ih, it;            // I^ (0 where not in view / outside the image), I (0 outside the image)
-  Ch3 du, dv;            // dI^/du, dI^/dv, pre-multiplied by 1/z (0 where not in view)
+  Ch3 du, dv;            // dI^/du, dI^/dv, pre-multiplied by 1/z (0 where not in view and on halo lanes)
   float U, V, D;         // q0/z, q1/z, depth
   float nm;              // 1 - mask, mask = all three channels of I^ exactly 0   base_model.py:96
 };
@@ -140,7 +157,8 @@ struct Pipe {            // a row whose gathers are in flight
   float it[3];
   float fu, fv, U, V, rz, D;
   float lg;              // explainability logit (only loaded when C.mp != nullptr)
-  bool inview;
+  bool inview;           // the sample is taken (in view, column inside the image)
+  bool inview_o;         // ... and the lane is an output lane: only there do dI^/du, dI^/dv exist (a halo lane has no gradient of its own)
 };
 
 __device__ __forceinline__ void zero(RowS& s) {
@@ -183,6 +201,7 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
   const Proj p = project(a0, a1, a2, C.P3[0], C.P3[1], C.P3[2], ps.D, C.sc, C.h, C.w);
   ps.U = p.U; ps.V = p.V; ps.rz = p.rz; ps.fu = p.fu; ps.fv = p.fv;
   ps.inview = p.inview && C.xin;
+  ps.inview_o = p.inview && C.outb;
 #ifdef SFM_ABLATE_MEM   // timing experiment only: every access hits the same few cache lines
   const unsigned off = (unsigned)((p.v0 * C.w + p.u0) & 63);
   const unsigned offt = (unsigned)((r * C.w + C.xc) & 63);
@@ -227,7 +246,7 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
 
 // stage A, second half: bilinear value and derivatives from the gathered taps
 __device__ __forceinline__ void finish_row(const SsimCtx& C, const Pipe& ps, RowS& s) {
-  const float rzi = ps.inview ? ps.rz : 0.f;
+  const float rzi = ps.inview_o ? ps.rz : 0.f;   // halo lanes get zero derivatives: nothing downstream of dL/dq needs a lane mask
   unsigned nz = 0;
   float ih[3], it[3], du[3], dv[3];
 #pragma unroll
@@ -256,8 +275,6 @@ __device__ __forceinline__ void finish_row(const SsimCtx& C, const Pipe& ps, Row
 __device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& s2, const int rc, float gq0, float gq1,
                                                   const float* gI, float* gacc, const bool first, float* gpm) {
   const int h = C.h, w = C.w;
-  gq0 *= C.outf;
-  gq1 *= C.outf;
   const float gq2 = -fmaf(gq0, s2.U, gq1 * s2.V);
   const float yf = (float)rc;
   const float a0 = fmaf(C.M1[0], yf, C.mx[0]), a1 = fmaf(C.M1[1], yf, C.mx[1]), a2 = fmaf(C.M1[2], yf, C.mx[2]);
@@ -331,39 +348,50 @@ __device__ __forceinline__ void pose_sums_expand(const SsimCtx& C, const float* 
   }
 }
 
-// Stage B for one channel group (T = f2: channels 0,1; T = float: channel 2).
+// Stage B, split in the three parts that the two channel groups (T = f2: channels 0,1; T = float: channel 2) run in step:
 //   x2,x1,x0 / y2,y1,y0: I^ and I of rows r-2, r-1, r;  out: horizontal 3-sums of the three SSIM partials of row r-1
 // SSIM in scaled sums (Sx = 9 mu_x ...), see the header of this file; models/base_model.py:130-142.
-template <bool GRAD, bool LOSS, typename T>
-__device__ __forceinline__ void ssim_stage_b(const T x2, const T x1, const T x0, const T y2, const T y1, const T y0,
-                                             const float kq_nm, T& ga, T& gb, T& ge, float& ssum) {
-  const float C1 = 81.f * 0.0001f, C2 = 81.f * 0.0009f;             // 81 c1, 81 c2   base_model.py:127-128
-  // separable 3x3 sums around (r-1, x): vertical over the ring rows r-2..r (in-lane), then horizontal (DPP)
-  T Sx = x2 + x1 + x0;
-  T Sy = y2 + y1 + y0;
+template <typename T>
+struct SsimSums { T Sx, Sy, Sqq, Sxy; };
+
+// (1) vertical 3-sums over the ring rows r-2..r (in-lane); the horizontal ones follow for both groups together (ssim_stage_b_row)
+template <typename T>
+__device__ __forceinline__ void ssim_vsums(const T x2, const T x1, const T x0, const T y2, const T y1, const T y0, SsimSums<T>& o) {
+  o.Sx = x2 + x1 + x0;
+  o.Sy = y2 + y1 + y0;
   // sigma_x + sigma_y only ever appear together (base_model.py:138), so E[xx] and E[yy] are pooled as one field
-  T Sqq = vfma(x2, x2, vfma(x1, x1, vfma(x0, x0, vfma(y2, y2, vfma(y1, y1, y0 * y0)))));
-  T Sxy = vfma(x2, y2, vfma(x1, y1, x0 * y0));
-  hsum3_group(Sx, Sy, Sqq, Sxy);
+  o.Sqq = vfma(x2, x2, vfma(x1, x1, vfma(x0, x0, vfma(y2, y2, vfma(y1, y1, y0 * y0)))));
+  o.Sxy = vfma(x2, y2, vfma(x1, y1, x0 * y0));
+}
+
+// v where |S| < 1, else 0: F.clip backward of clip((1 - S) / 2, 0, 1) -- strictly inside (0, 1) exactly when -1 < S < 1
+// (a NaN fails the test, like the clamped value it would produce)
+__device__ __forceinline__ float vsel_abs_lt1(float S, float v) { return (fabsf(S) < 1.f) ? v : 0.f; }
+__device__ __forceinline__ f2 vsel_abs_lt1(f2 S, f2 v) { f2 r; r.x = vsel_abs_lt1(S.x, v.x); r.y = vsel_abs_lt1(S.y, v.y); return r; }
+
+// (2) SSIM value from the pooled sums and, with GRAD, its three partials BEFORE their horizontal 3-sums, in the scaling
+//   ga = (1/9) kappa dS/dmu_x,   gb = (-2/81) kappa dS/dE[xx],   ge = (1/81) kappa dS/dE[xy]
+// (kq2_nm carries kappa's factor 2: with these scalings no constant multiplies are left here; stage C applies the 9)
+template <bool GRAD, bool LOSS, typename T>
+__device__ __forceinline__ void ssim_value_partials(const SsimSums<T>& p, const float kq2_nm, T& ga, T& gb, T& ge, float& ssum) {
+  const float C1 = 81.f * 0.0001f, C2 = 81.f * 0.0009f;             // 81 c1, 81 c2   base_model.py:127-128
+  const T Sx = p.Sx, Sy = p.Sy;
   const T pxy = Sx * Sy;
   const T sq = vfma(Sx, Sx, Sy * Sy);
   const T N1 = pxy * 2.f + C1;
-  const T N2 = pxy * -2.f + (Sxy * 18.f + C2);
+  const T N2 = pxy * -2.f + (p.Sxy * 18.f + C2);
   const T D1 = sq + C1;
-  const T D2 = (Sqq * 9.f + C2) - sq;
+  const T D2 = (p.Sqq * 9.f + C2) - sq;
   const T rD = vrcp(D1 * D2);
   const T Sv = N1 * N2 * rD;                                        // base_model.py:140
-  // (1 - SSIM) / 2 clipped to [0, 1] (base_model.py:142) in ONE instruction: the clamp rides on the multiply-add as its output
-  // modifier.  The clip's backward mask 0 < e < 1 is taken from the clipped value, which is strictly inside exactly when e is.
-  const T e = half_one_minus_clamped(Sv);
-  if (LOSS) ssum += vhadd(e);
+  // (1 - SSIM) / 2 clipped to [0, 1] (base_model.py:142) in ONE instruction: the clamp rides on the multiply-add as its output modifier
+  if (LOSS) ssum += vhadd(half_one_minus_clamped(Sv));
   if (GRAD) {
-    const T kap = vsel_open01(e, rD * kq_nm);                       // kappa / (D1 D2); F.clip backward: 0 < e < 1
+    const T kap = vsel_abs_lt1(Sv, rD * kq2_nm);                    // 2 kappa / (D1 D2); F.clip backward
     const T u3 = vfma(-(Sv * Sx), D2 - D1, Sy * (N2 - N1));
-    ga = kap * u3 * 2.f;                      // (1/9) kappa dS/dmu_x
-    gb = kap * Sv * D1 * -9.f;                // (1/9) kappa dS/dE[xx]
-    ge = kap * N1 * 18.f;                     // (1/9) kappa dS/dE[xy]
-    hsum3_group(ga, gb, ge);
+    ga = kap * u3;
+    gb = kap * Sv * D1;
+    ge = kap * N1;
   }
 }
 
@@ -374,7 +402,8 @@ __device__ __forceinline__ void ssim_stage_c(const T a2, const T a1, const T a0,
                                              const T e1, const T e0, const T ih, const T it, const T du, const T dv,
                                              const float kpn, T& g, T& q0, T& q1) {
   const T Aq = a2 + a1 + a0, Bq = b2 + b1 + b0, Eq = e2 + e1 + e0;
-  g = vfma(it, Eq, vfma(ih * 2.f, Bq, Aq)) + ksign(kpn, ih - it);
+  // dL/dI^ = A + 2 I^ B + I E in the partials' own scaling (ssim_value_partials): A + 9 (I E' - I^ B')
+  g = vfma(vfma(it, Eq, -(ih * Bq)), T_of<T>(9.f), Aq) + ksign(kpn, ih - it);
   q0 = g * du;
   q1 = g * dv;
 }
@@ -386,9 +415,17 @@ template <bool GRAD, bool LOSS>
 __device__ __forceinline__ void ssim_stage_b_row(const SsimCtx& C, const RowS& s2, const RowS& s1, const RowS& s0, RowG& g0,
                                                  const bool count, float& acc_pix, float& acc_ssim) {
   float ssum = 0.f;
-  const float kq_nm = C.kq * s1.nm;   // kappa before the clip test; s1.nm is 0 outside the image and on masked pixels (:114)
-  ssim_stage_b<GRAD, LOSS>(s2.ih.p, s1.ih.p, s0.ih.p, s2.it.p, s1.it.p, s0.it.p, kq_nm, g0.a.p, g0.b.p, g0.e.p, ssum);
-  ssim_stage_b<GRAD, LOSS>(s2.ih.s, s1.ih.s, s0.ih.s, s2.it.s, s1.it.s, s0.it.s, kq_nm, g0.a.s, g0.b.s, g0.e.s, ssum);
+  const float kq2_nm = C.kq * s1.nm;   // 2 kappa before the clip test; s1.nm is 0 outside the image and on masked pixels (:114)
+  // Both channel groups go through each part together: ONE run of DPP adds per horizontal 3-sum of all their fields (eight
+  // pooled sums, then six partials) instead of one per group -- every run starts with the wait states of the DPP hazard.
+  SsimSums<f2> pp;
+  SsimSums<float> ps;
+  ssim_vsums(s2.ih.p, s1.ih.p, s0.ih.p, s2.it.p, s1.it.p, s0.it.p, pp);
+  ssim_vsums(s2.ih.s, s1.ih.s, s0.ih.s, s2.it.s, s1.it.s, s0.it.s, ps);
+  hsum3_group(pp.Sx, pp.Sy, pp.Sqq, pp.Sxy, ps.Sx, ps.Sy, ps.Sqq, ps.Sxy);
+  ssim_value_partials<GRAD, LOSS>(pp, kq2_nm, g0.a.p, g0.b.p, g0.e.p, ssum);
+  ssim_value_partials<GRAD, LOSS>(ps, kq2_nm, g0.a.s, g0.b.s, g0.e.s, ssum);
+  if (GRAD) hsum3_group(g0.a.p, g0.b.p, g0.e.p, g0.a.s, g0.b.s, g0.e.s);
   if (LOSS) {
     const float wgt = count ? s1.nm * C.outf : 0.f;
     acc_ssim = fmaf(ssum, wgt, acc_ssim);                            // base_model.py:114-115

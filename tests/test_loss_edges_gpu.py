@@ -167,17 +167,3 @@ def test_forced_chunk_heights(rows):
     env = dict(os.environ, SFM_CHUNK_ROWS=str(rows))
     r = subprocess.run([sys.executable, os.path.join(here, "forced_chunks_probe.py")], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and ("OK rows=%d" % rows) in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
-
-
-@pytest.mark.parametrize("plan,chunks", [("2x20+2x14+2x8;1x20+1x12+1x10", "6,3"), ("1x28+3x12+4x6;0x0+2x21", "8,2")])
-def test_forced_class_plan(plan, chunks):
-    """Chunks of several heights per scale (the rank-weighted plans of plan_chunks), forced through SFM_CLASS_PLAN in a child
-    process: three classes per scale, an empty first class, a clipped last chunk (84 = 28 + 36 + 3 x 6 + 2; 42 = 2 x 21)."""
-    import os
-    import subprocess
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, SFM_CLASS_PLAN=plan, SFM_PROBE_CHUNKS=chunks)
-    env.pop("SFM_CHUNK_ROWS", None)
-    r = subprocess.run([sys.executable, os.path.join(here, "forced_chunks_probe.py")], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "OK rows=0" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

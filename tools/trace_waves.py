@@ -12,7 +12,7 @@ d = synth.make_inputs(B=TB, H=TH, W=TW, n_src=TS, n_scales=4, seed=1)
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 layout = os.environ.get("SFM_LAYOUT", "hwc")
 cv = (lambda a: ops.to_hwc(t(a))) if layout == "hwc" else t
-fl = ops.FusedLoss(smooth_reg=0.1, ssim_rate=0.15).bind([cv(a) for a in d["tgt_pyr"]], [cv(a) for a in d["src_pyr"]], t(d["intrinsics"]),
+fl = ops.FusedLoss(smooth_reg=0.1, ssim_rate=0.15, smooth_mode=os.environ.get("SFM_TRACE_SMOOTH", "second_order")).bind([cv(a) for a in d["tgt_pyr"]], [cv(a) for a in d["src_pyr"]], t(d["intrinsics"]),
                                                         [t(a) for a in d["disps"]], [t(a) for a in d["poses"]], layout=layout)
 run = {"fused": fl.forward_backward, "fwd": fl.forward, "bwd": lambda: fl.backward(1.0)}[mode]
 for _ in range(5): run()
@@ -100,6 +100,22 @@ elif stamps:
                 rk, m.sum(), dur_cyc[m].mean() / 1e3, src[m].mean() / 1e3, loop[m].mean() / 1e3, (loop[m] / b[m, 4]).mean(), b[m, 4].mean(),
                 (src[m] - loop[m]).mean() / 1e3, sm[m].mean() / 1e3, (dur_cyc[m] - src[m] - sm[m]).mean() / 1e3,
                 (b[m, 0] / b[m, 4]).mean(), (b[m, 1] / b[m, 4]).mean(), (b[m, 2] / b[m, 4]).mean(), (b[m, 3] / b[m, 4]).mean()))
+# finish time by DISPATCH round (age rank on the SIMD: workgroups j, j + S, j + 2S of an XCD share a SIMD)
+loc = wg >> 3
+S_xcd = max(1, len(u) // 8)
+drank = np.minimum(loc // S_xcd, 3)
+for rk in range(4):
+    m = drank == rk
+    if m.any():
+        print("dispatch-round %d: n=%d  start p50 %.2f us  end mean %.1f p10 %.1f p50 %.1f p90 %.1f us" % (
+            rk, m.sum(), np.percentile(st[m], 50), en[m].mean(), *np.percentile(en[m], [10, 50, 90])))
+order_d = np.zeros(len(a), int)
+for kk in u:
+    idx = np.where(key == kk)[0]
+    order_d[idx[np.argsort(en[idx])]] = np.arange(len(idx))
+print("finish order vs dispatch round (rows: dispatch round, cols: finish rank on its SIMD):")
+for rk in range(3):
+    print("  ", rk, [int(((drank == rk) & (order_d == f)).sum()) for f in range(3)])
 # per-SIMD completion times: is the launch limited by throughput (all SIMDs end together) or by imbalance?
 simd_end = np.array([en[key == kk].max() for kk in u])
 simd_work = np.array([(en - st)[key == kk].sum() for kk in u])
