@@ -237,6 +237,18 @@ __device__ __forceinline__ void stf(float* base, const unsigned idx, const float
   *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + idx * 4u) = v;
 }
 
+// The same store written THROUGH the XCD's L2 (sc1): for outputs that nothing in this launch reads again.  A plain store leaves
+// its line dirty in L2 until the release at the end of the kernel writes all of them back at once -- time the dispatch is
+// charged for and the next kernel waits for (MI355X_MICROARCH.md, 'boundary': + B / 6 TB/s for B dirty bytes); written through,
+// the bytes leave while the other waves still compute.
+__device__ __forceinline__ void stf_wt(float* base, const unsigned idx, const float v) {
+#ifdef SFM_PLAIN_OUTPUT_STORES
+  stf(base, idx, v);
+#else
+  __hip_atomic_store(reinterpret_cast<float*>(reinterpret_cast<char*>(base) + idx * 4u), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
 // ------------------------------------------------------------------------------------------
 // The per-pixel projection + sampling coordinates shared by every kernel.
 //

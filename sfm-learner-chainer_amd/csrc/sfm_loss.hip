@@ -237,12 +237,13 @@ __device__ __forceinline__ void smooth_edge_pass(const LossArgs& A, const ScaleA
     const float wx = __builtin_amdgcn_exp2f(fabsf(sx) * KE) * vx1f;
     const float wy = __builtin_amdgcn_exp2f(fabsf(sy3) * KE) * rowf;
     const float sy = ksign(wy, ddy);
+    // (tx and its neighbour difference are formed for every row, the one above the chunk included: a cross-lane read is not
+    // moved into the branch below, and left outside on its own it costs a register copy per operand instead of riding on the subtraction)
+    const float tx = ksign(wx, ddx);
+    const float gx = from_left(tx) - tx;
     if (q >= y0) {
       if (LOSS) acc_sm = fmaf(outf, fmaf(cex * fabsf(ddx), wx, cey * fabsf(ddy) * wy), acc_sm);
-      if (GRAD) {
-        const float tx = ksign(wx, ddx);
-        tile_put(gacc + (q - y0) * 64 + lane, fmaf(gcy, sy_prev - sy, gcx * (from_left(tx) - tx)), add);
-      }
+      if (GRAD) tile_put(gacc + (q - y0) * 64 + lane, fmaf(gcy, sy_prev - sy, gcx * gx), add);
     }
     sy_prev = sy;
   };
@@ -369,6 +370,33 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
     const float xf = (float)x;
     C.gp = gp;
     C.x0 = x - lane;
+#ifdef SFM_GEOM_IN_WAVE   // experiment: every wave builds the geometry of its pass itself, no geom_kernel, no table
+    {
+      typedef const __attribute__((address_space(4))) float* ConstF;
+      ConstF pp = (ConstF)(uintptr_t)(A.pose[i] + b * 6);
+      ConstF kp = (ConstF)(uintptr_t)(A.intrinsics + (size_t)(b * A.n_scales + s) * 9);
+      float pose6[6], K9[9];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) pose6[k] = pp[k];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) K9[k] = kp[k];
+      Geom g;
+      make_geom(pose6, K9, g);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        C.M1[k] = uniform(g.M[k * 3 + 1]);
+        C.P3[k] = uniform(g.P[k * 4 + 3]);
+        C.mx[k] = fmaf(uniform(g.M[k * 3 + 0]), xf, uniform(g.M[k * 3 + 2]));
+        C.K1[k] = uniform(g.Kinv[k * 3 + 1]);
+        C.kx[k] = fmaf(uniform(g.Kinv[k * 3 + 0]), xf, uniform(g.Kinv[k * 3 + 2]));
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      C.tp[k] = S.tgt + ((size_t)b * 3 + k) * P;
+      C.sp[k] = S.src + (((size_t)b * A.n_src + i) * 3 + k) * P;
+    }
+#else
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       C.M1[k] = gp->M[k * 3 + 1];
@@ -377,6 +405,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
       C.tp[k] = S.tgt + ((size_t)b * 3 + k) * P;
       C.sp[k] = S.src + (((size_t)b * A.n_src + i) * 3 + k) * P;
     }
+#endif
     C.k_pix = S.k_pix;
     C.kq = S.kq;
     C.k_exp = S.k_exp;
@@ -412,7 +441,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
   if (GRAD) {
     if (outl) {
       float* o = S.d_disp + (size_t)b * P;
-      for (int q = y0; q < y1; ++q) stf(o, (unsigned)(q * w + x), gacc[(q - y0) * 64 + lane]);
+      for (int q = y0; q < y1; ++q) stf_wt(o, (unsigned)(q * w + x), gacc[(q - y0) * 64 + lane]);
     }
   }
   if (A.trace && lane == 0) {   // timing-only diagnostics; never read by any kernel
@@ -862,7 +891,11 @@ static int run(const SfmLossDesc* d, bool grad, bool loss, float gy, float* loss
   if (((uintptr_t)ws & 255) != 0) return fail(SFM_ERR_WORKSPACE, "%s: workspace must be 256-byte aligned", who);
   bind_workspace(p, ws);
   const int ng = d->B * d->n_scales * d->n_src;
+#ifndef SFM_GEOM_IN_WAVE
   hipLaunchKernelGGL(geom_kernel, dim3((ng + 63) / 64), dim3(64), 0, st, p.args);
+#else
+  (void)ng;
+#endif
   p.args.trace = g_trace;
   g_trace = nullptr;
   hipEvent_t ev_start = g_ev_start, ev_stop = g_ev_stop;

@@ -51,6 +51,9 @@ struct SsimCtx {
   ScaleConst sc;
   // per lane
   float mx[3];          // M[k][0] x + M[k][2]
+#ifdef SFM_GEOM_IN_WAVE
+  float K1[3], kx[3];   // Kinv[j][1] (uniform), Kinv[j][0] x + Kinv[j][2]: for pose_sums_expand
+#endif
   unsigned xc;          // column, clamped into the image (address-safe for halo lanes)
   bool xin;             // column inside the image
   bool outb;            // output lane (not halo, inside the image)
@@ -133,11 +136,32 @@ __device__ __forceinline__ f2 half_one_minus_clamped(f2 S) {
   asm("v_pk_fma_f32 %0, %1, 0.5, 0.5 op_sel_hi:[1,0,0] neg_lo:[1,0,0] neg_hi:[1,0,0] clamp" : "=v"(r) : "v"(S));
   return r;
 }
-// k * sign(d), sign(0) = 0   (F.absolute backward; k carries the sign of the upstream gradient)
-__device__ __forceinline__ float ksign(float k, float d) {
-  return (d != 0.f) ? __uint_as_float(__float_as_uint(k) ^ (__float_as_uint(d) & 0x80000000u)) : 0.f;
+// sign(d) with sign(0) = 0 (F.absolute backward) as the difference of two clamped products: clamp(d * 2^127, 0, 1) is 1 for every
+// normal d > 0 and 0 for d <= 0 -- the clamp rides on the multiply as its output modifier, and these multiplies and the
+// subtraction issue at the full rate, where the compare + select + sign-bit form needs three slow-class instructions per value
+// (profiles/r03_op_cost_microbench.txt).  (A difference of two image values is either 0 or far above 2^-126: for denormal d the
+// result would be a fraction of 1.)
+__device__ __forceinline__ float sign01(float d) {
+  const float big = 0x1p127f;
+  float sp, sm;
+  asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(sp) : "v"(d), "s"(big));
+  asm("v_mul_f32_e64 %0, -%1, %2 clamp" : "=v"(sm) : "v"(d), "s"(big));
+  return sp - sm;
 }
-__device__ __forceinline__ f2 ksign(float k, f2 d) { f2 r; r.x = ksign(k, d.x); r.y = ksign(k, d.y); return r; }
+__device__ __forceinline__ f2 sign01(f2 d) {
+  f2 big;   // (a packed operand is a 64-bit register pair: the constant sits in one scalar pair, both halves)
+  big.x = 0x1p127f; big.y = 0x1p127f;
+  f2 sp, sm;
+  asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(sp) : "v"(d), "s"(big));
+  asm("v_pk_mul_f32 %0, %1, %2 neg_lo:[1,0] neg_hi:[1,0] clamp" : "=v"(sm) : "v"(d), "s"(big));
+  return sp - sm;
+}
+// k * sign(d)   (k carries the sign of the upstream gradient)
+__device__ __forceinline__ float ksign(float k, float d) { return k * sign01(d); }
+__device__ __forceinline__ f2 ksign(float k, f2 d) { return sign01(d) * k; }
+// g + k * sign(d)
+__device__ __forceinline__ float add_ksign(float g, float k, float d) { return fmaf(sign01(d), k, g); }
+__device__ __forceinline__ f2 add_ksign(f2 g, float k, f2 d) { return vfma(sign01(d), T_of<f2>(k), g); }
 __device__ __forceinline__ float vabs_sum(f2 d) { return fabsf(d.x) + fabsf(d.y); }
 __device__ __forceinline__ float vabs_sum(float d) { return fabsf(d); }
 __device__ __forceinline__ float vhadd(f2 v) { return v.x + v.y; }
@@ -145,8 +169,10 @@ __device__ __forceinline__ float vhadd(float v) { return v; }
 
 struct RowS {            // a warped row as the later stages need it (per lane = per pixel)
   Ch3 ih, it;            // I^ (0 where not in view / outside the image), I (0 outside the image)
-  Ch3 du, dv;            // dI^/du, dI^/dv, pre-multiplied by 1/z (0 where not in view and on halo lanes)
+  Ch3 du, dv;            // dI^/du, dI^/dv (of whatever the tap registers held where the sample is not in view: rzi masks them)
   float U, V, D;         // q0/z, q1/z, depth
+  float rzi;             // 1/z where the sample is in view AND the lane is an output lane, else 0: the factor that takes
+                         // dL/d(u,v) to dL/d(q0,q1), and the only mask the gradient needs downstream
   float nm;              // 1 - mask, mask = all three channels of I^ exactly 0   base_model.py:96
 };
 struct RowG { Ch3 a, b, e; };                             // horizontal 3-sums of the SSIM partials
@@ -163,7 +189,7 @@ struct Pipe {            // a row whose gathers are in flight
 
 __device__ __forceinline__ void zero(RowS& s) {
   s.ih = s.it = s.du = s.dv = ch3_zero();
-  s.U = s.V = s.D = s.nm = 0.f;
+  s.U = s.V = s.D = s.rzi = s.nm = 0.f;
 }
 __device__ __forceinline__ void zero(RowG& s) { s.a = s.b = s.e = ch3_zero(); }
 // The same zeros, but produced by instructions the compiler must leave where they are written.  The ring slot of a row
@@ -181,7 +207,7 @@ __device__ __forceinline__ Ch3 ch3_opaque_zero() {
 }
 __device__ __forceinline__ void zero_rare(RowS& s) {
   s.ih = ch3_opaque_zero(); s.it = ch3_opaque_zero(); s.du = ch3_opaque_zero(); s.dv = ch3_opaque_zero();
-  s.U = opaque_zero(); s.V = opaque_zero(); s.D = opaque_zero(); s.nm = opaque_zero();
+  s.U = opaque_zero(); s.V = opaque_zero(); s.D = opaque_zero(); s.rzi = opaque_zero(); s.nm = opaque_zero();
 }
 
 // stage A, first half: project row r and issue its loads (row r is inside the image)
@@ -246,7 +272,6 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
 
 // stage A, second half: bilinear value and derivatives from the gathered taps
 __device__ __forceinline__ void finish_row(const SsimCtx& C, const Pipe& ps, RowS& s) {
-  const float rzi = ps.inview_o ? ps.rz : 0.f;   // halo lanes get zero derivatives: nothing downstream of dL/dq needs a lane mask
   unsigned nz = 0;
   float ih[3], it[3], du[3], dv[3];
 #pragma unroll
@@ -257,8 +282,8 @@ __device__ __forceinline__ void finish_row(const SsimCtx& C, const Pipe& ps, Row
     const float dvv = bot - top;
     const float val = ps.inview ? fmaf(ps.fv, dvv, top) : 0.f;
     ih[c] = val;
-    dv[c] = dvv * rzi;
-    du[c] = fmaf(ps.fv, dxb - dxt, dxt) * rzi;
+    dv[c] = dvv;
+    du[c] = fmaf(ps.fv, dxb - dxt, dxt);
     it[c] = ps.it[c] * C.xinf;       // 0 outside the image (the load came from the clamped column)
     nz |= __float_as_uint(val);
   }
@@ -267,7 +292,15 @@ __device__ __forceinline__ void finish_row(const SsimCtx& C, const Pipe& ps, Row
   s.du = ch3(du[0], du[1], du[2]);
   s.dv = ch3(dv[0], dv[1], dv[2]);
   s.U = ps.U; s.V = ps.V; s.D = ps.D;
-  s.nm = ((nz << 1) != 0u) ? 1.f : 0.f;                             // base_model.py:96 (+-0 both count as 0)
+  s.rzi = ps.inview_o ? ps.rz : 0.f;   // halo lanes get no gradient of their own
+  // base_model.py:96: mask = all three channels exactly 0 (+-0 both count).  nz without its sign bit, read as a float, is 0 or
+  // at least the smallest magnitude among the channels: the clamped product with 2^127 is the 0 / 1 indicator (one full-rate
+  // instruction; shift + compare + select are three of the slow class)
+  {
+    const float big = 0x1p127f;
+    const float mag = __uint_as_float(nz & 0x7fffffffu);
+    asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(s.nm) : "v"(mag), "s"(big));
+  }
 }
 
 // From dL/dI^ of one pixel (already contracted with dI^/du, dI^/dv and 1/z into gq0, gq1) to its
@@ -318,8 +351,12 @@ __device__ __forceinline__ void pose_sums_expand(const SsimCtx& C, const float* 
   float K1[3], kx[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
+#ifdef SFM_GEOM_IN_WAVE
+    K1[j] = C.K1[j]; kx[j] = C.kx[j]; (void)xf;
+#else
     K1[j] = C.gp->Kinv[j * 3 + 1];
     kx[j] = fmaf(C.gp->Kinv[j * 3 + 0], xf, C.gp->Kinv[j * 3 + 2]);
+#endif
   }
   float v[12];
 #pragma unroll
@@ -372,20 +409,21 @@ __device__ __forceinline__ f2 vsel_abs_lt1(f2 S, f2 v) { f2 r; r.x = vsel_abs_lt
 // (2) SSIM value from the pooled sums and, with GRAD, its three partials BEFORE their horizontal 3-sums, in the scaling
 //   ga = (1/9) kappa dS/dmu_x,   gb = (-2/81) kappa dS/dE[xx],   ge = (1/81) kappa dS/dE[xy]
 // (kq2_nm carries kappa's factor 2: with these scalings no constant multiplies are left here; stage C applies the 9)
-template <bool GRAD, bool LOSS, typename T>
+template <bool GRAD, bool LOSS, bool FIRST, typename T>
 __device__ __forceinline__ void ssim_value_partials(const SsimSums<T>& p, const float kq2_nm, T& ga, T& gb, T& ge, float& ssum) {
   const float C1 = 81.f * 0.0001f, C2 = 81.f * 0.0009f;             // 81 c1, 81 c2   base_model.py:127-128
   const T Sx = p.Sx, Sy = p.Sy;
   const T pxy = Sx * Sy;
   const T sq = vfma(Sx, Sx, Sy * Sy);
   const T N1 = pxy * 2.f + C1;
-  const T N2 = pxy * -2.f + (p.Sxy * 18.f + C2);
+  const T N2 = vfma(p.Sxy, T_of<T>(18.f), vfma(pxy, T_of<T>(-2.f), T_of<T>(C2)));   // (one non-inline constant per instruction: a packed
+                                                                                     //  op takes a single scalar operand, a second one costs a register copy)
   const T D1 = sq + C1;
-  const T D2 = (p.Sqq * 9.f + C2) - sq;
+  const T D2 = vfma(p.Sqq, T_of<T>(9.f), C2 - sq);
   const T rD = vrcp(D1 * D2);
   const T Sv = N1 * N2 * rD;                                        // base_model.py:140
   // (1 - SSIM) / 2 clipped to [0, 1] (base_model.py:142) in ONE instruction: the clamp rides on the multiply-add as its output modifier
-  if (LOSS) ssum += vhadd(half_one_minus_clamped(Sv));
+  if (LOSS) ssum = FIRST ? vhadd(half_one_minus_clamped(Sv)) : ssum + vhadd(half_one_minus_clamped(Sv));
   if (GRAD) {
     const T kap = vsel_abs_lt1(Sv, rD * kq2_nm);                    // 2 kappa / (D1 D2); F.clip backward
     const T u3 = vfma(-(Sv * Sx), D2 - D1, Sy * (N2 - N1));
@@ -403,7 +441,7 @@ __device__ __forceinline__ void ssim_stage_c(const T a2, const T a1, const T a0,
                                              const float kpn, T& g, T& q0, T& q1) {
   const T Aq = a2 + a1 + a0, Bq = b2 + b1 + b0, Eq = e2 + e1 + e0;
   // dL/dI^ = A + 2 I^ B + I E in the partials' own scaling (ssim_value_partials): A + 9 (I E' - I^ B')
-  g = vfma(vfma(it, Eq, -(ih * Bq)), T_of<T>(9.f), Aq) + ksign(kpn, ih - it);
+  g = add_ksign(vfma(vfma(it, Eq, -(ih * Bq)), T_of<T>(9.f), Aq), kpn, ih - it);
   q0 = g * du;
   q1 = g * dv;
 }
@@ -423,8 +461,8 @@ __device__ __forceinline__ void ssim_stage_b_row(const SsimCtx& C, const RowS& s
   ssim_vsums(s2.ih.p, s1.ih.p, s0.ih.p, s2.it.p, s1.it.p, s0.it.p, pp);
   ssim_vsums(s2.ih.s, s1.ih.s, s0.ih.s, s2.it.s, s1.it.s, s0.it.s, ps);
   hsum3_group(pp.Sx, pp.Sy, pp.Sqq, pp.Sxy, ps.Sx, ps.Sy, ps.Sqq, ps.Sxy);
-  ssim_value_partials<GRAD, LOSS>(pp, kq2_nm, g0.a.p, g0.b.p, g0.e.p, ssum);
-  ssim_value_partials<GRAD, LOSS>(ps, kq2_nm, g0.a.s, g0.b.s, g0.e.s, ssum);
+  ssim_value_partials<GRAD, LOSS, true>(pp, kq2_nm, g0.a.p, g0.b.p, g0.e.p, ssum);
+  ssim_value_partials<GRAD, LOSS, false>(ps, kq2_nm, g0.a.s, g0.b.s, g0.e.s, ssum);
   if (GRAD) hsum3_group(g0.a.p, g0.b.p, g0.e.p, g0.a.s, g0.b.s, g0.e.s);
   if (LOSS) {
     const float wgt = count ? s1.nm * C.outf : 0.f;
@@ -444,7 +482,7 @@ __device__ __forceinline__ void ssim_stage_c_row(const SsimCtx& C, const int rc,
   ssim_stage_c(g2.a.p, g1.a.p, g0.a.p, g2.b.p, g1.b.p, g0.b.p, g2.e.p, g1.e.p, g0.e.p, s2.ih.p, s2.it.p, s2.du.p, s2.dv.p, kpn, gp, q0p, q1p);
   ssim_stage_c(g2.a.s, g1.a.s, g0.a.s, g2.b.s, g1.b.s, g0.b.s, g2.e.s, g1.e.s, g0.e.s, s2.ih.s, s2.it.s, s2.du.s, s2.dv.s, kpn, gs, q0s, q1s);
   const float gI[3] = {gp.x, gp.y, gs};
-  geometry_backward(C, s2, rc, vhadd(q0p) + q0s, vhadd(q1p) + q1s, gI, gacc, first, gpm);
+  geometry_backward(C, s2, rc, (vhadd(q0p) + q0s) * s2.rzi, (vhadd(q1p) + q1s) * s2.rzi, gI, gacc, first, gpm);
 }
 
 // Which stages run on which step of a pass, as bit k of one 32-bit word per question (a pass has at most 32 steps): every
@@ -593,11 +631,11 @@ __device__ __forceinline__ void l1_source_pass(const SsimCtx& C, float* gacc, co
       const f2 gp = ksign(kpn, s0.ih.p - s0.it.p);
       const float gs = ksign(kpn, s0.ih.s - s0.it.s);
       const float gI[3] = {gp.x, gp.y, gs};
-      const float gq0 = vhadd(gp * s0.du.p) + gs * s0.du.s;
-      const float gq1 = vhadd(gp * s0.dv.p) + gs * s0.dv.s;
+      const float gq0 = (vhadd(gp * s0.du.p) + gs * s0.du.s) * s0.rzi;
+      const float gq1 = (vhadd(gp * s0.dv.p) + gs * s0.dv.s) * s0.rzi;
       if (EXPL) {
         // d/dlogit of (1-alpha) mean(err sigmoid) + exp_reg mean(softplus(-logit))
-        if (C.outf != 0.f) stf(C.dmp, (unsigned)r * (unsigned)C.w + C.xc, C.k_pix * e1 * sgm * (1.f - sgm) + C.k_exp * (sgm - 1.f));
+        if (C.outf != 0.f) stf_wt(C.dmp, (unsigned)r * (unsigned)C.w + C.xc, C.k_pix * e1 * sgm * (1.f - sgm) + C.k_exp * (sgm - 1.f));
       }
       geometry_backward(C, s0, r, gq0, gq1, gI, gacc, first, gpm);
     }

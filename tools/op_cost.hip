@@ -33,6 +33,21 @@ __global__ void __launch_bounds__(64) k(unsigned long long* out, int iters, floa
 #define F_MAD24(n) "v_mad_u32_u24 %" #n ", %" #n ", %8, %9\n"
 #define F_LSHLADD(n) "v_lshl_add_u32 %" #n ", %" #n ", 1, %8\n"
 #define F_RCP(n) "v_rcp_f32 %" #n ", %" #n "\n"
+#define F_MULCL(n) "v_mul_f32_e64 %" #n ", %" #n ", %8 clamp\n"
+#define F_MED3(n) "v_med3_f32 %" #n ", %" #n ", %8, %9\n"
+#define F_MAX(n) "v_max_f32 %" #n ", %" #n ", %8\n"
+#define F_AND(n) "v_and_b32 %" #n ", %" #n ", %8\n"
+#define F_BFI(n) "v_bfi_b32 %" #n ", %8, %" #n ", %9\n"
+#define F_FRACT(n) "v_fract_f32 %" #n ", %" #n "\n"
+#define F_ADDU(n) "v_add_u32 %" #n ", %" #n ", %8\n"
+#define F_LSHL(n) "v_lshlrev_b32 %" #n ", 2, %" #n "\n"
+#define F_CMPV(n) "v_cmp_lt_f32 vcc, %" #n ", %8\n"
+#define F_CNDV(n) "v_cndmask_b32 %" #n ", %8, %" #n ", vcc\n"
+#define F_ADDDPP(n) "v_add_f32_dpp %" #n ", %8, %" #n " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+#define F_MOVDPP(n) "v_mov_b32_dpp %" #n ", %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+#define F_EXP(n) "v_exp_f32 %" #n ", %" #n "\n"
+#define F_SUBABS(n) "v_sub_f32_e64 %" #n ", |%" #n "|, %8\n"
+#define F_FMAK(n) "v_fmac_f32 %" #n ", %8, %9\n"
     if (MODE == 0) { REP8(asm volatile(OP8(F_FMA) : V8 : "v"(a), "v"(b));) }
     else if (MODE == 1) { REP8(asm volatile(OP8(F_MUL) : V8 : "v"(a), "v"(b));) }
     else if (MODE == 2) { REP8(asm volatile(OP8(F_MOV) : V8 : "v"(a), "v"(b));) }
@@ -81,6 +96,46 @@ __global__ void __launch_bounds__(64) k(unsigned long long* out, int iters, floa
       REP8(asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n");)
     } else if (MODE == 22) { REP8(asm volatile(OP8(F_RCP) : V8 : "v"(a), "v"(b));) }
     else if (MODE == 23) { REP8(asm volatile(OP8(F_ADD) : V8 : "v"(a), "v"(b));) }
+    else if (MODE == 24) { REP8(asm volatile(OP8(F_MULCL) : V8 : "v"(a), "v"(b));) }
+    else if (MODE == 25) { REP8(asm volatile(OP8(F_MED3) : V8 : "v"(a), "v"(b));) }
+    else if (MODE == 26) { REP8(asm volatile(OP8(F_MAX) : V8 : "v"(a), "v"(b));) }
+    else if (MODE == 27) { REP8(asm volatile(OP8(F_AND) : V8 : "v"(a), "v"(b));) }
+    else if (MODE == 28) { REP8(asm volatile(OP8(F_BFI) : V8 : "v"(a), "v"(b));) }
+    else if (MODE == 29) { REP8(asm volatile(OP8(F_FRACT) : V8 : "v"(a), "v"(b));) }
+    else if (MODE == 30) { REP8(asm volatile(OP8(F_ADDU) : V8 : "v"(sa), "v"(b));) }
+    else if (MODE == 31) { REP8(asm volatile(OP8(F_LSHL) : V8 : "v"(a), "v"(b));) }
+    else if (MODE == 32) { REP8(asm volatile(OP8(F_CMPV) : V8 : "v"(a), "v"(b) : "vcc");) }
+    else if (MODE == 33) { REP8(asm volatile(OP8(F_CNDV) : V8 : "v"(a), "v"(b) : "vcc");) }
+    else if (MODE == 34) { REP8(asm volatile(OP8(F_ADDDPP) : V8 : "v"(a), "v"(b));) }
+    else if (MODE == 35) { REP8(asm volatile(OP8(F_MOVDPP) : V8 : "v"(a), "v"(b));) }
+    else if (MODE == 36) { REP8(asm volatile(OP8(F_EXP) : V8 : "v"(a), "v"(b));) }
+    else if (MODE == 37) { REP8(asm volatile(OP8(F_SUBABS) : V8 : "v"(a), "v"(b));) }
+    else if (MODE == 38) { REP8(asm volatile(OP8(F_FMAK) : V8 : "v"(a), "v"(b));) }
+    else if (MODE == 41) {   // compare into VCC + select on VCC (VOP2 forms: what the compiler emits for `c ? a : b`)
+      REP8(asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32 %0, %8, %0, vcc\n v_cmp_lt_f32 vcc, %1, %8\n v_cndmask_b32 %1, %8, %1, vcc\n"
+                        "v_cmp_lt_f32 vcc, %2, %8\n v_cndmask_b32 %2, %8, %2, vcc\n v_cmp_lt_f32 vcc, %3, %8\n v_cndmask_b32 %3, %8, %3, vcc\n"
+                        : V8 : "v"(a), "v"(b) : "vcc");)
+    } else if (MODE == 42) {   // the same through an SGPR pair (VOP3 forms)
+      REP8(asm volatile("v_cmp_lt_f32_e64 s[20:21], %0, %8\n v_cndmask_b32_e64 %0, %8, %0, s[20:21]\n v_cmp_lt_f32_e64 s[22:23], %1, %8\n v_cndmask_b32_e64 %1, %8, %1, s[22:23]\n"
+                        "v_cmp_lt_f32_e64 s[20:21], %2, %8\n v_cndmask_b32_e64 %2, %8, %2, s[20:21]\n v_cmp_lt_f32_e64 s[22:23], %3, %8\n v_cndmask_b32_e64 %3, %8, %3, s[22:23]\n"
+                        : V8 : "v"(a), "v"(b) : "s20", "s21", "s22", "s23");)
+    } else if (MODE == 43) {   // select on VCC in the VOP3 encoding, VCC written once
+      REP8(asm volatile("v_cndmask_b32_e64 %0, %8, %0, vcc\n v_cndmask_b32_e64 %1, %8, %1, vcc\n v_cndmask_b32_e64 %2, %8, %2, vcc\n v_cndmask_b32_e64 %3, %8, %3, vcc\n"
+                        "v_cndmask_b32_e64 %4, %8, %4, vcc\n v_cndmask_b32_e64 %5, %8, %5, vcc\n v_cndmask_b32_e64 %6, %8, %6, vcc\n v_cndmask_b32_e64 %7, %8, %7, vcc\n"
+                        : V8 : "v"(a), "v"(b) : "vcc");)
+    } else if (MODE == 44) {   // two compares first, then the two selects (distance 2 between writer and reader)
+      REP8(asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cmp_lt_f32_e64 s[20:21], %1, %8\n v_cndmask_b32 %0, %8, %0, vcc\n v_cndmask_b32_e64 %1, %8, %1, s[20:21]\n"
+                        "v_cmp_lt_f32 vcc, %2, %8\n v_cmp_lt_f32_e64 s[20:21], %3, %8\n v_cndmask_b32 %2, %8, %2, vcc\n v_cndmask_b32_e64 %3, %8, %3, s[20:21]\n"
+                        : V8 : "v"(a), "v"(b) : "vcc", "s20", "s21");)
+    } else if (MODE == 39) {   // v_pk_fma_f32
+      REP8(asm volatile("v_pk_fma_f32 %0, %0, %4, %4\n v_pk_fma_f32 %1, %1, %4, %4\n v_pk_fma_f32 %2, %2, %4, %4\n v_pk_fma_f32 %3, %3, %4, %4\n"
+                        "v_pk_fma_f32 %0, %0, %4, %4\n v_pk_fma_f32 %1, %1, %4, %4\n v_pk_fma_f32 %2, %2, %4, %4\n v_pk_fma_f32 %3, %3, %4, %4\n"
+                        : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(A));)
+    } else if (MODE == 40) {   // v_pk_mul_f32 clamp
+      REP8(asm volatile("v_pk_mul_f32 %0, %0, %4 clamp\n v_pk_mul_f32 %1, %1, %4 clamp\n v_pk_mul_f32 %2, %2, %4 clamp\n v_pk_mul_f32 %3, %3, %4 clamp\n"
+                        "v_pk_mul_f32 %0, %0, %4 clamp\n v_pk_mul_f32 %1, %1, %4 clamp\n v_pk_mul_f32 %2, %2, %4 clamp\n v_pk_mul_f32 %3, %3, %4 clamp\n"
+                        : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(A));)
+    }
   }
   asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
   float r = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + p0.x + p1.y + p2.x + p3.y + (float)(q0 + q1 + q2 + q3) + lds[threadIdx.x];
@@ -130,6 +185,27 @@ int main() {
   run<14>("v_pk_mul_f32", 8, d, flag);
   run<15>("v_pk_add_f32", 8, d, flag);
   run<22>("v_rcp_f32", 8, d, flag);
+  run<24>("v_mul_f32 clamp", 8, d, flag);
+  run<25>("v_med3_f32", 8, d, flag);
+  run<26>("v_max_f32", 8, d, flag);
+  run<27>("v_and_b32", 8, d, flag);
+  run<28>("v_bfi_b32", 8, d, flag);
+  run<29>("v_fract_f32", 8, d, flag);
+  run<30>("v_add_u32", 8, d, flag);
+  run<31>("v_lshlrev_b32", 8, d, flag);
+  run<32>("v_cmp_lt_f32 -> vcc", 8, d, flag);
+  run<33>("v_cndmask_b32 (vcc)", 8, d, flag);
+  run<43>("v_cndmask_b32_e64 (vcc)", 8, d, flag);
+  run<41>("v_cmp -> vcc ; v_cndmask vcc (x4)", 8, d, flag);
+  run<42>("v_cmp -> sgpr ; v_cndmask sgpr (x4)", 8, d, flag);
+  run<44>("2 cmp ; 2 cndmask (x2)", 8, d, flag);
+  run<34>("v_add_f32_dpp wave_shr:1", 8, d, flag);
+  run<35>("v_mov_b32_dpp wave_shr:1", 8, d, flag);
+  run<36>("v_exp_f32", 8, d, flag);
+  run<37>("v_sub_f32 |a|", 8, d, flag);
+  run<38>("v_fmac_f32", 8, d, flag);
+  run<39>("v_pk_fma_f32", 8, d, flag);
+  run<40>("v_pk_mul_f32 clamp", 8, d, flag);
   run<16>("ds_write_b32 (+1 wait per 8)", 8, d, flag);
   run<17>("ds_add_f32 no return (+1 wait per 8)", 8, d, flag);
   run<18>("ds_read_b32 (+1 wait per 8)", 8, d, flag);
