@@ -87,13 +87,11 @@ def _load():
             "or `make -C sfm-learner-chainer_amd/csrc`. There is no CPU fallback." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
-        if os.environ.get("SFMWARP_ALLOW_OLD_ABI") and not hasattr(lib, name):
-            continue                # development only: A/B runs against a library built from an older commit
         fn = getattr(lib, name)     # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
     got = lib.sfm_abi_version()
-    if got != SFM_ABI_VERSION and not os.environ.get("SFMWARP_ALLOW_OLD_ABI"):
+    if got != SFM_ABI_VERSION:
         raise ImportError("libsfmwarp.so has ABI version %d, this package expects %d" % (got, SFM_ABI_VERSION))
     return lib
 

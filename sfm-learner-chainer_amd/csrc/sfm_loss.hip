@@ -421,6 +421,9 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
     C.P = P;
     C.sc = sc;
     C.xc = (unsigned)min(max(x, 0), w - 1);
+    C.xc12 = 12u * C.xc;
+    C.w12 = 12u * (unsigned)w;
+    C.w12f = (float)(12 * w);
     C.xin = xin;
     C.outb = outl;
     C.xinf = xin ? 1.f : 0.f;
@@ -744,6 +747,9 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
     const int h = d->H[s], w = d->W[s];
     if (h < 3 || w < 3) return fail(SFM_ERR_SHAPE, "sfm_loss: scale %d is %dx%d, need H,W >= 3", s, h, w);
     if ((long long)d->B * 3 * d->n_src * h * w >= (1ll << 31)) return fail(SFM_ERR_SHAPE, "sfm_loss: scale %d too large", s);
+    // (byte offsets inside one pixel-interleaved image are formed exactly in fp32 by the gather of the HWC kernels)
+    if (p.hwc && (long long)h * w * 12 >= (1ll << 24))
+      return fail(SFM_ERR_SHAPE, "sfm_loss: scale %d is %dx%d, SFM_LAYOUT_HWC takes images of fewer than 2^24 / 12 pixels", s, h, w);
     if (!d->tgt[s] || !d->src[s] || !d->disp[s]) return fail(SFM_ERR_NULL, "sfm_loss: tgt/src/disp[%d] is NULL", s);
     if (p.expl && !d->mask_logits[s]) return fail(SFM_ERR_NULL, "sfm_loss: exp_reg > 0 but mask_logits[%d] is NULL", s);
     ScaleArgs& S = A.sc[s];

@@ -55,6 +55,9 @@ struct SsimCtx {
   float K1[3], kx[3];   // Kinv[j][1] (uniform), Kinv[j][0] x + Kinv[j][2]: for pose_sums_expand
 #endif
   unsigned xc;          // column, clamped into the image (address-safe for halo lanes)
+  unsigned xc12;        // 12 xc: byte offset of the lane's texel in a pixel-interleaved row
+  unsigned w12;         // 12 w (uniform): bytes of a pixel-interleaved row
+  float w12f;           // ... as a float
   bool xin;             // column inside the image
   bool outb;            // output lane (not halo, inside the image)
   float xinf;           // ... as a factor: 1 or 0 (a multiply issues faster than a select)
@@ -216,6 +219,9 @@ struct __attribute__((packed, aligned(4))) Rgb {
   float c[3];
 };
 __device__ __forceinline__ Rgb load_rgb(const float* p) { return *reinterpret_cast<const Rgb*>(p); }
+struct __attribute__((packed, aligned(4))) Rgb2 {   // two horizontally adjacent pixel-interleaved texels: one 24-byte access
+  float c[6];
+};
 
 // HWC: the images are pixel-interleaved (SFM_LAYOUT_HWC): C.tp[0] / C.sp[0] are the (h,w,3) images of this sample /
 // (sample, source), and the three channels of a tap come with one load.
@@ -246,14 +252,19 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
   }
 #else
   if constexpr (HWC) {
-    // (plain pointer arithmetic here: the two horizontally adjacent taps of a row are then fetched as ONE 24-byte access,
-    // dwordx4 + dwordx2; four separate 12-byte loads per row step cost the gather path 40 % more time per step at 256x832)
-    const float* q = C.sp[0] + 3u * off;
-    const unsigned w3 = 3u * (unsigned)C.w;
-    const Rgb T0 = load_rgb(q), T1 = load_rgb(q + 3), B0 = load_rgb(q + w3), B1 = load_rgb(q + w3 + 3);
-    const Rgb I = load_rgb(C.tp[0] + 3u * offt);
+    // Byte offset of the top-left tap, 12 (v0 w + u0), formed in FLOAT from the integer parts U - fu, V - fv (exact: an image has
+    // fewer than 2^24 bytes, make_plan checks) and converted once: two full-rate subtractions, a multiply and a multiply-add
+    // instead of two conversions, two selects and a 64-bit multiply-add.  The two horizontally adjacent taps of a row are ONE
+    // 24-byte access (dwordx4 + dwordx2: four separate 12-byte loads cost the gather path 40 % more time per step at 256x832), the
+    // row below is the same address + 12 w.
+    const float bof = fmaf(p.V - p.fv, C.w12f, (p.U - p.fu) * 12.f);
+    const unsigned o12 = p.inview ? (unsigned)bof : 0u;
+    const char* q = reinterpret_cast<const char*>(C.sp[0]) + o12;   // (the source base lives in a vector register pair: the scalar file is full)
+    const Rgb2 T = *reinterpret_cast<const Rgb2*>(q), Bt = *reinterpret_cast<const Rgb2*>(q + C.w12);
+    const Rgb I = ld_off<Rgb>(C.tp[0], (unsigned)r * C.w12 + C.xc12);
+    (void)off; (void)offt;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { ps.ta[c] = T0.c[c]; ps.tb[c] = T1.c[c]; ps.ba[c] = B0.c[c]; ps.bb[c] = B1.c[c]; ps.it[c] = I.c[c]; }
+    for (int c = 0; c < 3; ++c) { ps.ta[c] = T.c[c]; ps.tb[c] = T.c[3 + c]; ps.ba[c] = Bt.c[c]; ps.bb[c] = Bt.c[3 + c]; ps.it[c] = I.c[c]; }
   } else {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -310,9 +321,11 @@ __device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& 
   const int h = C.h, w = C.w;
   const float gq2 = -fmaf(gq0, s2.U, gq1 * s2.V);
   const float yf = (float)rc;
-  const float a0 = fmaf(C.M1[0], yf, C.mx[0]), a1 = fmaf(C.M1[1], yf, C.mx[1]), a2 = fmaf(C.M1[2], yf, C.mx[2]);
-  const float gD = fmaf(gq0, a0, fmaf(gq1, a1, gq2 * a2));
-  const float gdisp = -gD * s2.D * s2.D;                         // d(1/d) = -1/d^2, base_model.py:60
+  // dL/d(depth) = gq . a with a = M (x,y,1) the ray of q = D a + P3.  D a = q - P3, and gq . q = 0 because U and
+  // V are homogeneous of degree 0 in q (with z = q2 + 1e-10 it is (gq0 U + gq1 V) 1e-10: ten orders below gq . P3), so
+  // gD = -(gq . P3) / D and dL/d(disp) = -gD D^2 (depth = 1/disp, base_model.py:60) = (gq . P3) D: three products with
+  // wave-uniform factors instead of rebuilding the ray -- and without the cancellation of a0 - U a2 for small translations.
+  const float gdisp = fmaf(gq0, C.P3[0], fmaf(gq1, C.P3[1], gq2 * C.P3[2])) * s2.D;
   float* ga = gacc + (rc - C.y0) * 64 + C.lane;
   // the tile is private to this wave: a plain store for the first contribution, then read-add-write through a register
   // (an LDS add without return value, ds_add_f32, has nothing to wait for but costs the launch 3 % at cfg3: it is a slow LDS op)
@@ -326,6 +339,7 @@ __device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& 
   gpm[3] = fmaf(yf, t0, gpm[3]); gpm[4] = fmaf(yf, t1, gpm[4]); gpm[5] = fmaf(yf, t2, gpm[5]);
   gpm[6] += gq0; gpm[7] += gq1; gpm[8] += gq2;
   if (C.dsp != nullptr) {   // optional dL/d(src): scatter of dL/dI^ over the four taps (uniform branch)
+    const float a0 = fmaf(C.M1[0], yf, C.mx[0]), a1 = fmaf(C.M1[1], yf, C.mx[1]), a2 = fmaf(C.M1[2], yf, C.mx[2]);
     const Proj p = project(a0, a1, a2, C.P3[0], C.P3[1], C.P3[2], s2.D, C.sc, h, w);
     if (p.inview && C.outf != 0.f) {
       float* ds = C.dsp + (unsigned)(p.v0 * w + p.u0);

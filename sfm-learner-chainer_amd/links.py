@@ -25,18 +25,28 @@ class _FusedLossFunction(Function):
     With backprop enabled the forward launch already produces every gradient
     (sfm_loss_fwd_bwd); backward only hands them out, scaled by the upstream gradient."""
 
-    def __init__(self, fused, S, n, with_masks, need_grad, run=None):
+    def __init__(self, fused, S, n, with_masks, need_grad, run=None, state=None):
         self.fused, self.S, self.n, self.with_masks, self.need_grad, self.run = fused, S, n, with_masks, need_grad, run
+        # the call of the link this node belongs to: the gradient arrays of a cached FusedLoss are valid for its latest call only
+        self.state, self.generation = state, (state.calls if state is not None else 0)
 
     def forward_gpu(self, inputs):
+        # The five scalars of THIS call get an array of their own (as every Chainer Function output does): the returned loss and
+        # the reported values stay what they were when a later call reuses the link's cached buffers.
         if self.run is not None:
-            loss5 = self.run()                 # pyramid + fused launch of this call, replayed from a HIP graph
+            loss5 = self.run().clone()         # pyramid + fused launch of this call, replayed from a HIP graph (fixed output)
         else:
-            loss5 = self.fused.forward_backward() if self.need_grad else self.fused.forward()
+            out = torch.empty((5,), dtype=torch.float32, device=self.fused.device)
+            loss5 = self.fused.forward_backward(out=out) if self.need_grad else self.fused.forward(out=out)
         self.loss5 = loss5
         return loss5[0:1].reshape(()),
 
     def backward_gpu(self, inputs, grad_outputs):
+        if self.state is not None and self.state.calls != self.generation:
+            raise RuntimeError(
+                "SFMLearnerLoss(cache_buffers=True): this loss belongs to call %d of the link, but the link has been called "
+                "again since (call %d) and its cached gradient buffers now hold the later call's gradients.  Call backward() "
+                "before the next forward, or construct the link with cache_buffers=False." % (self.generation, self.state.calls))
         gy = grad_outputs[0]
         # the seed of ones that Variable.backward() creates itself is not multiplied in (flag valid during that sweep only);
         # any gradient the caller has set on the loss (e.g. a loss scale) is
@@ -58,7 +68,9 @@ class SFMLearnerLoss:
       of input shapes and reused by every later call (only the input pointers are re-bound).  The arrays that
       `loss.backward()` hands to `x.grad` are therefore owned by the link and are overwritten by its next call with the same
       shapes -- the cleargrads() / forward / backward / update cycle of the reference's trainer (a caller that keeps
-      gradients across iterations copies them, or passes cache_buffers=False).
+      gradients across iterations copies them, or passes cache_buffers=False).  A `backward()` on the loss of an EARLIER
+      call, after the link has been called again, raises instead of handing out the later call's gradients.  The returned
+      loss and the five reported scalars are per-call arrays: they keep their values.
     use_graph (default False): when a call repeats the previous call's arrays exactly (same addresses: static input buffers),
       the pyramid launch and the three launches of the loss are replayed from one HIP graph.
     """
@@ -134,7 +146,8 @@ class SFMLearnerLoss:
             # :69-72 -- curr_tgt_img / curr_src_imgs of every scale, ONE launch for both tensors, written pixel-interleaved
             # (the layout the fused loss kernels fetch with the fewest loads; values identical to the planar pyramid)
             ops.pyramid_pair_hwc(tgt, stacked_src_imgs, n_scales, out=st.pyr)
-        node = _FusedLossFunction(fused, n_scales, n_sources, do_exp, need_grad, run)
+        st.calls += 1
+        node = _FusedLossFunction(fused, n_scales, n_sources, do_exp, need_grad, run, st if self.cache_buffers else None)
         total_loss = node(*inputs)
         l5 = node.loss5
         report({'total_loss': l5[0]}, self)                                    # :119-123

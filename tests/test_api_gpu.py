@@ -192,6 +192,41 @@ def test_loss_link_reuses_its_buffers_across_calls(synth, dev):
     assert float(loss.data) != l_a
 
 
+def test_loss_link_keeps_per_call_state(synth, dev):
+    """forward(A), forward(B), then backward on the loss of A: with cache_buffers=True (the default) the link's cached gradient
+    arrays hold B's gradients by then, so the stale backward raises instead of silently returning them (Chainer keeps per-call
+    state; with cache_buffers=False so does this link).  The returned loss and the reported scalars of A keep their values."""
+    import pytest as _pytest
+    dA = synth.make_inputs(B=2, H=32, W=104, n_src=2, n_scales=2, seed=8)
+    dB = synth.make_inputs(B=2, H=32, W=104, n_src=2, n_scales=2, seed=9)
+    cfgd = {"smooth_reg": 0.1, "exp_reg": 0, "seq_len": 3, "ssim_rate": 0.15}
+
+    def call(link, x):
+        disps = [cs.Variable(to_dev(a, dev)) for a in x["disps"]]
+        poses = [cs.Variable(to_dev(a, dev)) for a in x["poses"]]
+        K = to_dev(x["intrinsics"], dev)
+        return link(to_dev(x["tgt"], dev), to_dev(x["src"], dev), K, K, disps, poses), disps, poses
+
+    link = links.SFMLearnerLoss(cfgd)
+    la, disps_a, _ = call(link, dA)
+    va, rep_a = float(la.data), cs.get_report(link)["total_loss"]
+    lb, disps_b, _ = call(link, dB)
+    assert float(lb.data) != va
+    assert float(la.data) == va and float(rep_a) == va          # A's scalars were not overwritten by call B
+    with _pytest.raises(RuntimeError, match="called again since"):
+        la.backward()
+    lb.backward()                                                # the latest call's backward is fine
+    gb = to_np(disps_b[0].grad).copy()
+    # per-call state, as in Chainer: both orders work and give each call its own gradients
+    free = links.SFMLearnerLoss(cfgd, cache_buffers=False)
+    la2, disps_a2, _ = call(free, dA)
+    lb2, disps_b2, _ = call(free, dB)
+    la2.backward()
+    lb2.backward()
+    np.testing.assert_array_equal(to_np(disps_b2[0].grad), gb)
+    assert float(la2.data) == va and np.abs(to_np(disps_a2[0].grad) - gb).max() > 0
+
+
 def test_disp_activation_all_scales_in_one_launch(dev):
     """models/disp_net.py:104-122 and its backward; chained in front of the loss link the gradient lands
     on the raw network outputs"""

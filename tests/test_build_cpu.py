@@ -41,11 +41,9 @@ def test_loss_kernels_fit_their_register_budget(tmp_path):
     assert len(loss) == 54                       # {fwd, bwd, fused} x {l1, ssim, explain} x {no, 2nd-order, edge-aware smoothness} x {planar, hwc}
     for k, v in kernels.items():
         assert v["VGPRs Spill"] == 0, (k, v)
-        # (a variant may reserve a few bytes of frame for scalar-register spill slots it then never touches; anything larger means
-        # vector registers or arrays went to memory)
-        assert v["ScratchSize [bytes/lane]"] <= 32, (k, v)
-        if "ILb1ELb1E" in k:
-            assert v["ScratchSize [bytes/lane]"] == 0, (k, v)
+        # no frame at all, in any variant: scalar registers that do not fit are parked in vector-register lanes (counted in the
+        # budget below), never in memory -- a non-zero frame means real scratch traffic or an array demoted to memory
+        assert v["ScratchSize [bytes/lane]"] == 0, (k, v)
     for k, v in loss.items():
         ssim_grad = "ILb1ELb1E" in k             # loss_kernel<SSIM=true, GRAD=true, ...>
         assert v["VGPRs"] <= (168 if ssim_grad else 128), (k, v["VGPRs"])

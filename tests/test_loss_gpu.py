@@ -105,8 +105,28 @@ def _judged64(got, w32, w64, knife, what, extra=0.0):
     parity_note("second opinion (fp64 oracle) used for %s: passed" % what)
 
 
-POSE_PER_FLIP = GRAD_TOL     # what one pixel that demonstrably took the other branch may move d_pose by (of its maximum)
-POSE_FLIP_CAP = 0.01         # ... in total, per comparison
+POSE_PER_FLIP = GRAD_TOL     # what one pixel on the strict in-view test may move d_pose by (of its maximum), at 10^4 pixels per image
+POSE_FLIP_CAP = 1e-3         # ... in total, per comparison: the effective element-wise tolerance of d_pose never exceeds 3e-3
+POSE_L2_TOL = 1e-3           # relative L2 error of a d_pose array (its six components per sample, all samples)
+
+
+def src_footprints(ref, s, knife):
+    """The 2x2 scatter footprints in the source images of the knife-edge target pixels of scale s: (B, 3 n_src, h, w) bool."""
+    uv = ref["uv"][s]                                  # (B,n,2,h,w)
+    B, n, _, h, w = uv.shape
+    out = np.zeros((B, n, h, w), bool)
+    kb = np.broadcast_to(knife.reshape(B, 1, h, w), (B, n, h, w))
+    with np.errstate(invalid="ignore"):
+        u0, v0 = np.floor(uv[:, :, 0]), np.floor(uv[:, :, 1])
+    ok = kb & np.isfinite(u0) & np.isfinite(v0) & (u0 >= -1) & (u0 <= w - 1) & (v0 >= -1) & (v0 <= h - 1)
+    bi, ni, _, _ = np.nonzero(ok)
+    uu, vv = u0[ok].astype(np.int64), v0[ok].astype(np.int64)
+    for dv in (0, 1):
+        for du in (0, 1):
+            y, x = vv + dv, uu + du
+            m = (y >= 0) & (y < h) & (x >= 0) & (x < w)
+            out[bi[m], ni[m], y[m], x[m]] = True
+    return np.repeat(out, 3, axis=1)
 
 
 def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=True, what="", ref64=None):
@@ -128,49 +148,57 @@ def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=T
                 raise
             _judged64(got, w, second(key, idx), knife, "%s %s" % (what, name), extra=extra)
 
-    def l2_ok(got, w, knife, name, key, idx):
+    def l2_ok(got, w, knife, name, key, idx, tol=L2_TOL):
         l2 = rel_l2(got, w, knife)
-        if l2 > L2_TOL:
+        if l2 > tol:
             # one ill-conditioned element can carry the whole norm: the fp64 oracle decides, with the fp32 oracle's own error as the yardstick
             assert ref64 is not None, "%s: relative L2 error %.2e outside knife pixels" % (name, l2)
             w64 = second(key, idx)
             mine, theirs = rel_l2(got, w64, knife), rel_l2(w, w64, knife)
-            assert mine <= max(L2_TOL, 3.0 * theirs), "%s: relative L2 error %.2e vs the fp64 oracle (the fp32 oracle's own: %.2e)" % (name, mine, theirs)
+            assert mine <= max(tol, 3.0 * theirs), "%s: relative L2 error %.2e vs the fp64 oracle (the fp32 oracle's own: %.2e)" % (name, mine, theirs)
             parity_note("second opinion (fp64 oracle) used for the L2 norm of %s %s: %.2e vs the fp32 oracle's own %.2e" % (what, name, mine, theirs))
             return min(l2, mine)
         return l2
 
-    flipped = None       # per sample: knife-edge pixels where the kernel demonstrably took the other branch (a count)
+    observed = None      # per sample: knife-edge pixels where the kernel demonstrably took the other branch (a count; REPORTED only)
+    on_test = None       # per sample: pixels the ORACLE places within `thr` of the strict in-view test (what the allowance goes by)
+    knives = []
     for s, (g, w) in enumerate(zip(fl.d_disps, ref["d_disps"])):
         knife = _knife(ref, s, n_src, what=what)
+        knives.append(knife)
         gnp = to_np(g)
-        # (a quarter of the gradient tolerance already counts as "took the other branch": rounding noise is 1000x smaller, and a
-        # pixel that matters little to d_disp can still matter to d_pose, which weighs it with its ray)
+        # (a quarter of the gradient tolerance already counts as "took the other branch": rounding noise is 1000x smaller)
         off = (np.abs(gnp.astype(np.float64) - w) > 0.25 * GRAD_TOL * np.abs(w).max()) & np.broadcast_to(knife, w.shape)
         cnt = off.reshape(off.shape[0], -1).sum(axis=1)
-        flipped = cnt if flipped is None else flipped + cnt
+        observed = cnt if observed is None else observed + cnt
+        flip = knife_mask(ref, s)[1]                                   # (B,h,w): from the oracle's own margins only
+        fc = flip.reshape(flip.shape[0], -1).sum(axis=1)
+        on_test = fc if on_test is None else on_test + fc
         close(gnp, w, knife, "d_disp[%d]" % s, "d_disps", s)
         worst = max(worst, l2_ok(gnp, w, knife, "d_disp[%d]" % s, "d_disps", s))
         if check_mask:
             close(to_np(fl.d_masks[s]), ref["d_masks"][s], None, "d_mask[%d]" % s, "d_masks", s)
             l2_ok(to_np(fl.d_masks[s]), ref["d_masks"][s], None, "d_mask[%d]" % s, "d_masks", s)
-    # d_pose of a sample sums SIGNED terms of all its pixels and scales: a knife-edge pixel whose d_disp shows that the kernel
-    # took the other side of the kink changes one term by its full size, which can be many times the net sum's share of a
-    # pixel (measured: one such pixel of a 92x108 image moved d_pose by 0.26 % of its maximum).  Each OBSERVED pixel is allowed
-    # one gradient tolerance at 10^4 pixels per image and proportionally less above, POSE_FLIP_CAP in total; printed.
-    n_flipped = 0 if flipped is None else int(flipped.max())
+    # d_pose of a sample sums SIGNED terms of all its pixels and scales: a pixel on the strict in-view test that the two fp32
+    # evaluations place on different sides changes one term by its full size, which can be many times the net sum's share of a
+    # pixel (measured: one such pixel of a 92x108 image moved d_pose by 0.26 % of its maximum).  The allowance goes by how many
+    # pixels the ORACLE puts within `thr` of that test (nothing the kernel computes enters it): one gradient tolerance per such
+    # pixel at 10^4 pixels per image and proportionally less above, POSE_FLIP_CAP in total.  The observed count is printed.
+    n_on_test = 0 if on_test is None else int(on_test.max())
+    n_observed = 0 if observed is None else int(observed.max())
     px0 = float(fl.d_disps[0].shape[-2] * fl.d_disps[0].shape[-1])      # a pixel's weight in the sums falls with the image size
-    extra = min(POSE_FLIP_CAP, POSE_PER_FLIP * min(1.0, 1.0e4 / px0) * n_flipped)
+    extra = min(POSE_FLIP_CAP, POSE_PER_FLIP * min(1.0, 1.0e4 / px0) * n_on_test)
+    worst_pose = 0.0
     for i, (g, w) in enumerate(zip(fl.d_poses, ref["d_poses"]) if check_pose else ()):
         close(to_np(g), w, None, "d_pose[%d]" % i, "d_poses", i, extra=extra)
-    parity_note("grads %s: worst relative L2 of d_disp outside knife pixels %.2e (tol %.0e); d_pose allowance %.2e for %d observed knife flips" % (
-        what, worst, L2_TOL, extra, n_flipped))
+        worst_pose = max(worst_pose, l2_ok(to_np(g), w, None, "d_pose[%d]" % i, "d_poses", i, tol=POSE_L2_TOL))
+    parity_note("grads %s: worst relative L2 of d_disp outside knife pixels %.2e (tol %.0e), of d_pose %.2e (tol %.0e); d_pose "
+                "element-wise allowance %.2e for %d pixels the oracle has on the in-view test (%d observed as taken differently)" % (
+                    what, worst, L2_TOL, worst_pose, POSE_L2_TOL, extra, n_on_test, n_observed))
     if check_src:
         for s, (g, w) in enumerate(zip(fl.d_srcs, ref["d_srcs"])):
-            # scatter targets of knife-edge pixels: compare in aggregate
-            err = np.abs(to_np(g) - w)
-            scale = np.abs(w).max()
-            assert (err > GRAD_TOL * scale).mean() < 1e-3, ("d_src[%d]" % s, err.max(), scale)
+            # element-wise everywhere except on the 2x2 scatter footprints of the knife-edge target pixels
+            assert_close_masked(to_np(g), w, GRAD_TOL, src_footprints(ref, s, knives[s]), what="d_src[%d]" % s)
 
 
 CONFIGS = {
@@ -275,6 +303,32 @@ def test_batch_shard_is_additive(ops, synth, dev):
     ("ssim_smooth", 4, 128, 416, 2, 4),    # cfg3's live loss mode (2nd-order smoothness), full resolution, oracle-sized batch
     ("edge_aware", 4, 128, 416, 2, 4),     # BASELINE cfg3 AS WRITTEN: L1 + SSIM + EDGE-AWARE smoothness (base_model.py:144-155)
 ])
+def count_in_view_mismatches(ops, dev, d, ref, layout, what):
+    """How many pixels the fused kernel zeroes differently from the oracle -- counted, not inferred.  With the L1 term alone and
+    ONE source, d_disp of a pixel is exactly 0 iff its sample is not in view (or its photometric gradient vanishes by itself), so
+    the zero set of a single-source L1-only launch IS the kernel's out-of-view set of that source; the oracle's is the mask of
+    models/base_model.py:96 on its warped image.  Returns / prints per source and scale (kernel out & oracle in, kernel in & oracle out)."""
+    n_src = len(d["poses"])
+    total = [0, 0]
+    for i in range(n_src):
+        one = dict(d, src_pyr=[a[:, 3 * i:3 * i + 3] for a in d["src_pyr"]], poses=[d["poses"][i]], masks=None)
+        fl = _bind(ops, dev, one, dict(), layout=layout)
+        fl.forward_backward()
+        for s, g in enumerate(fl.d_disps):
+            k_out = to_np(g)[:, 0] == 0
+            o_out = (ref["warped"][s][:, i] == 0).all(axis=1)
+            a, b = int((k_out & ~o_out).sum()), int((~k_out & o_out).sum())
+            near = int((k_out != o_out)[ref["margin"][s][:, i] < 8e-6].sum())
+            total[0] += a
+            total[1] += b
+            if a or b:
+                parity_note("in-view sets %s src %d scale %d: kernel out / oracle in %d, kernel in / oracle out %d of %d px (%d of them within 8e-6 of the strict test)" % (
+                    what, i, s, a, b, k_out.size, near))
+    parity_note("in-view sets %s: %d + %d pixels zeroed differently from the oracle over %d sources x %d scales" % (
+        what, total[0], total[1], n_src, len(d["disps"])))
+    return total
+
+
 @pytest.mark.parametrize("layout", ["planar", "hwc"])
 def test_baseline_configs_vs_oracle(ops, synth, dev, cfg_name, B, H, W, n_src, n_scales, layout):
     """BASELINE.json configs at full 128x416 resolution against the oracle, at batches the oracle finishes in seconds."""
@@ -284,7 +338,29 @@ def test_baseline_configs_vs_oracle(ops, synth, dev, cfg_name, B, H, W, n_src, n
     fl = _bind(ops, dev, d, cfg, layout=layout)
     _check_losses(fl.forward(), ref)
     _check_losses(fl.forward_backward(), ref)
-    _check_grads(fl, ref, n_src, what="%s B=%d %dx%d %s" % (cfg_name, B, H, W, layout))
+    what = "%s B=%d %dx%d %s" % (cfg_name, B, H, W, layout)
+    _check_grads(fl, ref, n_src, what=what)
+    a, b = count_in_view_mismatches(ops, dev, d, ref, layout, what)
+    # every pixel the two evaluations treat differently sits on the strict test (the knife mask covers it): a handful per image
+    assert a + b <= 4 * B * n_src * n_scales, (a, b)
+
+
+@pytest.mark.parametrize("cfg_name,B,H,W,n_src", [
+    ("ssim_smooth", 32, 128, 416, 2),     # BASELINE cfg3 / cfg4's per-GPU share at the FULL batch, live smoothness form
+    ("edge_aware", 32, 128, 416, 2),      # BASELINE cfg3 as written (edge-aware smoothness), full batch
+    ("ssim_smooth", 8, 256, 832, 4),      # BASELINE cfg5 at its full batch, 5-frame snippet = 4 sources
+])
+def test_full_batch_vs_oracle(ops, synth, dev, cfg_name, B, H, W, n_src):
+    """BASELINE cfg3 (both smoothness forms) and cfg5 at their FULL batch against the fp32 oracle (a minute of NumPy each), in the
+    pixel-interleaved layout bench.py measures: the five scalars to 1e-4, every gradient by the criteria of _check_grads."""
+    cfg = CONFIGS[cfg_name]
+    d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=4, seed=1)
+    ref = _oracle(d, cfg)
+    fl = _bind(ops, dev, d, cfg, layout="hwc")
+    _check_losses(fl.forward_backward(), ref)
+    what = "FULL BATCH %s B=%d %dx%d %d src hwc" % (cfg_name, B, H, W, n_src)
+    _check_grads(fl, ref, n_src, what=what)
+    count_in_view_mismatches(ops, dev, d, ref, "hwc", what)
 
 
 @pytest.mark.parametrize("cfg_name,B,H,W,n_src", [
