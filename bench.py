@@ -7,9 +7,10 @@
 One "step" = forward + backward of the multi-scale photometric loss through the C ABI over one synthetic batch
 that is already resident in HBM: the fused launch sfm_loss_fwd_bwd (loss and all gradients -- what
 SFMLearnerLoss.__call__ runs when backprop is enabled) plus, for N > 1, the RCCL all-reduce of the five
-reported scalars, EVERY step.  Workload at any N: BASELINE.json configs[2]/[3] -- B = 32 samples PER GPU,
-128x416, 4 scales, 2 sources, L1 + SSIM(0.15) + second-order smoothness(0.1) (experiments/sfm_learner_v1_ssim.yml),
-weak scaling.
+reported scalars, EVERY step.  Workload at any N: BASELINE.json configs[2]/[3] AS WRITTEN -- B = 32 samples PER GPU,
+128x416, 4 scales, 2 sources, L1 + SSIM(0.15, experiments/sfm_learner_v1_ssim.yml) + EDGE-AWARE smoothness(0.1)
+(models/base_model.py:144-155), weak scaling.  The same with the second-order smoothness the reference's live code runs
+(base_model.py:75-77,169-185) is the secondary key `cfg3` of the line.
 
 `--gpus N` with N > 1 and no torchrun environment: this process starts N ranks itself (as child processes, before
 anything touches a GPU) and returns their exit code.
@@ -38,23 +39,19 @@ PKG = "sfm-learner-chainer_amd"
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_FWD, BYTES_BWD = 28, 32   # algorithmic bytes per warped pixel, SURVEY.md 8(d)
 N_SIMD = 1024                   # 256 CUs x 4 SIMDs
-# Vector-instruction issue ceiling of the SSIM instruction mix on one SIMD, measured with tools/mix_cycles.hip
-# (profiles/r01_valu_mix_microbench.txt: 175 VALU instructions per iteration; 498 / 447 cycles per iteration and SIMD at
-# 3 / 4 resident waves), and the in-kernel clock of the fused launch (profiles/r02_wave_stage_stamps.txt).
-VALU_CEILING_PER_CYCLE = {3: 175.0 / 498.0, 4: 175.0 / 447.0}
-KERNEL_CLOCK_GHZ = 2.04
+PROFILE_TAGS = ("r03",)         # profiles/<tag>_summary.json, _issue_model.json, _wave_stage_stamps.txt: what roofline_valu is built from
 GRAD_BUFFER_FLOATS = 36489060 + 3393892   # DispNet + PoseNet parameters: the ~160 MB all-reduce probe
 
 WORKLOADS = {
     # name: (B per GPU, H, W, n_src, n_scales, loss config, description)
     "cfg3": (32, 128, 416, 2, 4, dict(smooth_reg=0.1, ssim_rate=0.15),
-             "BASELINE cfg3: B=32/GPU, 128x416, 4 scales, 2 src, L1+SSIM(0.15)+2nd-order smoothness(0.1)"),
+             "BASELINE cfg3 with the reference's LIVE smoothness: B=32/GPU, 128x416, 4 scales, 2 src, L1+SSIM(0.15)+2nd-order smoothness(0.1)"),
     "cfg1": (1, 128, 416, 2, 1, dict(),
              "BASELINE cfg1: B=1, 128x416, 1 scale, 2 src, L1 only (the CPU baseline's workload)"),
     "cfg2": (8, 128, 416, 2, 4, dict(smooth_reg=0.1),
              "BASELINE cfg2: B=8, 128x416, 4 scales, 2 src, L1 + smoothness"),
     "cfg3_edge": (32, 128, 416, 2, 4, dict(smooth_reg=0.1, ssim_rate=0.15, smooth_mode="edge_aware"),
-                  "BASELINE cfg3 as written: L1+SSIM(0.15)+EDGE-AWARE smoothness (base_model.py:144-155)"),
+                  "BASELINE cfg3 as written: B=32/GPU, 128x416, 4 scales, 2 src, L1+SSIM(0.15)+EDGE-AWARE smoothness(0.1) (base_model.py:144-155)"),
     "cfg5": (8, 256, 832, 4, 4, dict(smooth_reg=0.1, ssim_rate=0.15),
              "BASELINE cfg5: B=8, 256x832, 5-frame (4 src), 4 scales"),
     "cfg5_2src": (8, 256, 832, 2, 4, dict(smooth_reg=0.1, ssim_rate=0.15),
@@ -191,8 +188,41 @@ def spawn_ranks(n):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver of this pool only supports dmabuf IPC; without it RCCL's cross-process buffer
+    # registration fails with `hipIpcGetMemHandle: invalid argument` (environment note of the task; already exported on the
+    # boxes -- kept here so that a shell that lost it still works).  The children inherit everything else unchanged.
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     return subprocess.call(cmd, env=env)
+
+
+def dry_run_rank(args):
+    """SFM_BENCH_DRYRUN=1 (tests/test_bench_spawn_cpu.py): everything of the multi-rank plumbing EXCEPT the GPU work -- the
+    rendezvous the ranks were started with (gloo instead of RCCL), the per-step collective on a 5-float row, the barrier + MAX
+    reduction of the elapsed time, and the single JSON line of rank 0 -- so that `python bench.py --gpus N` can be exercised on a
+    machine without GPUs.  SFM_BENCH_DRYRUN_FAIL_RANK=k makes rank k exit with code 3 (exit-code propagation)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py --gpus %d, but WORLD_SIZE=%d" % (args.gpus, world))
+    if os.environ.get("SFM_BENCH_DRYRUN_FAIL_RANK") == str(rank):
+        sys.exit(3)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    row = torch.full((5,), float(rank + 1))
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(max(args.steps, 1)):
+        step_row = row.clone()
+        dist.all_reduce(step_row)
+    dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "sum_of_ranks": float(step_row[0]),
+                          "max_elapsed_s": float(tt.item())}), flush=True)
+    dist.destroy_process_group()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -321,15 +351,44 @@ def graph_path(torch, np, runner, min_time=0.12, k=25):
     return round(float(np.median(blocks)) * 1e3, 5)
 
 
-def profile_summary(tag_order=("r02", "r01")):
-    for tag in tag_order:
-        path = os.path.join(ROOT, "profiles", "%s_summary.json" % tag)
-        if os.path.exists(path):
-            try:
-                return tag, json.load(open(path))
-            except Exception:
-                pass
-    return None, None
+def profile_facts(workload, layout, mode, kernel_name):
+    """What the committed profiles say about the kernel this run launches (collected offline with tools/collect_profiles.sh on this
+    same command; bench.py itself cannot read hardware counters): HBM-side bytes and SQ_INSTS_VALU per launch
+    (profiles/<tag>_summary.json, variant workload_layout_mode), the mean issue cost of one of its vector instructions
+    (profiles/<tag>_issue_model.json: the ISA of the row step priced with profiles/<tag>_op_cost_microbench.txt) and the in-kernel
+    clock (profiles/<tag>_wave_stage_stamps.txt).  Missing pieces are None."""
+    import re
+    out = {"tag": None, "counters": None, "traffic_raw": None, "traffic_x2": None, "issue": None, "clock_ghz": None, "rocprof_avg_ns": None}
+    for tag in PROFILE_TAGS:
+        try:
+            summ = json.load(open(os.path.join(ROOT, "profiles", "%s_summary.json" % tag)))
+            var = summ["variants"]["%s_%s_%s" % (workload, layout, mode)]
+            kv = var["kernels"][kernel_name]
+            out.update(tag=tag, counters=kv.get("counters_per_launch"), traffic_raw=kv.get("hbm_bytes_raw"), traffic_x2=kv.get("hbm_bytes_fetch_x2"),
+                       rocprof_avg_ns=kv.get("avg_ns"))
+        except Exception:
+            continue
+        try:
+            out["issue"] = json.load(open(os.path.join(ROOT, "profiles", "%s_issue_model.json" % tag)))["kernels"][kernel_name]
+        except Exception:
+            pass
+        try:
+            m = re.search(r"in-kernel clock.*?median ([\d.]+) GHz", open(os.path.join(ROOT, "profiles", "%s_wave_stage_stamps.txt" % tag)).read())
+            out["clock_ghz"] = float(m.group(1))
+        except Exception:
+            pass
+        break
+    return out
+
+
+def kernel_symbol(cfg, layout, mode):
+    """Name of the loss_kernel instantiation a run's dominant launch uses (as rocprofv3 prints it)."""
+    expl = bool(cfg.get("exp_reg"))
+    ssim = bool(cfg.get("ssim_rate")) and not expl
+    smode = 0 if not cfg.get("smooth_reg") else (2 if cfg.get("smooth_mode") == "edge_aware" else 1)
+    grad, loss = (True, True) if mode == "fused" else (True, False)
+    tf = lambda v: "true" if v else "false"
+    return "void sfm::loss_kernel<%s, %s, %s, %s, %d, %s>(sfm::LossArgs)" % (tf(ssim), tf(grad), tf(loss), tf(expl), smode, tf(layout == "hwc"))
 
 
 def main():
@@ -337,7 +396,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="cfg3_edge", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="fused", choices=["separate", "fused"],
                     help="separate: sfm_loss_fwd then sfm_loss_bwd (the reference's forward / loss.backward()); "
                          "fused: one sfm_loss_fwd_bwd launch")
@@ -356,6 +415,9 @@ def main():
         # started as plain `python bench.py --gpus N`: this process only starts the ranks (fresh child processes, nothing here
         # has touched a GPU) and hands their exit code on
         sys.exit(spawn_ranks(args.gpus))
+
+    if os.environ.get("SFM_BENCH_DRYRUN"):
+        return dry_run_rank(args)
 
     import numpy as np
     import torch
@@ -485,7 +547,7 @@ def main():
                                                                     "separate" if args.mode == "fused" else "fused", args.batch)))
         guarded("graph_ms_per_step", lambda: graph_path(torch, np, R))
         guarded("link_ms_per_step", lambda: link_path(torch, np, R))
-        for name in ("cfg3_edge", "cfg2", "cfg5", "cfg5_2src", "cfg1"):
+        for name in ("cfg3", "cfg3_edge", "cfg2", "cfg5", "cfg5_2src", "cfg1"):
             if name != args.workload:
                 guarded(name, lambda name=name: quick(torch, np, ev, Runner(torch, np, ops, synth, dev, name, args.layout, "fused")))
 
@@ -501,26 +563,17 @@ def main():
             kname, kbytes, kt = "loss_kernel<grad> (sfm_loss_bwd)", BYTES_BWD, k_second
         kms = float(np.mean(kt))
         achieved = kbytes * R.warped_px / (kms * 1e-3) / 1e9
-        # HBM-side bytes and issued vector instructions per launch of that kernel from the rocprofv3 PMC passes (collected
-        # offline with tools/collect_profiles.sh on this same command; bench.py itself cannot read hardware counters)
-        traffic = traffic_detail = valu = None
-        tag, prof = profile_summary()
-        try:
-            pc = prof["bench"]["config"]
-            if pc["mode"] == args.mode and args.workload == "cfg3" and args.batch == 0 and pc.get("image_layout", "planar") == args.layout:
-                want = "sfm_loss_fwd_bwd" if args.mode == "fused" else "sfm_loss_bwd"
-                for kn, kv in prof["kernels"].items():
-                    is_hwc = kn.rstrip().endswith("true>(sfm::LossArgs)")      # last template argument: HWC
-                    if kv.get("entry_point") == want and "hbm_bytes_raw" in kv and is_hwc == (args.layout == "hwc"):
-                        traffic = round(kv["hbm_bytes_fetch_x2"])
-                        traffic_detail = {"bytes_per_launch_raw": round(kv["hbm_bytes_raw"]),
-                                          "bytes_per_launch_fetch_x2": round(kv["hbm_bytes_fetch_x2"]),
-                                          "source": "profiles/%s_summary.json (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes; "
-                                                    "KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md, uncalibrated for 4-12 B/lane loads)" % tag}
-                        if "SQ_INSTS_VALU" in kv.get("counters_per_launch", {}):
-                            valu = float(kv["counters_per_launch"]["SQ_INSTS_VALU"])
-        except Exception:
-            traffic = traffic_detail = valu = None
+        # HBM-side bytes and issued vector instructions per launch of that kernel from the rocprofv3 PMC passes committed under profiles/
+        ksym = kernel_symbol(R.cfg, args.layout, args.mode)
+        facts = profile_facts(args.workload, args.layout, args.mode, ksym) if args.batch == 0 else profile_facts("-", "-", "-", "-")
+        traffic = round(facts["traffic_x2"]) if facts["traffic_x2"] else None
+        traffic_detail = None
+        if traffic:
+            traffic_detail = {"bytes_per_launch_raw": round(facts["traffic_raw"]), "bytes_per_launch_fetch_x2": traffic,
+                              "source": "profiles/%s_summary.json, variant %s_%s_%s (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes; KiB "
+                                        "units; FETCH_SIZE doubled per MI355X_MICROARCH.md, uncalibrated for 4-24 B/lane loads)" % (
+                                            facts["tag"], args.workload, args.layout, args.mode)}
+        valu = float(facts["counters"]["SQ_INSTS_VALU"]) if facts["counters"] and "SQ_INSTS_VALU" in facts["counters"] else None
         roofline = {
             # what binds: vector-instruction issue at the kernel's occupancy, not HBM.  `achieved` / `frac` keep
             # SURVEY 8(d)'s convention (ALGORITHMIC bytes / kernel time vs the 8 TB/s line) so that rounds stay comparable.
@@ -530,14 +583,20 @@ def main():
             "kernel": kname, "kernel_ms": round(kms, 5), "kernel_ms_median": round(float(np.median(kt)), 5),
             "kernel_ms_p10_p90": [round(float(np.percentile(kt, 10)), 5), round(float(np.percentile(kt, 90)), 5)],
             "bytes_per_warped_px": kbytes, "launches_timed": len(kt)}
+        roofline["kernel_symbol"] = ksym
+        if facts["rocprof_avg_ns"]:
+            roofline["rocprof_kernel_ms_in_profiles"] = round(facts["rocprof_avg_ns"] * 1e-6, 5)
         roofline_valu = None
-        if valu:
-            wps = 3 if (R.cfg.get("ssim_rate") and not R.cfg.get("exp_reg")) else 4
-            floor_ms = valu / N_SIMD / VALU_CEILING_PER_CYCLE[wps] / (KERNEL_CLOCK_GHZ * 1e9) * 1e3
-            roofline_valu = {"bound": "valu_issue", "valu_insts_per_launch": valu, "waves_per_simd": wps,
-                             "ceiling_insts_per_cycle_per_simd": round(VALU_CEILING_PER_CYCLE[wps], 4), "clock_GHz": KERNEL_CLOCK_GHZ,
+        if valu and facts["issue"] and facts["clock_ghz"]:
+            # issue-bound floor of a launch: counted vector instructions x the mean issue cost of one of them at this kernel's
+            # occupancy (ISA of the row step priced with the measured per-class costs), spread over the SIMDs, at the in-kernel clock
+            iss = facts["issue"]
+            floor_ms = valu * iss["mean_issue_cycles_per_valu"] / N_SIMD / (facts["clock_ghz"] * 1e9) * 1e3
+            roofline_valu = {"bound": "valu_issue", "valu_insts_per_launch": valu, "waves_per_simd": iss["waves_per_simd"],
+                             "mean_issue_cycles_per_valu": iss["mean_issue_cycles_per_valu"], "clock_GHz": facts["clock_ghz"],
                              "floor_ms": round(floor_ms, 5), "frac": round(floor_ms / kms, 4),
-                             "source": "SQ_INSTS_VALU from profiles/%s_summary.json; ceiling = tools/mix_cycles.hip at that occupancy" % tag}
+                             "source": "SQ_INSTS_VALU: profiles/%s_summary.json; cycles per instruction: profiles/%s_issue_model.json (ISA of HEAD "
+                                       "priced with profiles/%s_op_cost_microbench.txt); clock: profiles/%s_wave_stage_stamps.txt" % ((facts["tag"],) * 4)}
         out = {
             "metric": "warp+photo-loss fwd+bwd Mpixels/s @128x416x4scales; % HBM roofline",
             "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
