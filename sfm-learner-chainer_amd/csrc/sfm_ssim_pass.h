@@ -172,8 +172,10 @@ __device__ __forceinline__ float vhadd(float v) { return v; }
 
 struct RowS {            // a warped row as the later stages need it (per lane = per pixel)
   Ch3 ih, it;            // I^ (0 where not in view / outside the image), I (0 outside the image)
-  Ch3 du, dv;            // dI^/du, dI^/dv (of whatever the tap registers held where the sample is not in view: rzi masks them)
-  float U, V, D;         // q0/z, q1/z, depth
+  f2 dup, dvp;           // dI^/du, dI^/dv of channels 0, 1 (of whatever the tap registers held where the sample is not in view: rzi masks them)
+  f2 duv_s;              // (dI^/du, dI^/dv) of channel 2: paired, so that the contraction to dL/d(u,v) ends in packed instructions
+  f2 UV;                 // q0/z, q1/z: one register pair, so that everything per-coordinate is one packed instruction
+  float D;               // depth
   float rzi;             // 1/z where the sample is in view AND the lane is an output lane, else 0: the factor that takes
                          // dL/d(u,v) to dL/d(q0,q1), and the only mask the gradient needs downstream
   float nm;              // 1 - mask, mask = all three channels of I^ exactly 0   base_model.py:96
@@ -184,15 +186,16 @@ struct Pipe {            // a row whose gathers are in flight
   float ta[3], tb[3];    // taps (u0, v0), (u0+1, v0) of the three channels
   float ba[3], bb[3];    // taps (u0, v0+1), (u0+1, v0+1)
   float it[3];
-  float fu, fv, U, V, rz, D;
+  f2 UV, f;              // sampling position (q0/z, q1/z) and its bilinear fractions
+  float rz, D;
   float lg;              // explainability logit (only loaded when C.mp != nullptr)
   bool inview;           // the sample is taken (in view, column inside the image)
   bool inview_o;         // ... and the lane is an output lane: only there do dI^/du, dI^/dv exist (a halo lane has no gradient of its own)
 };
 
 __device__ __forceinline__ void zero(RowS& s) {
-  s.ih = s.it = s.du = s.dv = ch3_zero();
-  s.U = s.V = s.D = s.rzi = s.nm = 0.f;
+  s.ih = s.it = ch3_zero(); s.dup = s.dvp = s.duv_s = T_of<f2>(0.f);
+  s.UV = T_of<f2>(0.f); s.D = s.rzi = s.nm = 0.f;
 }
 __device__ __forceinline__ void zero(RowG& s) { s.a = s.b = s.e = ch3_zero(); }
 // The same zeros, but produced by instructions the compiler must leave where they are written.  The ring slot of a row
@@ -209,8 +212,9 @@ __device__ __forceinline__ Ch3 ch3_opaque_zero() {
   return ch3(a, b, c);
 }
 __device__ __forceinline__ void zero_rare(RowS& s) {
-  s.ih = ch3_opaque_zero(); s.it = ch3_opaque_zero(); s.du = ch3_opaque_zero(); s.dv = ch3_opaque_zero();
-  s.U = opaque_zero(); s.V = opaque_zero(); s.D = opaque_zero(); s.rzi = opaque_zero(); s.nm = opaque_zero();
+  s.ih = ch3_opaque_zero(); s.it = ch3_opaque_zero();
+  s.dup.x = opaque_zero(); s.dup.y = opaque_zero(); s.dvp.x = opaque_zero(); s.dvp.y = opaque_zero(); s.duv_s.x = opaque_zero(); s.duv_s.y = opaque_zero();
+  s.UV.x = opaque_zero(); s.UV.y = opaque_zero(); s.D = opaque_zero(); s.rzi = opaque_zero(); s.nm = opaque_zero();
 }
 
 // stage A, first half: project row r and issue its loads (row r is inside the image)
@@ -232,9 +236,27 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
   // correction (they decide the strict in-view test), the depth does not need one -- a last-bit change of D moves the sample by
   // 1e-7 of its parallax
   ps.D = rcp(disp);
-  const float a0 = fmaf(C.M1[0], yf, C.mx[0]), a1 = fmaf(C.M1[1], yf, C.mx[1]), a2 = fmaf(C.M1[2], yf, C.mx[2]);
-  const Proj p = project(a0, a1, a2, C.P3[0], C.P3[1], C.P3[2], ps.D, C.sc, C.h, C.w);
-  ps.U = p.U; ps.V = p.V; ps.rz = p.rz; ps.fu = p.fu; ps.fv = p.fv;
+  // The projection of sfm_common.h's project(), with the x and y components of every step in ONE packed instruction (the same
+  // IEEE operations per component: bit-identical values, two thirds of the instructions):
+  //   a = M (x,y,1) ; q = D a + P[:,3] ; z = q2 + 1e-10 ; (U,V) = (q0,q1) / z ; in view iff U (W-1-U) > 0 and V (H-1-V) > 0
+  f2 M1p, mxp, P3p, whm1;
+  M1p.x = C.M1[0]; M1p.y = C.M1[1]; mxp.x = C.mx[0]; mxp.y = C.mx[1]; P3p.x = C.P3[0]; P3p.y = C.P3[1];
+  whm1.x = C.sc.wm1; whm1.y = C.sc.hm1;
+  const f2 a = vfma(M1p, T_of<f2>(yf), mxp);
+  const float a2 = fmaf(C.M1[2], yf, C.mx[2]);
+  const f2 q = vfma(T_of<f2>(ps.D), a, P3p);
+  const float z = fmaf(ps.D, a2, C.P3[2]) + 1e-10f;                 // transform.py:123
+  const float rz = rcp(z);
+  const f2 qr = q * rz;                                             // div_r of both quotients (transform.py:124-125)
+  const f2 UV = vfma(vfma(-qr, T_of<f2>(z), q), T_of<f2>(rz), qr);
+  const f2 sg = UV * (whm1 - UV);
+  Proj p;
+  p.inview = (sg.x > 0.0f) & (sg.y > 0.0f);
+  f2 fr;
+  fr.x = __builtin_amdgcn_fractf(UV.x); fr.y = __builtin_amdgcn_fractf(UV.y);
+  p.U = UV.x; p.V = UV.y; p.fu = fr.x; p.fv = fr.y; p.rz = rz;
+  p.u0 = p.inview ? (int)UV.x : 0; p.v0 = p.inview ? (int)UV.y : 0;   // (only the planar gather uses the integer cell)
+  ps.UV = UV; ps.f = fr; ps.rz = rz;
   ps.inview = p.inview && C.xin;
   ps.inview_o = p.inview && C.outb;
 #ifdef SFM_ABLATE_MEM   // timing experiment only: every access hits the same few cache lines
@@ -260,7 +282,8 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
     // instead of two conversions, two selects and a 64-bit multiply-add.  The two horizontally adjacent taps of a row are ONE
     // 24-byte access (dwordx4 + dwordx2: four separate 12-byte loads cost the gather path 40 % more time per step at 256x832), the
     // row below is the same address + 12 w.
-    const float bof = fmaf(p.V - p.fv, C.w12f, (p.U - p.fu) * 12.f);
+    const f2 cell = UV - fr;
+    const float bof = fmaf(cell.y, C.w12f, cell.x * 12.f);
     const unsigned o12 = p.inview ? (unsigned)bof : 0u;
     const char* q = reinterpret_cast<const char*>(C.sp[0]) + o12;   // (the source base lives in a vector register pair: the scalar file is full)
     const Rgb2 T = *reinterpret_cast<const Rgb2*>(q), Bt = *reinterpret_cast<const Rgb2*>(q + C.w12);
@@ -291,21 +314,21 @@ __device__ __forceinline__ void finish_row(const SsimCtx& C, const Pipe& ps, Row
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float dxt = ps.tb[c] - ps.ta[c], dxb = ps.bb[c] - ps.ba[c];
-    const float top = fmaf(ps.fu, dxt, ps.ta[c]);
-    const float bot = fmaf(ps.fu, dxb, ps.ba[c]);
+    const float top = fmaf(ps.f.x, dxt, ps.ta[c]);
+    const float bot = fmaf(ps.f.x, dxb, ps.ba[c]);
     const float dvv = bot - top;
-    const float val = ps.inview ? fmaf(ps.fv, dvv, top) : 0.f;
+    const float val = ps.inview ? fmaf(ps.f.y, dvv, top) : 0.f;
     ih[c] = val;
     dv[c] = dvv;
-    du[c] = fmaf(ps.fv, dxb - dxt, dxt);
+    du[c] = fmaf(ps.f.y, dxb - dxt, dxt);
     it[c] = ps.it[c] * C.xinf;       // 0 outside the image (the load came from the clamped column)
     nz |= __float_as_uint(val);
   }
   s.ih = ch3(ih[0], ih[1], ih[2]);
   s.it = ch3(it[0], it[1], it[2]);
-  s.du = ch3(du[0], du[1], du[2]);
-  s.dv = ch3(dv[0], dv[1], dv[2]);
-  s.U = ps.U; s.V = ps.V; s.D = ps.D;
+  s.dup.x = du[0]; s.dup.y = du[1]; s.dvp.x = dv[0]; s.dvp.y = dv[1];
+  s.duv_s.x = du[2]; s.duv_s.y = dv[2];
+  s.UV = ps.UV; s.D = ps.D;
   s.rzi = ps.inview_o ? ps.rz : 0.f;   // halo lanes get no gradient of their own
   // base_model.py:96: mask = all three channels exactly 0 (+-0 both count).  nz without its sign bit, read as a float, is 0 or
   // at least the smallest magnitude among the channels: the clamped product with 2^127 is the 0 / 1 indicator (one full-rate
@@ -317,18 +340,26 @@ __device__ __forceinline__ void finish_row(const SsimCtx& C, const Pipe& ps, Row
   }
 }
 
-// From dL/dI^ of one pixel (already contracted with dI^/du, dI^/dv and 1/z into gq0, gq1) to its
+// the nine per-lane sums of geometry_backward, the x / y components of each triple as one register pair
+struct PoseAcc {
+  f2 A, B, Cq;         // sum gq D, sum y gq D, sum gq   (components 0, 1)
+  float A2, B2, C2;    // ... component 2
+};
+__device__ __forceinline__ void zero(PoseAcc& a) { a.A = a.B = a.Cq = T_of<f2>(0.f); a.A2 = a.B2 = a.C2 = 0.f; }
+
+// From dL/dI^ of one pixel (already contracted with dI^/du, dI^/dv and 1/z into gq = (gq0, gq1)) to its
 // share of d_depth (LDS tile), of the 12 sums of dL/dPm and, optionally, of dL/d(src).
-__device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& s2, const int rc, float gq0, float gq1,
-                                                  const float* gI, float* gacc, const bool first, float* gpm) {
+__device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& s2, const int rc, const f2 gq,
+                                                  const float* gI, float* gacc, const bool first, PoseAcc& gpm) {
   const int h = C.h, w = C.w;
-  const float gq2 = -fmaf(gq0, s2.U, gq1 * s2.V);
+  const f2 guv = gq * s2.UV;
+  const float gq2 = -(guv.x + guv.y);
   const float yf = (float)rc;
   // dL/d(depth) = gq . a with a = M (x,y,1) the ray of q = D a + P3.  D a = q - P3, and gq . q = 0 because U and
   // V are homogeneous of degree 0 in q (with z = q2 + 1e-10 it is (gq0 U + gq1 V) 1e-10: ten orders below gq . P3), so
   // gD = -(gq . P3) / D and dL/d(disp) = -gD D^2 (depth = 1/disp, base_model.py:60) = (gq . P3) D: three products with
   // wave-uniform factors instead of rebuilding the ray -- and without the cancellation of a0 - U a2 for small translations.
-  const float gdisp = fmaf(gq0, C.P3[0], fmaf(gq1, C.P3[1], gq2 * C.P3[2])) * s2.D;
+  const float gdisp = fmaf(gq.x, C.P3[0], fmaf(gq.y, C.P3[1], gq2 * C.P3[2])) * s2.D;
   float* ga = gacc + (rc - C.y0) * 64 + C.lane;
   // the tile is private to this wave: a plain store for the first contribution, then read-add-write through a register
   // (an LDS add without return value, ds_add_f32, has nothing to wait for but costs the launch 3 % at cfg3: it is a slow LDS op)
@@ -337,10 +368,11 @@ __device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& 
   // dL/dPm[k][j] = sum over pixels of gq_k * c_j with c = D * (K1 y + kx) (the back-projected point), c_3 = 1.  The ray
   // is linear in the row, so a lane only accumulates  A_k = sum gq_k D,  B_k = sum y gq_k D,  C_k = sum gq_k  (9 values
   // instead of 12) and expands them once per pass: gpm[k][j] = K1[j] B_k + kx[j] A_k, K1 = Kinv[:,1], kx = Kinv[:,0] x + Kinv[:,2]   (pose_sums_expand)
-  const float t0 = gq0 * s2.D, t1 = gq1 * s2.D, t2 = gq2 * s2.D;
-  gpm[0] += t0; gpm[1] += t1; gpm[2] += t2;
-  gpm[3] = fmaf(yf, t0, gpm[3]); gpm[4] = fmaf(yf, t1, gpm[4]); gpm[5] = fmaf(yf, t2, gpm[5]);
-  gpm[6] += gq0; gpm[7] += gq1; gpm[8] += gq2;
+  const f2 t = gq * s2.D;
+  const float t2 = gq2 * s2.D;
+  gpm.A += t; gpm.A2 += t2;
+  gpm.B = vfma(T_of<f2>(yf), t, gpm.B); gpm.B2 = fmaf(yf, t2, gpm.B2);
+  gpm.Cq += gq; gpm.C2 += gq2;
   if (C.dsp != nullptr) {   // optional dL/d(src): scatter of dL/dI^ over the four taps (uniform branch)
     const float a0 = fmaf(C.M1[0], yf, C.mx[0]), a1 = fmaf(C.M1[1], yf, C.mx[1]), a2 = fmaf(C.M1[2], yf, C.mx[2]);
     const Proj p = project(a0, a1, a2, C.P3[0], C.P3[1], C.P3[2], s2.D, C.sc, h, w);
@@ -362,7 +394,8 @@ __device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& 
 // The twelve wave reductions run in LOCKSTEP (stage by stage over all twelve values): twelve independent DPP adds per stage
 // instead of twelve dependent chains of six (each link of a chain waits for the previous one; 2.7-3.9k cycles per pass in
 // profiles/r02_wave_stage_stamps.txt).  Same adds in the same order per value: the sums are bit-identical to wave_sum's.
-__device__ __forceinline__ void pose_sums_expand(const SsimCtx& C, const float* acc, float* gpm_out) {
+__device__ __forceinline__ void pose_sums_expand(const SsimCtx& C, const PoseAcc& pa, float* gpm_out) {
+  const float acc[9] = {pa.A.x, pa.A.y, pa.A2, pa.B.x, pa.B.y, pa.B2, pa.Cq.x, pa.Cq.y, pa.C2};
   // K1[j] = Kinv[j][1], kx[j] = Kinv[j][0] x + Kinv[j][2]: only needed here, so neither lives through the row loop
   const float xf = (float)(C.x0 + C.lane);
   float K1[3], kx[3];
@@ -460,16 +493,13 @@ __device__ __forceinline__ void ssim_value_partials(const SsimSums<T>& p, const 
 }
 
 // Stage C for one channel group: dL/dI^ of row r-2 from the transposed 3x3 pool of the SSIM partials plus the L1
-// term, contracted with dI^/du, dI^/dv (already divided by z)
+// term (the contraction with dI^/du, dI^/dv and 1/z follows for all channels together: contract_uv)
 template <typename T>
 __device__ __forceinline__ void ssim_stage_c(const T a2, const T a1, const T a0, const T b2, const T b1, const T b0, const T e2,
-                                             const T e1, const T e0, const T ih, const T it, const T du, const T dv,
-                                             const float kpn, T& g, T& q0, T& q1) {
+                                             const T e1, const T e0, const T ih, const T it, const float kpn, T& g) {
   const T Aq = a2 + a1 + a0, Bq = b2 + b1 + b0, Eq = e2 + e1 + e0;
   // dL/dI^ = A + 2 I^ B + I E in the partials' own scaling (ssim_value_partials): A + 9 (I E' - I^ B')
   g = add_ksign(vfma(vfma(it, Eq, -(ih * Bq)), T_of<T>(9.f), Aq), kpn, ih - it);
-  q0 = g * du;
-  q1 = g * dv;
 }
 
 // Stage B at centre row rb (rows rb-1, rb, rb+1 in s2, s1, s0): SSIM value and, with GRAD, the horizontal 3-sums of its
@@ -498,17 +528,25 @@ __device__ __forceinline__ void ssim_stage_b_row(const SsimCtx& C, const RowS& s
   }
 }
 
+// dL/dI^ of the three channels (gp: channels 0, 1; gs: channel 2) contracted with dI^/du, dI^/dv and 1/z: (dL/dq0, dL/dq1) as a pair
+__device__ __forceinline__ f2 contract_uv(const RowS& s, const f2 gp, const float gs) {
+  const f2 pu = gp * s.dup, pv = gp * s.dvp;
+  f2 hq;
+  hq.x = pu.x + pu.y; hq.y = pv.x + pv.y;
+  return vfma(T_of<f2>(gs), s.duv_s, hq) * s.rzi;
+}
+
 // Stage C at row rc (the row in s2; partials of the rows rc-1, rc, rc+1 in g2, g1, g0): dL/dI^ -> dL/d(u,v) -> dL/dq -> d_depth
 // tile and the sums of dL/dPm.
 __device__ __forceinline__ void ssim_stage_c_row(const SsimCtx& C, const int rc, const RowS& s2, const RowG& g2, const RowG& g1,
-                                                 const RowG& g0, float* gacc, const bool first, float* gpm) {
+                                                 const RowG& g0, float* gacc, const bool first, PoseAcc& gpm) {
   const float kpn = C.k_pix * s2.nm;
-  f2 gp, q0p, q1p;
-  float gs, q0s, q1s;
-  ssim_stage_c(g2.a.p, g1.a.p, g0.a.p, g2.b.p, g1.b.p, g0.b.p, g2.e.p, g1.e.p, g0.e.p, s2.ih.p, s2.it.p, s2.du.p, s2.dv.p, kpn, gp, q0p, q1p);
-  ssim_stage_c(g2.a.s, g1.a.s, g0.a.s, g2.b.s, g1.b.s, g0.b.s, g2.e.s, g1.e.s, g0.e.s, s2.ih.s, s2.it.s, s2.du.s, s2.dv.s, kpn, gs, q0s, q1s);
+  f2 gp;
+  float gs;
+  ssim_stage_c(g2.a.p, g1.a.p, g0.a.p, g2.b.p, g1.b.p, g0.b.p, g2.e.p, g1.e.p, g0.e.p, s2.ih.p, s2.it.p, kpn, gp);
+  ssim_stage_c(g2.a.s, g1.a.s, g0.a.s, g2.b.s, g1.b.s, g0.b.s, g2.e.s, g1.e.s, g0.e.s, s2.ih.s, s2.it.s, kpn, gs);
   const float gI[3] = {gp.x, gp.y, gs};
-  geometry_backward(C, s2, rc, (vhadd(q0p) + q0s) * s2.rzi, (vhadd(q1p) + q1s) * s2.rzi, gI, gacc, first, gpm);
+  geometry_backward(C, s2, rc, contract_uv(s2, gp, gs), gI, gacc, first, gpm);
 }
 
 // Which stages run on which step of a pass, as bit k of one 32-bit word per question (a pass has at most 32 steps): every
@@ -534,7 +572,7 @@ template <bool GRAD, bool LOSS, bool HWC>
 __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const StepMasks& M, const int k, const int r, Pipe& ps, float& disp_next,
                                               RowS& s0, const RowS& s1, const RowS& s2,
                                               RowG& g0, const RowG& g1, const RowG& g2, float* gacc, const bool first,
-                                              float& acc_pix, float& acc_ssim, float* gpm SFM_STAMPS_ARG) {
+                                              float& acc_pix, float& acc_ssim, PoseAcc& gpm SFM_STAMPS_ARG) {
   const int w = C.w;
 #ifdef SFM_STAMPS
   unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
@@ -593,9 +631,8 @@ __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, 
 #endif
   const int rbeg = C.y0 - HS, rend = C.y1 + HS;
   const int rload = min(rend, C.h);   // rows below are neither inside the image nor part of this pass: never fetched
-  float gpm[9];   // A_k, B_k, C_k of geometry_backward
-#pragma unroll
-  for (int k = 0; k < 9; ++k) gpm[k] = 0.f;
+  PoseAcc gpm;    // A_k, B_k, C_k of geometry_backward
+  zero(gpm);
   // The rings need no initial value: stage B first runs on the third row of the pass, when all three RowS slots have
   // been written, and stage C two rows later, when all three RowG slots have (see ssim_row_step).
   RowS S0, S1, S2;
@@ -630,9 +667,8 @@ __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, 
 template <bool GRAD, bool LOSS, bool EXPL, bool HWC>
 __device__ __forceinline__ void l1_source_pass(const SsimCtx& C, float* gacc, const bool first, float& acc_pix, float& acc_exp,
                                                float* gpm_out) {
-  float gpm[9];   // A_k, B_k, C_k of geometry_backward
-#pragma unroll
-  for (int k = 0; k < 9; ++k) gpm[k] = 0.f;
+  PoseAcc gpm;    // A_k, B_k, C_k of geometry_backward
+  zero(gpm);
   Pipe ps;
   ps.lg = 0.f;
   float disp_next = 1.f;
@@ -657,13 +693,11 @@ __device__ __forceinline__ void l1_source_pass(const SsimCtx& C, float* gacc, co
       const f2 gp = ksign(kpn, s0.ih.p - s0.it.p);
       const float gs = ksign(kpn, s0.ih.s - s0.it.s);
       const float gI[3] = {gp.x, gp.y, gs};
-      const float gq0 = (vhadd(gp * s0.du.p) + gs * s0.du.s) * s0.rzi;
-      const float gq1 = (vhadd(gp * s0.dv.p) + gs * s0.dv.s) * s0.rzi;
       if (EXPL) {
         // d/dlogit of (1-alpha) mean(err sigmoid) + exp_reg mean(softplus(-logit))
         if (C.outf != 0.f) stf_wt(C.dmp, (unsigned)r * (unsigned)C.w + C.xc, C.k_pix * e1 * sgm * (1.f - sgm) + C.k_exp * (sgm - 1.f));
       }
-      geometry_backward(C, s0, r, gq0, gq1, gI, gacc, first, gpm);
+      geometry_backward(C, s0, r, contract_uv(s0, gp, gs), gI, gacc, first, gpm);
     }
   }
   if (GRAD) pose_sums_expand(C, gpm, gpm_out);
