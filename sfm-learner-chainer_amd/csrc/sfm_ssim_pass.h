@@ -236,26 +236,33 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
   // correction (they decide the strict in-view test), the depth does not need one -- a last-bit change of D moves the sample by
   // 1e-7 of its parallax
   ps.D = rcp(disp);
-  // The projection of sfm_common.h's project(), with the x and y components of every step in ONE packed instruction (the same
-  // IEEE operations per component: bit-identical values, two thirds of the instructions):
-  //   a = M (x,y,1) ; q = D a + P[:,3] ; z = q2 + 1e-10 ; (U,V) = (q0,q1) / z ; in view iff U (W-1-U) > 0 and V (H-1-V) > 0
-  f2 M1p, mxp, P3p, whm1;
-  M1p.x = C.M1[0]; M1p.y = C.M1[1]; mxp.x = C.mx[0]; mxp.y = C.mx[1]; P3p.x = C.P3[0]; P3p.y = C.P3[1];
-  whm1.x = C.sc.wm1; whm1.y = C.sc.hm1;
-  const f2 a = vfma(M1p, T_of<f2>(yf), mxp);
-  const float a2 = fmaf(C.M1[2], yf, C.mx[2]);
-  const f2 q = vfma(T_of<f2>(ps.D), a, P3p);
-  const float z = fmaf(ps.D, a2, C.P3[2]) + 1e-10f;                 // transform.py:123
-  const float rz = rcp(z);
-  const f2 qr = q * rz;                                             // div_r of both quotients (transform.py:124-125)
-  const f2 UV = vfma(vfma(-qr, T_of<f2>(z), q), T_of<f2>(rz), qr);
-  const f2 sg = UV * (whm1 - UV);
   Proj p;
-  p.inview = (sg.x > 0.0f) & (sg.y > 0.0f);
-  f2 fr;
-  fr.x = __builtin_amdgcn_fractf(UV.x); fr.y = __builtin_amdgcn_fractf(UV.y);
-  p.U = UV.x; p.V = UV.y; p.fu = fr.x; p.fv = fr.y; p.rz = rz;
-  p.u0 = p.inview ? (int)UV.x : 0; p.v0 = p.inview ? (int)UV.y : 0;   // (only the planar gather uses the integer cell)
+  f2 UV, fr;
+  float rz;
+  if constexpr (HWC) {
+    // The projection of sfm_common.h's project(), with the x and y components of every step in ONE packed instruction (the same
+    // IEEE operations per component: bit-identical values, two thirds of the instructions):
+    //   a = M (x,y,1) ; q = D a + P[:,3] ; z = q2 + 1e-10 ; (U,V) = (q0,q1) / z ; in view iff U (W-1-U) > 0 and V (H-1-V) > 0
+    f2 M1p, mxp, P3p, whm1;
+    M1p.x = C.M1[0]; M1p.y = C.M1[1]; mxp.x = C.mx[0]; mxp.y = C.mx[1]; P3p.x = C.P3[0]; P3p.y = C.P3[1];
+    whm1.x = C.sc.wm1; whm1.y = C.sc.hm1;
+    const f2 a = vfma(M1p, T_of<f2>(yf), mxp);
+    const float a2 = fmaf(C.M1[2], yf, C.mx[2]);
+    const f2 q = vfma(T_of<f2>(ps.D), a, P3p);
+    const float z = fmaf(ps.D, a2, C.P3[2]) + 1e-10f;                 // transform.py:123
+    rz = rcp(z);
+    const f2 qr = q * rz;                                             // div_r of both quotients (transform.py:124-125)
+    UV = vfma(vfma(-qr, T_of<f2>(z), q), T_of<f2>(rz), qr);
+    const f2 sg = UV * (whm1 - UV);
+    p.inview = (sg.x > 0.0f) & (sg.y > 0.0f);
+    fr.x = __builtin_amdgcn_fractf(UV.x); fr.y = __builtin_amdgcn_fractf(UV.y);
+    p.u0 = p.v0 = 0;   // (the pixel-interleaved gather forms its offset from UV - fr)
+  } else {
+    // (the planar gather needs the integer cell as well, and measured 4 % slower with the packed chain in front of it)
+    const float a0 = fmaf(C.M1[0], yf, C.mx[0]), a1 = fmaf(C.M1[1], yf, C.mx[1]), a2 = fmaf(C.M1[2], yf, C.mx[2]);
+    p = project(a0, a1, a2, C.P3[0], C.P3[1], C.P3[2], ps.D, C.sc, C.h, C.w);
+    UV.x = p.U; UV.y = p.V; fr.x = p.fu; fr.y = p.fv; rz = p.rz;
+  }
   ps.UV = UV; ps.f = fr; ps.rz = rz;
   ps.inview = p.inview && C.xin;
   ps.inview_o = p.inview && C.outb;

@@ -10,6 +10,9 @@ dev = torch.device("cuda:0")
 TB, TH, TW, TS = [int(v) for v in os.environ.get("SFM_TRACE_SHAPE", "32,128,416,2").split(",")]
 d = synth.make_inputs(B=TB, H=TH, W=TW, n_src=TS, n_scales=4, seed=1)
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+if os.environ.get("SFM_TRACE_ZERO"):   # DVFS probe (MI355X_MICROARCH.md, DVFS give-back): the same launch on all-zero images
+    for k in ("tgt_pyr", "src_pyr"):
+        d[k] = [np.zeros_like(a) for a in d[k]]
 layout = os.environ.get("SFM_LAYOUT", "hwc")
 cv = (lambda a: ops.to_hwc(t(a))) if layout == "hwc" else t
 fl = ops.FusedLoss(smooth_reg=0.1, ssim_rate=0.15, smooth_mode=os.environ.get("SFM_TRACE_SMOOTH", "second_order")).bind([cv(a) for a in d["tgt_pyr"]], [cv(a) for a in d["src_pyr"]], t(d["intrinsics"]),
