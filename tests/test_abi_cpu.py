@@ -78,6 +78,20 @@ def test_tiny_scale_is_rejected():
     assert _lib.lib.sfm_loss_fwd(C.byref(d), None, None, 0, None) == _lib.ERR_SHAPE
 
 
+def test_hwc_layout_rejects_images_whose_byte_offsets_leave_fp32():
+    """SFM_LAYOUT_HWC forms the byte offset of a gather inside one image exactly in fp32: an image of a scale must have fewer than
+    2^24 / 12 pixels; the planar layout takes the same shape."""
+    d = _desc(n_scales=1, image_layout=_lib.SFM_LAYOUT_HWC)
+    d.B = d.norm_B = 1
+    d.H[0], d.W[0] = 1200, 1200            # 1.44 M pixels > 1,398,101
+    assert _lib.lib.sfm_loss_fwd(C.byref(d), None, None, 0, None) == _lib.ERR_SHAPE and "2^24" in _lib.last_error()
+    d.image_layout = _lib.SFM_LAYOUT_PLANAR
+    assert _lib.lib.sfm_loss_workspace_bytes(C.byref(d)) > 0
+    d.image_layout = _lib.SFM_LAYOUT_HWC
+    d.H[0], d.W[0] = 1000, 1398            # just below the limit
+    assert _lib.lib.sfm_loss_workspace_bytes(C.byref(d)) > 0
+
+
 def test_missing_workspace_is_reported_before_any_launch():
     d = _desc()
     buf = (C.c_float * 5)()

@@ -156,6 +156,14 @@ def test_bench_workloads_follow_baseline_json():
     assert bench.BYTES_FWD + bench.BYTES_BWD == 60
     px = B * n_src * sum((H >> s) * (W >> s) for s in range(n_scales))
     assert px == 4526080
+    # the headline workload is BASELINE configs[2] AS WRITTEN: L1 + SSIM + EDGE-AWARE smoothness (models/base_model.py:144-155)
+    assert "edge-aware" in base["configs"][2]
+    import argparse
+    default = [a for a in open(os.path.join(root, "bench.py")) if '"--workload"' in a][0]
+    assert 'default="cfg3_edge"' in default
+    Be, He, We, ne, se, cfge, desc = bench.WORKLOADS["cfg3_edge"]
+    assert (Be, He, We, ne, se) == (32, 128, 416, 2, 4) and cfge["smooth_mode"] == "edge_aware" and cfge["ssim_rate"] == 0.15
+    assert bench.kernel_symbol(cfge, "hwc", "fused") == "void sfm::loss_kernel<true, true, true, false, 2, true>(sfm::LossArgs)"
 
 
 def test_augmentation_parameters_follow_the_reference_rng_order():
