@@ -126,10 +126,12 @@ def test_random_shapes_and_modes(ops, synth, dev, B, H, W, n_src, n_scales, cfg_
     """A seeded sweep; every case is judged by the SAME criteria as the fixed-shape tests (_check_losses, _check_grads: loss
     1e-4, gradients 2e-3 element-wise + relative L2, knife share capped).  A pixel on the strict `-1 < x < 1` test of
     transform.py:129 may be sampled in one fp32 evaluation and exactly 0 in the other; it can move a loss term by at most
-    (6 + 3) / (3 B h w).  The pixels within 8e-6 of that test (20 ulp of the normalised coordinate) are COUNTED, what they can move is added to the loss tolerance,
-    and inputs where that exceeds 5e-4 (the loss terms are O(1)) or whose knife-edge pixels exceed the cap are re-drawn with
-    the next seed (up to 16 draws) -- all of it reported (gpurun_out/parity_stats.txt)."""
-    from test_loss_gpu import knife_cap, knife_mask
+    (6 + 3) / (3 B h w).  Inputs whose pixels within 8e-6 of that test (20 ulp of the normalised coordinate) could move the loss
+    by more than 5e-4, or whose knife-edge pixels exceed the cap, are re-drawn with the next seed (up to 16 draws; a choice made
+    from oracle quantities alone).  The loss comparison itself gets NO allowance unless the kernel demonstrably zeroed a pixel
+    differently from the oracle: those pixels are COUNTED (count_in_view_mismatches: single-source L1-only launches against the
+    oracle's), and only their reach -- never more than the oracle-side bound -- is added.  All of it is reported."""
+    from test_loss_gpu import count_in_view_mismatches, knife_cap, knife_mask
     from util import parity_note
     cfg = CONFIGS[cfg_name]
     for attempt in range(16):
@@ -148,9 +150,17 @@ def test_random_shapes_and_modes(ops, synth, dev, B, H, W, n_src, n_scales, cfg_
         pytest.fail("no admissible input in 16 draws")
     parity_note("sweep case B=%d %dx%d n_src=%d scales=%d %s: input re-drawn %d times; %d pixels on the (-1,1) test, reach %.1e of the loss" % (
         B, H, W, n_src, n_scales, cfg_name, attempt, flips, flip_reach))
-    fl = _bind(ops, dev, d, cfg, layout="hwc" if seed % 2 else "planar")     # both image layouts take part in the sweep
-    _check_losses(fl.forward(), ref, slack=flip_reach)
-    _check_losses(fl.forward_backward(), ref, slack=flip_reach)
+    layout = "hwc" if seed % 2 else "planar"                                   # both image layouts take part in the sweep
+    fl = _bind(ops, dev, d, cfg, layout=layout)
+    plain = dict(d, masks=None)
+    count_in_view_mismatches(ops, dev, plain, ref, layout, "sweep %s %dx%d" % (cfg_name, H, W))
+    counted = sum(c * 3.0 / (B * ref["margin"][s_].shape[-2] * ref["margin"][s_].shape[-1])
+                  for s_, c in enumerate(count_in_view_mismatches.per_scale))
+    slack = min(flip_reach, counted)
+    parity_note("sweep case %s %dx%d: loss allowance %.1e (%d pixels counted as zeroed differently; oracle-side bound %.1e)" % (
+        cfg_name, H, W, slack, sum(count_in_view_mismatches.per_scale), flip_reach))
+    _check_losses(fl.forward(), ref, slack=slack)
+    _check_losses(fl.forward_backward(), ref, slack=slack)
     ref64 = lambda: O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], d["masks"], backward=True,
                                dtype=np.float64, **cfg)
     _check_grads(fl, ref, n_src, check_mask=bool(cfg.get("exp_reg")), what="sweep %s %dx%d" % (cfg_name, H, W), ref64=ref64)

@@ -308,6 +308,7 @@ def count_in_view_mismatches(ops, dev, d, ref, layout, what):
     models/base_model.py:96 on its warped image.  Returns / prints per source and scale (kernel out & oracle in, kernel in & oracle out)."""
     n_src = len(d["poses"])
     total = [0, 0]
+    per_scale = [0] * len(d["disps"])
     for i in range(n_src):
         one = dict(d, src_pyr=[a[:, 3 * i:3 * i + 3] for a in d["src_pyr"]], poses=[d["poses"][i]], masks=None)
         fl = _bind(ops, dev, one, dict(), layout=layout)
@@ -322,11 +323,13 @@ def count_in_view_mismatches(ops, dev, d, ref, layout, what):
             near = int((k_out != o_out)[ref["margin"][s][:, i] < 8e-6].sum())
             total[0] += a
             total[1] += b
+            per_scale[s] += a + b
             if a or b:
                 parity_note("in-view sets %s src %d scale %d: kernel out / oracle in %d, kernel in / oracle out %d of %d px (%d of them within 8e-6 of the strict test)" % (
                     what, i, s, a, b, k_out.size, near))
     parity_note("in-view sets %s: %d + %d pixels zeroed differently from the oracle over %d sources x %d scales" % (
         what, total[0], total[1], n_src, len(d["disps"])))
+    count_in_view_mismatches.per_scale = per_scale
     return total
 
 
