@@ -5,10 +5,11 @@
 //                      issued one step earlier, then issue the gathers of row r+1 and the
 //                      disparity load of row r+2, so that their latency is covered by B and C
 //   B  SSIM at row r-1 (models/base_model.py:126-142) from the separable 3x3 sums
-//                      (horizontal: DPP wave shifts; vertical: ring), and the partials
-//                      a,b,e = kappa * dS/d{mu_x, E[xx], E[xy]}
-//   C  gradients at row r-2: transposed 3x3 pool of a,b,e  ->  dL/dI^  ->  dL/d(u,v)  ->
-//                      dL/dq  ->  d_depth (LDS tile, summed over sources) and the 12 sums of dL/dPm
+//                      (horizontal: DPP wave shifts, all fields of both channel groups in one run; vertical:
+//                      ring), and the partials a,b,e ~ kappa * dS/d{mu_x, E[xx], E[xy]} (ssim_value_partials)
+//   C  gradients at row r-2: transposed 3x3 pool of a,b,e  ->  dL/dI^  ->  (dL/dq0, dL/dq1) as a register
+//                      pair (contract_uv)  ->  d_depth (LDS tile, summed over sources) and the nine per-lane
+//                      sums behind the 12 of dL/dPm (PoseAcc)
 // The ring is rotated statically (the loop body is instantiated three times), so no register
 // moves are spent on it.
 //
