@@ -497,17 +497,23 @@ constexpr int FINALIZE_WAVES = 16;   // waves of the block that sums the loss pa
 __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const LossArgs A, float* __restrict__ loss5, const int n_pose_blocks) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if ((int)blockIdx.x < n_pose_blocks) {
-    if (wave != 0) return;   // no block-level synchronisation in this branch
-    // d_pose of (b, i): every lane folds its tiles of every scale into K_s^T . gPm (linear), ONE in-register
-    // wave reduction at the end (DPP; a shuffle butterfly on doubles costs ~150 LDS-crossbar round trips)
+    // d_pose of (b, i): every lane folds its tiles of every scale into K_s^T . gPm (linear), one in-register wave reduction (DPP).
+    // A sample with many tiles (308 at cfg2, 376 at cfg5) is spread over the sixteen waves of the block, so that its partials are
+    // fetched in ONE round of independent loads instead of up to six dependent rounds (-1 us on those steps); the waves' sums meet
+    // in LDS and are added in wave order: a fixed order, the result does not depend on timing.
     const int b = blockIdx.x / A.n_src, i = blockIdx.x - b * A.n_src;
+    __shared__ float pose_red[FINALIZE_WAVES][12];
     float gT3[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) gT3[k] = 0.f;
     // all (scale, tile) pairs of this sample as one index space: independent loads, no per-scale round trips
     int total = 0;
     for (int s = 0; s < A.n_scales; ++s) total += A.sc[s].tiles;
-    for (int idx = lane; idx < total; idx += 64) {
+    // up to two rounds of loads one wave does alone (cfg3: the block's other waves leave at once, no LDS, no barrier: 1 us
+    // faster than sharing); more are spread over all the waves of the block
+    const int nw = total > 128 ? FINALIZE_WAVES : 1;    // block-uniform
+    if (wave >= nw) return;
+    for (int idx = threadIdx.x; idx < total; idx += 64 * nw) {
       int s = 0, off = 0;
 #pragma unroll
       for (int k = 0; k < SFM_MAX_SCALES - 1; ++k)
@@ -526,6 +532,20 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const Los
     float gT[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) gT[k] = wave_sum(gT3[k]);
+    if (nw > 1) {          // (every wave of the block is here: none left above)
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) pose_red[wave][k] = gT[k];
+      }
+      __syncthreads();
+      if (wave != 0) return;
+      // lane k < 12 adds the sixteen partial sums of component k in wave order, then the twelve totals go to every lane
+      float a = 0.f;
+      if (lane < 12)
+        for (int wv = 0; wv < FINALIZE_WAVES; ++wv) a += pose_red[wv][lane];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) gT[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), k));
+    }
     if (lane == 0) {
       float d[6];
       pose_backward(A.pose[i] + b * 6, gT, d);
