@@ -320,56 +320,120 @@ __global__ void sampler_fwd_kernel(const float* __restrict__ x, const float* __r
   }
 }
 
-// gx is a scatter: every output pixel adds to its four taps.  In a warp field most pixels have the next lane's cell right
-// beside their own (same tap row, next tap column), so the right-hand taps of lane l and the left-hand taps of lane l+1
-// are the same two addresses: lane l takes the neighbour's share along (DPP shift) and the neighbour skips those two
-// atomics.  Half the atomics on smooth grids, the same number on random ones; which lanes pair up depends only on the
-// grid, not on timing.
+// gx is a scatter: every output pixel adds to its four taps (float atomics: 12 per pixel at C = 3).  A float atomic is priced
+// per 64-byte request at the memory side, i.e. per wave-instruction and row it touches (MI355X_MICROARCH.md), so what counts is
+// the number of atomic INSTRUCTIONS with many active lanes.  A wave owns 64 consecutive output columns and walks DOWN a segment
+// of SAMPLER_BWD_ROWS output rows; in a warp field neighbouring output pixels sample neighbouring cells:
+//   * the pixel to the RIGHT usually has its cell one column further (same tap rows): its left-hand taps are my right-hand
+//     taps, so I take its two left-hand shares along (DPP shift) and it skips those two atomics;
+//   * the pixel BELOW usually has its cell one row further (same tap columns): its top taps are my bottom taps, so the bottom
+//     shares of a row are not written but CARRIED into the next row's top shares.
+// In the interior of a smooth field one atomic instruction per row and channel is left (the top-right taps) instead of four;
+// where cells do not line up the carried shares are written at once (a sparse instruction).  On a random grid nothing merges
+// and nothing is lost.  Which shares travel depends only on the grid, not on timing.
 __device__ __forceinline__ int int_from_left(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, true); }
 __device__ __forceinline__ int int_from_right(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x130, 0xf, 0xf, true); }
 
-__global__ void sampler_bwd_kernel(const float* __restrict__ x, const float* __restrict__ grid, const float* __restrict__ gy,
-                                   float* __restrict__ ggrid, float* __restrict__ gx, int C, int H, int W, int oP) {
-  const int n = blockIdx.y;
-  const int jj = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = jj < oP;          // no early exit: the lanes of a wave exchange values below
-  const int j = valid ? jj : oP - 1;
-  const int lane = threadIdx.x & 63;
-  const PadTap t = pad_taps(grid[((size_t)n * 2 + 0) * oP + j], grid[((size_t)n * 2 + 1) * oP + j], H, W);
-  const int u = t.u0, v = t.v0;
-  // pairing: my right-hand column is the neighbour's left-hand column, in the same pair of rows
-  const int nu = int_from_right(u), nv = int_from_right(v), nvalid = int_from_right(valid ? 1 : 0);
-  const bool take_right = (gx != nullptr) && valid && lane != 63 && nvalid != 0 && nv == v && nu == u + 1;
-  const bool skip_left = int_from_left(take_right ? 1 : 0) != 0;     // lane 0 receives 0
-  const bool in_u0 = u >= 1 && u <= W, in_u1 = u + 1 >= 1 && u + 1 <= W;
-  const bool in_v0 = v >= 1 && v <= H, in_v1 = v + 1 >= 1 && v + 1 <= H;
-  float gu = 0.f, gv = 0.f;
-  for (int c = 0; c < C; ++c) {
-    const float* img = x + ((size_t)n * C + c) * H * W;
-    const float g = valid ? gy[((size_t)n * C + c) * oP + j] : 0.f;
-    const float x1 = pad_read(img, v, u, H, W), x2 = pad_read(img, v, u + 1, H, W);
-    const float x3 = pad_read(img, v + 1, u, H, W), x4 = pad_read(img, v + 1, u + 1, H, W);
-    gu += g * (-t.wy0 * x1 + t.wy0 * x2 - t.wy1 * x3 + t.wy1 * x4);
-    gv += g * (-t.wx0 * x1 - t.wx1 * x2 + t.wx0 * x3 + t.wx1 * x4);
-    if (gx) {   // uniform
-      float* o = gx + ((size_t)n * C + c) * H * W;
-      const float a00 = g * t.wx0 * t.wy0, a10 = g * t.wx0 * t.wy1;
-      float a01 = g * t.wx1 * t.wy0, a11 = g * t.wx1 * t.wy1;
-      const float n00 = from_right(a00), n10 = from_right(a10);   // the neighbour's left-hand shares
-      if (take_right) { a01 += n00; a11 += n10; }
-      if (valid) {
-        if (!skip_left) {
-          if (in_u0 && in_v0) atomicAdd(o + (v - 1) * W + (u - 1), a00);
-          if (in_u0 && in_v1) atomicAdd(o + v * W + (u - 1), a10);
+constexpr int SAMPLER_BWD_ROWS = 8;        // output rows a wave walks down
+constexpr int SAMPLER_BWD_MAXC = 4;        // channels whose carried shares live in registers (more channels: no vertical carry)
+
+template <bool CARRY>
+__global__ void __launch_bounds__(256) sampler_bwd_kernel(const float* __restrict__ x, const float* __restrict__ grid, const float* __restrict__ gy,
+                                                          float* __restrict__ ggrid, float* __restrict__ gx, int C, int H, int W, int oH, int oW) {
+  const int n = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ox = blockIdx.x * 64 + lane;
+  const int oy0 = (blockIdx.y * 4 + wave) * SAMPLER_BWD_ROWS;
+  if (oy0 >= oH) return;                           // whole wave
+  const bool col_ok = ox < oW;                     // no early exit of single lanes: the lanes of a wave exchange values below
+  const int oP = oH * oW;
+  const bool scatter = gx != nullptr;
+  // the bottom shares of the previous row that have not been written yet (per channel), and the cell they belong to
+  float pend_l[SAMPLER_BWD_MAXC], pend_r[SAMPLER_BWD_MAXC];
+  bool pend = false, pend_l_owned = false;
+  int pu = 0, pv = 0;
+#pragma unroll
+  for (int c = 0; c < SAMPLER_BWD_MAXC; ++c) pend_l[c] = pend_r[c] = 0.f;
+  const int rows = min(SAMPLER_BWD_ROWS, oH - oy0);
+  for (int r = 0; r < rows; ++r) {
+    const int oy = oy0 + r;
+    const bool valid = col_ok;
+    const int j = oy * oW + (valid ? ox : oW - 1);
+    const PadTap t = pad_taps(grid[((size_t)n * 2 + 0) * oP + j], grid[((size_t)n * 2 + 1) * oP + j], H, W);
+    const int u = t.u0, v = t.v0;
+    // horizontal pairing: my right-hand column is the right neighbour's left-hand column, in the same pair of rows
+    const int nu = int_from_right(u), nv = int_from_right(v), nvalid = int_from_right(valid ? 1 : 0);
+    const bool take_right = scatter && valid && lane != 63 && nvalid != 0 && nv == v && nu == u + 1;
+    const bool skip_left = int_from_left(take_right ? 1 : 0) != 0;     // lane 0 receives 0
+    // vertical pairing: the cell of the previous row sits right above this one
+    const bool match = CARRY && pend && valid && pv + 1 == v && pu == u;
+    const bool in_u0 = u >= 1 && u <= W, in_u1 = u + 1 >= 1 && u + 1 <= W;
+    const bool in_v0 = v >= 1 && v <= H, in_v1 = v + 1 >= 1 && v + 1 <= H;
+    const bool pin_u0 = pu >= 1 && pu <= W, pin_u1 = pu + 1 >= 1 && pu + 1 <= W, pin_v1 = pv + 1 >= 1 && pv + 1 <= H;
+    float gu = 0.f, gv = 0.f;
+    auto channel = [&](const int c) {
+      {
+        const float* img = x + ((size_t)n * C + c) * H * W;
+        const float g = valid ? gy[((size_t)n * C + c) * oP + j] : 0.f;
+        const float x1 = pad_read(img, v, u, H, W), x2 = pad_read(img, v, u + 1, H, W);
+        const float x3 = pad_read(img, v + 1, u, H, W), x4 = pad_read(img, v + 1, u + 1, H, W);
+        gu += g * (-t.wy0 * x1 + t.wy0 * x2 - t.wy1 * x3 + t.wy1 * x4);
+        gv += g * (-t.wx0 * x1 - t.wx1 * x2 + t.wx0 * x3 + t.wx1 * x4);
+        if (scatter) {   // uniform
+          float* o = gx + ((size_t)n * C + c) * H * W;
+          float a00 = g * t.wx0 * t.wy0, a10 = g * t.wx0 * t.wy1;
+          float a01 = g * t.wx1 * t.wy0, a11 = g * t.wx1 * t.wy1;
+          const float n00 = from_right(a00), n10 = from_right(a10);   // the right neighbour's left-hand shares
+          if (take_right) { a01 += n00; a11 += n10; }
+          if (CARRY) {
+            // what the previous row left pending either joins this row's top shares (same addresses) or is written now
+            if (pend) {
+              if (match) a01 += pend_r[c];
+              else if (pin_u1 && pin_v1) atomicAdd(o + pv * W + pu, pend_r[c]);
+              if (pend_l_owned) {
+                if (match && !skip_left) a00 += pend_l[c];
+                else if (pin_u0 && pin_v1) atomicAdd(o + pv * W + (pu - 1), pend_l[c]);
+              }
+            }
+            if (valid) {
+              if (!skip_left && in_u0 && in_v0) atomicAdd(o + (v - 1) * W + (u - 1), a00);
+              if (in_u1 && in_v0) atomicAdd(o + (v - 1) * W + u, a01);
+            }
+            pend_l[c] = a10; pend_r[c] = a11;
+          } else if (valid) {
+            if (!skip_left) {
+              if (in_u0 && in_v0) atomicAdd(o + (v - 1) * W + (u - 1), a00);
+              if (in_u0 && in_v1) atomicAdd(o + v * W + (u - 1), a10);
+            }
+            if (in_u1 && in_v0) atomicAdd(o + (v - 1) * W + u, a01);
+            if (in_u1 && in_v1) atomicAdd(o + v * W + u, a11);
+          }
         }
-        if (in_u1 && in_v0) atomicAdd(o + (v - 1) * W + u, a01);
-        if (in_u1 && in_v1) atomicAdd(o + v * W + u, a11);
       }
+    };
+    if constexpr (CARRY) {   // a compile-time bound: the carried shares are register arrays
+#pragma unroll
+      for (int c = 0; c < SAMPLER_BWD_MAXC; ++c)
+        if (c < C) channel(c);
+    } else {
+      for (int c = 0; c < C; ++c) channel(c);
+    }
+    if (CARRY) { pend = scatter && valid; pend_l_owned = !skip_left; pu = u; pv = v; }
+    if (valid) {
+      ggrid[((size_t)n * 2 + 0) * oP + j] = t.ok_u ? gu * ((float)(W - 1) * 0.5f) : 0.f;
+      ggrid[((size_t)n * 2 + 1) * oP + j] = t.ok_v ? gv * ((float)(H - 1) * 0.5f) : 0.f;
     }
   }
-  if (valid) {
-    ggrid[((size_t)n * 2 + 0) * oP + j] = t.ok_u ? gu * ((float)(W - 1) * 0.5f) : 0.f;
-    ggrid[((size_t)n * 2 + 1) * oP + j] = t.ok_v ? gv * ((float)(H - 1) * 0.5f) : 0.f;
+  if (CARRY && pend) {   // the bottom shares of the segment's last row
+    const bool pin_u0 = pu >= 1 && pu <= W, pin_u1 = pu + 1 >= 1 && pu + 1 <= W, pin_v1 = pv + 1 >= 1 && pv + 1 <= H;
+#pragma unroll
+    for (int c = 0; c < SAMPLER_BWD_MAXC; ++c) {
+      if (c < C) {
+        float* o = gx + ((size_t)n * C + c) * H * W;
+        if (pin_u1 && pin_v1) atomicAdd(o + pv * W + pu, pend_r[c]);
+        if (pend_l_owned && pin_u0 && pin_v1) atomicAdd(o + pv * W + (pu - 1), pend_l[c]);
+      }
+    }
   }
 }
 
@@ -797,8 +861,13 @@ int sfm_sampler_bwd(const float* x, const float* grid, const float* gy, float* g
   SFM_REQUIRE(x && grid && gy && ggrid, SFM_ERR_NULL, "sfm_sampler_bwd: NULL pointer");
   if (int e = check_sampler_shape("sfm_sampler_bwd", N, C, H, W, oH, oW)) return e;
   if (N == 0 || oH * oW == 0) return SFM_OK;
-  hipLaunchKernelGGL(sampler_bwd_kernel, dim3((oH * oW + 255) / 256, N), dim3(256), 0, (hipStream_t)stream, x, grid, gy, ggrid,
-                     gx, C, H, W, oH * oW);
+  const int row_blocks = (oH + 4 * SAMPLER_BWD_ROWS - 1) / (4 * SAMPLER_BWD_ROWS);
+  SFM_REQUIRE(N <= 65535 && row_blocks <= 65535, SFM_ERR_SHAPE, "sfm_sampler_bwd: N=%d / oH=%d exceed the grid", N, oH);
+  const dim3 g((oW + 63) / 64, row_blocks, N);
+  if (C <= SAMPLER_BWD_MAXC)   // the carried shares of up to four channels live in registers
+    hipLaunchKernelGGL(sampler_bwd_kernel<true>, g, dim3(256), 0, (hipStream_t)stream, x, grid, gy, ggrid, gx, C, H, W, oH, oW);
+  else
+    hipLaunchKernelGGL(sampler_bwd_kernel<false>, g, dim3(256), 0, (hipStream_t)stream, x, grid, gy, ggrid, gx, C, H, W, oH, oW);
   return check_launch("sfm_sampler_bwd");
 }
 

@@ -107,7 +107,7 @@ def test_projective_inverse_warp_fwd_bwd(ops, synth, dev, shape, texture, depth_
     assert (e > 1e-3 * np.abs(w_src).max()).mean() < 1e-3
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 8, 13, 8, 13), (1, 2, 5, 7, 11, 3), (2, 3, 16, 52, 16, 52)])
+@pytest.mark.parametrize("shape", [(2, 3, 8, 13, 8, 13), (1, 2, 5, 7, 11, 3), (2, 3, 16, 52, 16, 52), (1, 6, 9, 70, 35, 67), (1, 4, 40, 9, 33, 130)])
 def test_normalized_sampler_fwd_bwd(ops, dev, shape):
     """F.spatial_transformer_sampler as called at models/transform.py:189, arbitrary grids
     including the zero-pad ring and far outside."""
@@ -126,7 +126,7 @@ def test_normalized_sampler_fwd_bwd(ops, dev, shape):
     np.testing.assert_allclose(to_np(gx), wgx, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 16, 52), (1, 2, 37, 70), (3, 3, 128, 416)])
+@pytest.mark.parametrize("shape", [(2, 3, 16, 52), (1, 2, 37, 70), (3, 3, 128, 416), (1, 6, 37, 70), (2, 4, 67, 130)])
 def test_normalized_sampler_bwd_on_warp_fields(ops, dev, shape):
     """The grids this sampler sees in the path (models/transform.py:189): the identity lattice plus a smooth displacement.
     Here most lanes share a tap column with their neighbour and sampler_bwd merges the two contributions before the atomic
