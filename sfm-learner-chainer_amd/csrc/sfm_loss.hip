@@ -67,7 +67,6 @@ struct LossArgs {
   int simds_per_xcd;           // SIMDs of one XCD (dispatch rounds -> age rank, see loss_kernel)
   int prio_top;                // resident waves per SIMD - 1, at most 3
   unsigned prio_tab;           // issue priority levels: 2 bits per (phase, rank), phase = first / second half of the sources
-  unsigned smooth_pos;         // where the smoothness pass runs, 2 bits per age rank (see loss_kernel)
 };
 
 template <bool SSIM, bool GRAD, int SMODE>
@@ -343,18 +342,17 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
   // Phases of a wave: the smoothness pass and one pass per source.  The smoothness pass is short on arithmetic and long
   // on latency, and the co-resident waves of a SIMD start together: the middle one (by age) runs it LAST, so that it
   // does not coincide with the others'.  (One call site per kind of pass: the phase loop costs no code.)
-  // (smooth_pos: 2 bits per age rank -- 0 first, 1 between the sources, 2 last; default: oldest and youngest first, middle last.
-  // Measured round 3, cfg3: every wave first +2 %, oldest first / middle between / youngest last +4...7 %, profiles/r03_smooth_position_sweep.txt)
-  const int spos = (int)((A.smooth_pos >> (2 * prio_rank)) & 3u);
-  const int smooth_at = (SMODE == 0) ? -1 : (spos == 0 ? 0 : (spos == 1 ? (A.n_src + 1) / 2 : A.n_src));
+  // (Measured round 3 with a run-time table, commit 40da7e8: every wave first +2 %, oldest first / middle between the sources /
+  // youngest last +4...7 %, the other mixed orders within noise of this one: profiles/r03_smooth_position_sweep.txt.)
+  const bool smooth_last = (SMODE != 0) && (prio_rank == 1);
   const int n_phases = A.n_src + (SMODE != 0 ? 1 : 0);
   for (int ph = 0; ph < n_phases; ++ph) {
-    const int i = (SMODE == 0) ? ph : (ph == smooth_at ? -1 : (ph < smooth_at ? ph : ph - 1));   // source of this phase; -1 = the smoothness pass
+    const int i = (SMODE != 0 && !smooth_last) ? ph - 1 : ph;   // source of this phase; -1 or n_src = the smoothness pass
 #ifdef SFM_STAMPS
     unsigned long long tp0 = 0, tp1 = 0;
     SFM_STAMP(tp0);
 #endif
-    if (SMODE != 0 && i < 0) {
+    if (SMODE != 0 && (i < 0 || i >= A.n_src)) {
       if (SMODE == 1) smooth2_pass<GRAD, LOSS>(A, S, S.disp + (size_t)b * P, lane, x, xin, outl, y0, y1, gacc, acc_sm, !first);
       else smooth_edge_pass<GRAD, LOSS, HWC>(A, S, S.disp + (size_t)b * P, S.tgt + (size_t)b * 3 * P, lane, x, xin, outl, y0, y1, gacc, acc_sm, !first);
       first = false;
@@ -639,8 +637,6 @@ struct Tuning {
   int rows_list[SFM_MAX_SCALES] = {0};      // SFM_CHUNK_ROWS_LIST: chunk height per scale, "13,13,16,8"
   bool has_prio = false;
   unsigned prio_tab = 0;                    // SFM_PRIO_TABLE: "0123,3210" = levels of ranks 0.. in phase 1, phase 2
-  bool has_smooth_pos = false;
-  unsigned smooth_pos = 0;                  // SFM_SMOOTH_POS: "020" = position of the smoothness pass of ranks 0.. (0 first, 1 middle, 2 last)
   Tuning() {
     if (const char* e = getenv("SFM_CHUNK_ROWS")) chunk_rows = atoi(e);
     if (const char* rl = getenv("SFM_CHUNK_ROWS_LIST")) {
@@ -649,11 +645,6 @@ struct Tuning {
         while (*rl && *rl != ',') ++rl;
         if (*rl == ',') ++rl;
       }
-    }
-    if (const char* sp = getenv("SFM_SMOOTH_POS")) {
-      for (int r = 0; *sp && r < 4; ++sp, ++r)
-        if (*sp >= '0' && *sp <= '2') smooth_pos |= (unsigned)(*sp - '0') << (2 * r);
-      has_smooth_pos = true;
     }
     if (const char* pt = getenv("SFM_PRIO_TABLE")) {
       int phase = 0, r = 0;
@@ -772,7 +763,6 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
   for (int r = 0; r <= A.prio_top; ++r)   // youngest preferred in the first half of the sources, oldest in the second
     A.prio_tab |= (unsigned)r << (2 * r) | (unsigned)(A.prio_top - r) << (8 + 2 * r);
   if (tuning().has_prio) A.prio_tab = tuning().prio_tab;
-  A.smooth_pos = tuning().has_smooth_pos ? tuning().smooth_pos : (0u | 2u << 2 | 0u << 4 | 0u << 6);
   plan_chunks(d, sw, 2 * (hs > hm ? hs : hm), slots, rows);
   int items = 0;
   for (int s = 0; s < d->n_scales; ++s) {
