@@ -334,6 +334,15 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
 
   float acc_pix = 0.f, acc_ssim = 0.f, acc_sm = 0.f, acc_exp = 0.f;
   bool first = true;
+  // the disparities every source pass of this wave starts from (see ssim_source_pass / l1_source_pass): loaded once, now
+  float disp_first, disp_second;
+  {
+    const float* dpl = S.disp + (size_t)b * P;
+    const int rfirst = y0 - HH::HS;
+    const unsigned xcl = (unsigned)min(max(x, 0), w - 1);
+    disp_first = ldf(dpl, (unsigned)min(max(rfirst, 0), h - 1) * (unsigned)w + xcl);
+    disp_second = ldf(dpl, (unsigned)min(max(rfirst + 1, 0), h - 1) * (unsigned)w + xcl);
+  }
 #ifdef SFM_STAMPS
   Stamps st = {0, 0, 0, 0, 0};
   unsigned long long ts0 = 0, cyc_smooth = 0, cyc_src = 0;
@@ -423,6 +432,8 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
     C.P = P;
     C.sc = sc;
     C.xc = (unsigned)min(max(x, 0), w - 1);
+    C.disp_first = disp_first;
+    C.disp_second = disp_second;
     C.xc12 = 12u * C.xc;
     C.w12 = 12u * (unsigned)w;
     C.w12f = (float)(12 * w);

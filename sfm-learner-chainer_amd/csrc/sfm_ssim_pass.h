@@ -55,6 +55,7 @@ struct SsimCtx {
 #ifdef SFM_GEOM_IN_WAVE
   float K1[3], kx[3];   // Kinv[j][1] (uniform), Kinv[j][0] x + Kinv[j][2]: for pose_sums_expand
 #endif
+  float disp_first, disp_second;   // disparity of the first row a pass fetches (row y0 - halo, clamped into the image) and of the next
   unsigned xc;          // column, clamped into the image (address-safe for halo lanes)
   unsigned xc12;        // 12 xc: byte offset of the lane's texel in a pixel-interleaved row
   unsigned w12;         // 12 w (uniform): bytes of a pixel-interleaved row
@@ -657,8 +658,10 @@ __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, 
   M.c = step_range(HS + 2, HS + 2 + R);
   // prologue: row rbeg in flight, and the disparity of the first row the loop will put in flight (row rbeg + 1, or row 0 for
   // the chunk at the top of the image: the steps before it fetch nothing and leave disp_next alone)
-  if (rbeg >= 0 && rbeg < C.h) issue_row<HWC>(C, rbeg, ldf(C.dp, (unsigned)rbeg * (unsigned)C.w + C.xc), ps);
-  disp_next = ldf(C.dp, (unsigned)min(max(rbeg + 1, 0), C.h - 1) * (unsigned)C.w + C.xc);
+  // (the two disparities a pass starts from are the same for every source: the wave loaded them once, at its start, so that no
+  // pass waits for a disparity before it can even form the addresses of its first gathers)
+  if (rbeg >= 0 && rbeg < C.h) issue_row<HWC>(C, rbeg, C.disp_first, ps);
+  disp_next = C.disp_second;
   for (int k = 0; k < n; k += 3) {
     const int r = rbeg + k;
     ssim_row_step<GRAD, LOSS, HWC>(C, M, k, r, ps, disp_next, S0, S2, S1, G0, G2, G1, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
@@ -681,8 +684,8 @@ __device__ __forceinline__ void l1_source_pass(const SsimCtx& C, float* gacc, co
   ps.lg = 0.f;
   float disp_next = 1.f;
   const int rbeg = C.y0, rend = C.y1;    // rows of a chunk are always inside the image
-  issue_row<HWC>(C, rbeg, ldf(C.dp, (unsigned)rbeg * (unsigned)C.w + C.xc), ps);
-  if (rbeg + 1 < rend) disp_next = ldf(C.dp, (unsigned)(rbeg + 1) * (unsigned)C.w + C.xc);
+  issue_row<HWC>(C, rbeg, C.disp_first, ps);
+  if (rbeg + 1 < rend) disp_next = C.disp_second;
   for (int r = rbeg; r < rend; ++r) {
     RowS s0;
     finish_row(C, ps, s0);
