@@ -130,7 +130,9 @@ def test_random_shapes_and_modes(ops, synth, dev, B, H, W, n_src, n_scales, cfg_
     by more than 5e-4, or whose knife-edge pixels exceed the cap, are re-drawn with the next seed (up to 16 draws; a choice made
     from oracle quantities alone).  The loss comparison itself gets NO allowance unless the kernel demonstrably zeroed a pixel
     differently from the oracle: those pixels are COUNTED (count_in_view_mismatches: single-source L1-only launches against the
-    oracle's), and only their reach -- never more than the oracle-side bound -- is added.  All of it is reported."""
+    oracle's), and only their reach -- never more than the oracle-side bound -- is added.  A d_pose array that misses its criteria
+    is accepted only when the oracle, re-run with named knife-edge pixels pushed across the discontinuity they sit on, matches the
+    kernel by the flat criteria (pose_explained_by_discontinuities).  All of it is reported."""
     from test_loss_gpu import count_in_view_mismatches, knife_cap, knife_mask
     from util import parity_note
     cfg = CONFIGS[cfg_name]
@@ -163,7 +165,9 @@ def test_random_shapes_and_modes(ops, synth, dev, B, H, W, n_src, n_scales, cfg_
     _check_losses(fl.forward_backward(), ref, slack=slack)
     ref64 = lambda: O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], d["masks"], backward=True,
                                dtype=np.float64, **cfg)
-    _check_grads(fl, ref, n_src, check_mask=bool(cfg.get("exp_reg")), what="sweep %s %dx%d" % (cfg_name, H, W), ref64=ref64)
+    from test_loss_gpu import pose_explained_by_discontinuities
+    _check_grads(fl, ref, n_src, check_mask=bool(cfg.get("exp_reg")), what="sweep %s %dx%d" % (cfg_name, H, W), ref64=ref64,
+                 explain=lambda i, got: pose_explained_by_discontinuities(d, cfg, ref, i, got))
 
 
 @pytest.mark.parametrize("rows", [4, 28])

@@ -132,9 +132,69 @@ def src_footprints(ref, s, knife):
     return np.repeat(out, 3, axis=1)
 
 
-def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=True, what="", ref64=None, cell_thr=1e-4):
+def pose_explained_by_discontinuities(d, cfg, ref, i, got, norm_B=None, cell_thr=1e-4, max_px=48):
+    """Third opinion for d_pose[i] (B,6): is the kernel's value the ORACLE's with a few named pixels on the other side of a
+    discontinuity they sit on?  For every sample whose d_pose row is off by more than a quarter of the gradient tolerance, the
+    fp32 oracle is re-run on that sample and source alone (same normalisation: norm_batch) with ONE knife-edge pixel's disparity
+    nudged by +-1e-3 / +-1e-2 of its value; a nudge that makes d_pose JUMP (by more than 1e-4 of its maximum; the smooth response
+    to such a nudge is <= 1e-2 of one pixel's share, 1e-5) is that pixel taking its other branch.  Jumps are then picked greedily
+    (each pixel once, only while the distance to the kernel's row shrinks by > 10 %).  Returns the oracle's array with the
+    picked jumps added and the list of pixels; the caller judges the kernel against it with the flat criteria."""
+    want = np.asarray(ref["d_poses"][i], np.float64)
+    got = np.asarray(got, np.float64)
+    scale = float(np.abs(want).max())
+    S = len(d["disps"])
+    B = want.shape[0]
+    Bn = B if norm_B is None else norm_B
+    kw = dict(cfg, smooth_reg=0.0)
+    out, named = want.copy(), []
+    for b in np.nonzero(np.abs(got - want).max(axis=1) > 0.25 * GRAD_TOL * scale)[0]:
+        sl = slice(int(b), int(b) + 1)
+        base_in = dict(tgt_pyr=[a[sl] for a in d["tgt_pyr"]], src_pyr=[a[sl, 3 * i:3 * i + 3] for a in d["src_pyr"]], intrinsics=d["intrinsics"][sl],
+                       poses=[d["poses"][i][sl]], masks=[a[sl, i:i + 1] for a in d["masks"]] if (d["masks"] is not None and cfg.get("exp_reg")) else None)
+
+        def pose_grad(disps):
+            r = O.sfm_loss(base_in["tgt_pyr"], base_in["src_pyr"], base_in["intrinsics"], disps, base_in["poses"], base_in["masks"],
+                           backward=True, norm_batch=Bn, **kw)
+            return np.asarray(r["d_poses"][0][0], np.float64)
+
+        disps0 = [a[sl].copy() for a in d["disps"]]
+        base = pose_grad(disps0)
+        assert np.abs(base - want[b]).max() <= 1e-5 * scale, "the one-sample oracle run does not reproduce the batch's d_pose"
+        cands = []
+        for s in range(S):
+            m = ((ref["margin"][s][b, i] < 8e-6) | (ref["cell_margin"][s][b, i] < cell_thr) | (ref["abs_margin"][s][b, i] < 3e-5)
+                 | (ref["clip_margin"][s][b, i] < 5e-5))
+            cands += [(s, int(y), int(x)) for y, x in np.argwhere(m)]
+        if len(cands) > max_px:
+            return None, "sample %d has %d knife-edge pixels (> %d): too many to probe" % (b, len(cands), max_px)
+        jumps = []
+        for (s, y, x) in cands:
+            for rel in (1e-3, -1e-3, 1e-2, -1e-2):
+                disps = [a.copy() for a in disps0]
+                disps[s][0, 0, y, x] *= np.float32(1 + rel)
+                dlt = pose_grad(disps) - base
+                if np.abs(dlt).max() > 1e-4 * scale and not any(p == (s, y, x) and np.abs(dlt - q).max() < 1e-5 * scale for p, q in jumps):
+                    jumps.append(((s, y, x), dlt))
+        res, used = got[b] - want[b], set()
+        while True:
+            best = None
+            for p, dlt in jumps:
+                if p not in used and (best is None or np.linalg.norm(res - dlt) < np.linalg.norm(res - best[1])):
+                    best = (p, dlt)
+            if best is None or np.linalg.norm(res - best[1]) > 0.9 * np.linalg.norm(res):
+                break
+            used.add(best[0])
+            res = res - best[1]
+            out[b] += best[1]
+            named.append("sample %d scale %d pixel (%d,%d)" % ((b,) + best[0]))
+    return out, named
+
+
+def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=True, what="", ref64=None, cell_thr=1e-4, explain=None):
     """`ref64`: optional callable returning the fp64 oracle's result; consulted only for an array that misses the fp32
-    criterion (see _judged64), and every such use is reported.  `cell_thr`: see _knife."""
+    criterion (see _judged64), and every such use is reported.  `cell_thr`: see _knife.  `explain`: optional callable
+    (i, got) -> pose_explained_by_discontinuities(...), consulted for a d_pose array that misses everything else."""
     worst = 0.0
     r64 = []
 
@@ -145,7 +205,13 @@ def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=T
 
     def close(got, w, knife, name, key, idx, extra=0.0):
         try:
-            assert_close_masked(got, w, GRAD_TOL + extra, knife, what=name)
+            try:
+                assert_close_masked(got, w, GRAD_TOL, knife, what=name)
+            except AssertionError:
+                if not extra:
+                    raise
+                assert_close_masked(got, w, GRAD_TOL + extra, knife, what=name)
+                parity_note("in-view allowance USED for %s %s: misses the flat %.0e, passes at %.2e" % (what, name, GRAD_TOL, GRAD_TOL + extra))
         except AssertionError:
             if ref64 is None:
                 raise
@@ -187,6 +253,9 @@ def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=T
     # pixel (measured: one such pixel of a 92x108 image moved d_pose by 0.26 % of its maximum).  The allowance goes by how many
     # pixels the ORACLE puts within `thr` of that test (nothing the kernel computes enters it): one gradient tolerance per such
     # pixel at 10^4 pixels per image and proportionally less above, POSE_FLIP_CAP in total.  The observed count is printed.
+    # An array that still misses a criterion can be EXPLAINED where the oracle is cheap to re-run (`explain`, see
+    # pose_explained_by_discontinuities): the oracle is re-evaluated with single named pixels pushed across the discontinuity
+    # they sit on, and the kernel must then meet the flat criteria, without any allowance, against that evaluation.
     n_on_test = 0 if on_test is None else int(on_test.max())
     n_observed = 0 if observed is None else int(observed.max())
     px0 = float(fl.d_disps[0].shape[-2] * fl.d_disps[0].shape[-1])      # a pixel's weight in the sums falls with the image size
@@ -194,8 +263,23 @@ def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=T
     worst_pose = 0.0
     pose_l2_tol = POSE_L2_TOL if px0 <= 1.0e5 else 2.0 * POSE_L2_TOL
     for i, (g, w) in enumerate(zip(fl.d_poses, ref["d_poses"]) if check_pose else ()):
-        close(to_np(g), w, None, "d_pose[%d]" % i, "d_poses", i, extra=extra)
-        worst_pose = max(worst_pose, l2_ok(to_np(g), w, None, "d_pose[%d]" % i, "d_poses", i, tol=pose_l2_tol))
+        try:
+            close(to_np(g), w, None, "d_pose[%d]" % i, "d_poses", i, extra=extra)
+            worst_pose = max(worst_pose, l2_ok(to_np(g), w, None, "d_pose[%d]" % i, "d_poses", i, tol=pose_l2_tol))
+        except AssertionError as first:
+            if explain is None:
+                raise
+            w2, named = explain(i, to_np(g))
+            if w2 is None or not named:
+                raise AssertionError("%s\n(not explained by knife-edge pixels: %s)" % (first, named))
+            # against the oracle with the named pixels on their other branch: the flat criteria, no allowance
+            assert_close_masked(to_np(g), w2, GRAD_TOL, None, what="d_pose[%d] vs the oracle with %s on the other branch" % (i, named))
+            l2 = rel_l2(to_np(g), w2)
+            assert l2 <= pose_l2_tol, "d_pose[%d]: relative L2 %.2e vs the oracle with %s on the other branch" % (i, l2, named)
+            worst_pose = max(worst_pose, l2)
+            parity_note("d_pose EXPLAINED for %s d_pose[%d]: misses the criteria against the oracle as is (%s); equals the oracle with %s "
+                        "pushed across the discontinuity it sits on (relative L2 %.2e, flat %.0e met)" % (
+                            what, i, str(first).split("\n")[0][:120], ", ".join(named), l2, GRAD_TOL))
     parity_note("grads %s: worst relative L2 of d_disp outside knife pixels %.2e (tol %.0e), of d_pose %.2e (tol %.0e); d_pose "
                 "element-wise allowance %.2e for %d pixels the oracle has on the in-view test (%d observed as taken differently)" % (
                     what, worst, L2_TOL, worst_pose, pose_l2_tol, extra, n_on_test, n_observed))
