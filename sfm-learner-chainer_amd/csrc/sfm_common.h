@@ -58,13 +58,35 @@ __device__ __forceinline__ void mat3_mul_nt(const float* a, const float* b, floa
     for (int j = 0; j < 3; ++j) o[i * 3 + j] = a[i * 3 + 0] * b[j * 3 + 0] + a[i * 3 + 1] * b[j * 3 + 1] + a[i * 3 + 2] * b[j * 3 + 2];
 }
 
+// sin and cos of an angle in [-pi, pi] (euler2mat clips to that range, transform.py:23): one Cody-Waite reduction by pi/2 (two
+// constants, fused multiply-adds: the reduced argument is exact to 1e-15) and the single-precision minimax kernels on
+// [-pi/4, pi/4] (Cephes sinf / cosf; < 1 ulp there).  The library's sincosf spends 500 of its 600 instructions on arguments this
+// path never sees (Payne-Hanek reduction), and the geometry and finalize kernels are single chains of dependent instructions:
+// 0.6 - 1.6 us of a 64 us step (profiles/r03_ab_small_kernels.txt).
+__device__ __forceinline__ void sincos_pi(const float a, float* sn, float* cs) {
+  const float kf = rintf(a * 0.636619772367581343f);            // quadrant: -2 .. 2
+  float y = fmaf(-kf, 1.57079637050628662109375f, a);
+  y = fmaf(-kf, -4.37113900018624283e-8f, y);
+  const float z = y * y;
+  const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * y, y);
+  const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fmaf(-0.5f, z, 1.0f));
+  const int q = (int)kf & 3;                                     // two's complement: -1 -> 3, -2 -> 2
+  const float s0 = (q & 1) ? pc : ps, c0 = (q & 1) ? ps : pc;
+  *sn = (q & 2) ? -s0 : s0;
+  *cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
 // euler2mat, models/transform.py:11-40:  R = (X . Y) . Z, angles clipped to [-pi, pi]
 __device__ __forceinline__ void euler2mat(const float* r, Rot& o) {
   const float pi = 3.14159265358979323846f;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     float a = fminf(fmaxf(r[k], -pi), pi);
-    sincosf(a, &o.s[k], &o.c[k]);   // one argument reduction for both (same values as sinf / cosf)
+#ifdef SFM_LIBRARY_SINCOS   // the library's sincosf instead
+    sincosf(a, &o.s[k], &o.c[k]);
+#else
+    sincos_pi(a, &o.s[k], &o.c[k]);
+#endif
   }
   const float Z[9] = {o.c[2], -o.s[2], 0.f, o.s[2], o.c[2], 0.f, 0.f, 0.f, 1.f};
   const float Y[9] = {o.c[1], 0.f, o.s[1], 0.f, 1.f, 0.f, -o.s[1], 0.f, o.c[1]};
@@ -120,10 +142,9 @@ __device__ __forceinline__ void make_geom(const float* pose6, const float* K, Ge
 
 // Backward of proj_tgt_to_src for one sample.
 //   gT3 = (K^T . gPm[0:3, :]) accumulated by the caller over scales: 3x4, row-major
-__device__ __forceinline__ void pose_backward(const float* pose6, const float* gT3, float* d_pose6) {
+//   rot = euler2mat(pose6): taken as an argument so that a caller can compute it while the sums behind gT3 are still in flight
+__device__ __forceinline__ void pose_backward(const float* pose6, const Rot& rot, const float* gT3, float* d_pose6) {
   const float pi = 3.14159265358979323846f;
-  Rot rot;
-  euler2mat(pose6, rot);
   float gR[9];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
@@ -142,6 +163,12 @@ __device__ __forceinline__ void pose_backward(const float* pose6, const float* g
     d_pose6[k] = (pose6[k] > -pi && pose6[k] < pi) ? g : 0.f;   // F.clip backward (transform.py:23)
     d_pose6[3 + k] = gT3[k * 4 + 3];
   }
+}
+
+__device__ __forceinline__ void pose_backward(const float* pose6, const float* gT3, float* d_pose6) {
+  Rot rot;
+  euler2mat(pose6, rot);
+  pose_backward(pose6, rot, gT3, d_pose6);
 }
 
 // ------------------------------------------------------------------------------------------

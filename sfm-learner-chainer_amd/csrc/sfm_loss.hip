@@ -522,21 +522,42 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const Los
     // faster than sharing); more are spread over all the waves of the block
     const int nw = total > 128 ? FINALIZE_WAVES : 1;    // block-uniform
     if (wave >= nw) return;
-    for (int idx = threadIdx.x; idx < total; idx += 64 * nw) {
+    // The pose is fetched first and its rotation (euler2mat: a chain of ~150 dependent instructions) is built by wave 0 while
+    // the first round of partials is in flight; pose_backward below then starts from it.
+    float pose6[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pose6[k] = A.pose[i][b * 6 + k];
+    auto fetch = [&](const int idx, float4& v0, float4& v1, float4& v2, float* K) {
       int s = 0, off = 0;
 #pragma unroll
       for (int k = 0; k < SFM_MAX_SCALES - 1; ++k)
         if (k + 1 < A.n_scales && idx >= off + A.sc[k].tiles && s == k) { off += A.sc[k].tiles; s = k + 1; }
       const int t = idx - off;
       const float4* p = reinterpret_cast<const float4*>(A.part_gpm + ((size_t)(A.sc[s].item_begin + b * A.sc[s].tiles + t) * A.n_src + i) * 12);
-      const float4 v0 = p[0], v1 = p[1], v2 = p[2];
+      v0 = p[0]; v1 = p[1]; v2 = p[2];
+      const float* Kp = A.intrinsics + ((size_t)b * A.n_scales + s) * 9;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) K[k] = Kp[k];
+    };
+    auto fold = [&](const float4& v0, const float4& v1, const float4& v2, const float* K) {
       const float g[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
-      const float* K = A.intrinsics + ((size_t)b * A.n_scales + s) * 9;
       // gT3 += K^T . gPm   (K4^T . gPm of the rows that reach R and t)
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 4; ++c) gT3[r * 4 + c] += K[0 * 3 + r] * g[0 * 4 + c] + K[1 * 3 + r] * g[1 * 4 + c] + K[2 * 3 + r] * g[2 * 4 + c];
+    };
+    float4 a0, a1, a2;
+    float Ka[9];
+    const int idx0 = threadIdx.x;
+    const bool has0 = idx0 < total;
+    if (has0) fetch(idx0, a0, a1, a2, Ka);
+    Rot rot;
+    if (wave == 0) euler2mat(pose6, rot);      // (wave-uniform; the result is only read by lane 0 of wave 0)
+    if (has0) fold(a0, a1, a2, Ka);
+    for (int idx = idx0 + 64 * nw; idx < total; idx += 64 * nw) {
+      fetch(idx, a0, a1, a2, Ka);
+      fold(a0, a1, a2, Ka);
     }
     float gT[12];
 #pragma unroll
@@ -557,7 +578,7 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const Los
     }
     if (lane == 0) {
       float d[6];
-      pose_backward(A.pose[i] + b * 6, gT, d);
+      pose_backward(pose6, rot, gT, d);
 #pragma unroll
       for (int k = 0; k < 6; ++k) A.d_pose[i][b * 6 + k] = d[k];
     }

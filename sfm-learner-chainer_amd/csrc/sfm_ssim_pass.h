@@ -587,6 +587,10 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const StepMasks&
   unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
 #endif
   SFM_STAMP(t0);
+#ifdef SFM_EXTRA_SALU   // timing experiment only: what a scalar instruction costs the row step
+#pragma unroll
+  for (int q = 0; q < SFM_EXTRA_SALU; ++q) asm volatile("s_cmp_eq_u32 0, 0" ::: "scc");
+#endif
   // ---------------- A: finish row r, put row r+1 in flight ----------------
   // (the arithmetic always runs -- on whatever the tap registers hold when the row lies outside the image -- and the rare case
   // overwrites the slot: an if / else costs five more scalar instructions per step than an if)
