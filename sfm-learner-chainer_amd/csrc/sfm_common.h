@@ -234,6 +234,24 @@ __device__ __forceinline__ float wave_sum(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// N wave sums in LOCKSTEP (stage by stage over all N values): N independent DPP adds per stage instead of N dependent chains of
+// six.  Same adds in the same order per value as wave_sum: bit-identical totals, left in lane 63 of every v[k].
+template <int N>
+__device__ __forceinline__ void wave_sums_lockstep(float (&v)[N]) {
+#define SFM_DPP_STAGE(ctrl, rmask)                                                                                              \
+  _Pragma("unroll") for (int i = 0; i < N; ++i)                                                                                 \
+      v[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[i]), ctrl, rmask, 0xf, true));  \
+  __builtin_amdgcn_sched_barrier(0)
+  SFM_DPP_STAGE(0x111, 0xf);   // row_shr:1
+  SFM_DPP_STAGE(0x112, 0xf);   // row_shr:2
+  SFM_DPP_STAGE(0x114, 0xf);   // row_shr:4
+  SFM_DPP_STAGE(0x118, 0xf);   // row_shr:8   -> lane 15 of every row of 16 holds the row sum
+  SFM_DPP_STAGE(0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+  SFM_DPP_STAGE(0x143, 0xc);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+#undef SFM_DPP_STAGE
+}
+__device__ __forceinline__ float lane63(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); }
+
 __device__ __forceinline__ float uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 
 // sign(t) with sign(0) = 0 (F.absolute backward): copysign(1, t) unless t == 0   (v_bfi + v_cmp + v_cndmask)

@@ -93,11 +93,23 @@ __global__ void geom_kernel(const LossArgs A) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int total = A.B * A.n_scales * A.n_src;
   if (t >= total) return;
+#ifdef SFM_ABLATE_GEOM_EMPTY   // timing experiment only: the floor of this launch
+  if (A.gy != 12345.f) return;
+#endif
   const int i = t % A.n_src;
   const int bs = t / A.n_src;  // b * n_scales + s
   const int b = bs / A.n_scales;
+  // (the pose pointer is SELECTED from the argument block, not loaded through a lane-dependent index: that load would be one more
+  //  round trip to memory in front of the pose itself -- this kernel is nothing but a chain of such round trips)
+  const float* pp = nullptr;
+#pragma unroll
+  for (int k = 0; k < SFM_MAX_SRC; ++k) {
+    const float* pk = A.pose[k];
+    asm volatile("" : "+s"(pk));     // (keeps the selection from being folded back into an indexed load)
+    pp = (i == k) ? pk : pp;
+  }
   Geom g;
-  make_geom(A.pose[i] + b * 6, A.intrinsics + (size_t)bs * 9, g);
+  make_geom(pp + b * 6, A.intrinsics + (size_t)bs * 9, g);
   A.geom[t] = g;
 }
 
@@ -501,67 +513,109 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+#ifdef SFM_FIN_STAMPS   // diagnostic build only: 100 MHz time stamps of finalize_kernel's stages into the debug trace buffer (tools/trace_finalize.py)
+#define SFM_FSTAMP(slot) do { if (A.trace && threadIdx.x == 0) A.trace[200000 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SFM_FSTAMP(slot) do { } while (0)
+#endif
+
 constexpr int FINALIZE_WAVES = 16;   // waves of the block that sums the loss partials (the pose blocks use one)
 
 __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const LossArgs A, float* __restrict__ loss5, const int n_pose_blocks) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#ifdef SFM_ABLATE_FINALIZE_EMPTY   // timing experiment only: the floor of this launch
+  if (A.gy != 12345.f) return;
+#endif
   if ((int)blockIdx.x < n_pose_blocks) {
     // d_pose of (b, i): every lane folds its tiles of every scale into K_s^T . gPm (linear), one in-register wave reduction (DPP).
     // A sample with many tiles (308 at cfg2, 376 at cfg5) is spread over the sixteen waves of the block, so that its partials are
     // fetched in ONE round of independent loads instead of up to six dependent rounds (-1 us on those steps); the waves' sums meet
     // in LDS and are added in wave order: a fixed order, the result does not depend on timing.
     const int b = blockIdx.x / A.n_src, i = blockIdx.x - b * A.n_src;
+    const bool stamp = blockIdx.x == 0;
+    if (stamp) SFM_FSTAMP(0);
     __shared__ float pose_red[FINALIZE_WAVES][12];
-    float gT3[12];
+    // This block is a chain of round trips to memory with little arithmetic between them, so it is written to need TWO: every field
+    // of the argument block it uses is fetched unconditionally and at once (tile counts of all SFM_MAX_SCALES scales -- zero beyond
+    // n_scales --, all pose pointers: the one of source i is selected, not loaded through an index), then the pose and up to two
+    // rounds of partials go out together.  While they are in flight wave 0 has nothing to do; when the pose arrives it builds the
+    // rotation (euler2mat: ~150 dependent instructions) under the shadow of the partials.
+    int tl[SFM_MAX_SCALES], ib[SFM_MAX_SCALES];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) gT3[k] = 0.f;
-    // all (scale, tile) pairs of this sample as one index space: independent loads, no per-scale round trips
+    for (int k = 0; k < SFM_MAX_SCALES; ++k) { tl[k] = A.sc[k].tiles; ib[k] = A.sc[k].item_begin; }
+    const float* pp = nullptr;
+    float* dp = nullptr;
+#pragma unroll
+    for (int k = 0; k < SFM_MAX_SRC; ++k) {
+      const float* pk = A.pose[k];
+      float* dk = A.d_pose[k];
+      asm volatile("" : "+s"(pk), "+s"(dk));   // (keeps the selection from being folded back into an indexed load)
+      pp = (i == k) ? pk : pp;
+      dp = (i == k) ? dk : dp;
+    }
     int total = 0;
-    for (int s = 0; s < A.n_scales; ++s) total += A.sc[s].tiles;
+#pragma unroll
+    for (int k = 0; k < SFM_MAX_SCALES; ++k) total += tl[k];
     // up to two rounds of loads one wave does alone (cfg3: the block's other waves leave at once, no LDS, no barrier: 1 us
     // faster than sharing); more are spread over all the waves of the block
     const int nw = total > 128 ? FINALIZE_WAVES : 1;    // block-uniform
     if (wave >= nw) return;
-    // The pose is fetched first and its rotation (euler2mat: a chain of ~150 dependent instructions) is built by wave 0 while
-    // the first round of partials is in flight; pose_backward below then starts from it.
+    if (stamp) SFM_FSTAMP(1);
     float pose6[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) pose6[k] = A.pose[i][b * 6 + k];
-    auto fetch = [&](const int idx, float4& v0, float4& v1, float4& v2, float* K) {
-      int s = 0, off = 0;
+    for (int k = 0; k < 6; ++k) pose6[k] = pp[b * 6 + k];
+    float gT3[12];
 #pragma unroll
-      for (int k = 0; k < SFM_MAX_SCALES - 1; ++k)
-        if (k + 1 < A.n_scales && idx >= off + A.sc[k].tiles && s == k) { off += A.sc[k].tiles; s = k + 1; }
-      const int t = idx - off;
-      const float4* p = reinterpret_cast<const float4*>(A.part_gpm + ((size_t)(A.sc[s].item_begin + b * A.sc[s].tiles + t) * A.n_src + i) * 12);
-      v0 = p[0]; v1 = p[1]; v2 = p[2];
-      const float* Kp = A.intrinsics + ((size_t)b * A.n_scales + s) * 9;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) K[k] = Kp[k];
-    };
-    auto fold = [&](const float4& v0, const float4& v1, const float4& v2, const float* K) {
-      const float g[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
-      // gT3 += K^T . gPm   (K4^T . gPm of the rows that reach R and t)
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) gT3[r * 4 + c] += K[0 * 3 + r] * g[0 * 4 + c] + K[1 * 3 + r] * g[1 * 4 + c] + K[2 * 3 + r] * g[2 * 4 + c];
-    };
-    float4 a0, a1, a2;
-    float Ka[9];
-    const int idx0 = threadIdx.x;
-    const bool has0 = idx0 < total;
-    if (has0) fetch(idx0, a0, a1, a2, Ka);
+    for (int k = 0; k < 12; ++k) gT3[k] = 0.f;
+    // (macros, not lambdas: arrays captured by reference are not split into registers, the compiler parks them in LDS and fetches
+    //  the workgroup size for that from the dispatch packet -- in host memory, 10 us away)
+#define SFM_FIN_FETCH(idx_, v0_, v1_, v2_, K_)                                                                                    \
+  {                                                                                                                               \
+    int s_ = 0, off_ = 0;                                                                                                         \
+    _Pragma("unroll") for (int k = 0; k < SFM_MAX_SCALES - 1; ++k)                                                                \
+        if ((idx_) >= off_ + tl[k] && s_ == k) { off_ += tl[k]; s_ = k + 1; }                                                     \
+    int ibs_ = ib[0], tls_ = tl[0];                                                                                               \
+    _Pragma("unroll") for (int k = 1; k < SFM_MAX_SCALES; ++k) { ibs_ = (s_ == k) ? ib[k] : ibs_; tls_ = (s_ == k) ? tl[k] : tls_; } \
+    const float4* p_ = reinterpret_cast<const float4*>(A.part_gpm + ((size_t)(ibs_ + b * tls_ + ((idx_) - off_)) * A.n_src + i) * 12); \
+    v0_ = p_[0]; v1_ = p_[1]; v2_ = p_[2];                                                                                        \
+    const float* Kp_ = A.intrinsics + ((size_t)b * A.n_scales + s_) * 9;                                                          \
+    _Pragma("unroll") for (int k = 0; k < 9; ++k) K_[k] = Kp_[k];                                                                 \
+  }
+    // gT3 += K^T . gPm   (K4^T . gPm of the rows that reach R and t)
+#define SFM_FIN_FOLD(v0_, v1_, v2_, K_)                                                                                           \
+  {                                                                                                                               \
+    const float g_[12] = {v0_.x, v0_.y, v0_.z, v0_.w, v1_.x, v1_.y, v1_.z, v1_.w, v2_.x, v2_.y, v2_.z, v2_.w};                    \
+    _Pragma("unroll") for (int r = 0; r < 3; ++r)                                                                                 \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                             \
+            gT3[r * 4 + c] += K_[0 * 3 + r] * g_[0 * 4 + c] + K_[1 * 3 + r] * g_[1 * 4 + c] + K_[2 * 3 + r] * g_[2 * 4 + c];      \
+  }
+    const int stride = 64 * nw;
+    const int idx0 = threadIdx.x, idx1 = idx0 + stride;
+    const bool has0 = idx0 < total, has1 = idx1 < total;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, c0 = a0, c1 = a0, c2 = a0;
+    float Ka[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, Kc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (has0) SFM_FIN_FETCH(idx0, a0, a1, a2, Ka)
+    if (has1) SFM_FIN_FETCH(idx1, c0, c1, c2, Kc)
     Rot rot;
     if (wave == 0) euler2mat(pose6, rot);      // (wave-uniform; the result is only read by lane 0 of wave 0)
-    if (has0) fold(a0, a1, a2, Ka);
-    for (int idx = idx0 + 64 * nw; idx < total; idx += 64 * nw) {
-      fetch(idx, a0, a1, a2, Ka);
-      fold(a0, a1, a2, Ka);
+#ifdef SFM_FIN_STAMPS
+    if (stamp && rot.R[0] != 77.f) SFM_FSTAMP(2);
+#endif
+    if (has0) SFM_FIN_FOLD(a0, a1, a2, Ka)
+    if (has1) SFM_FIN_FOLD(c0, c1, c2, Kc)
+    for (int idx = idx1 + stride; idx < total; idx += stride) {   // (samples of more than 2048 tiles)
+      SFM_FIN_FETCH(idx, a0, a1, a2, Ka)
+      SFM_FIN_FOLD(a0, a1, a2, Ka)
     }
+#undef SFM_FIN_FETCH
+#undef SFM_FIN_FOLD
+#ifdef SFM_FIN_STAMPS
+    if (stamp && gT3[0] != 77.f) SFM_FSTAMP(3);
+#endif
+    wave_sums_lockstep(gT3);
     float gT[12];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) gT[k] = wave_sum(gT3[k]);
+    for (int k = 0; k < 12; ++k) gT[k] = lane63(gT3[k]);
     if (nw > 1) {          // (every wave of the block is here: none left above)
       if (lane == 0) {
 #pragma unroll
@@ -576,11 +630,17 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const Los
 #pragma unroll
       for (int k = 0; k < 12; ++k) gT[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), k));
     }
+#ifdef SFM_FIN_STAMPS
+    if (stamp && gT[0] != 77.f) SFM_FSTAMP(4);
+#endif
     if (lane == 0) {
       float d[6];
       pose_backward(pose6, rot, gT, d);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) A.d_pose[i][b * 6 + k] = d[k];
+      for (int k = 0; k < 6; ++k) dp[b * 6 + k] = d[k];
+#ifdef SFM_FIN_STAMPS
+      if (stamp && d[0] != 77.f) SFM_FSTAMP(5);
+#endif
     }
     return;
   }
@@ -589,6 +649,7 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const Los
   // wave reduction of (hi, lo) float pairs (DPP), recombined in fp64
   // (16 waves, so that the partials are fetched in one or two rounds of independent loads; the waves' sums
   // meet in LDS and are added in wave order: the result does not depend on timing)
+  SFM_FSTAMP(8);
   __shared__ double wave_red[FINALIZE_WAVES][4];
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   const float4* pl = reinterpret_cast<const float4*>(A.part_loss);
@@ -597,19 +658,38 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const Los
     const float4 v = pl[t];
     acc[0] += (double)v.x; acc[1] += (double)v.y; acc[2] += (double)v.z; acc[3] += (double)v.w;
   }
+#ifdef SFM_FIN_STAMPS
+  if (acc[0] != 77.0) SFM_FSTAMP(9);
+#endif
+  {
+    float hl[8];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float hi = (float)acc[k];
-    const float lo = (float)(acc[k] - (double)hi);
-    const double r = (double)wave_sum(hi) + (double)wave_sum(lo);
-    if (lane == 0) wave_red[wave][k] = r;
+    for (int k = 0; k < 4; ++k) {
+      hl[2 * k] = (float)acc[k];
+      hl[2 * k + 1] = (float)(acc[k] - (double)hl[2 * k]);
+    }
+    wave_sums_lockstep(hl);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double r = (double)lane63(hl[2 * k]) + (double)lane63(hl[2 * k + 1]);
+      if (lane == 0) wave_red[wave][k] = r;
+    }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double red[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int wv = 0; wv < FINALIZE_WAVES; ++wv)
+  SFM_FSTAMP(10);
+  if (wave == 0) {
+    // lane k < 4 adds the sixteen wave sums of scalar k in wave order (four chains side by side instead of 64 additions in a row)
+    double mine = 0.0;
+    if (lane < 4)
+      for (int wv = 0; wv < FINALIZE_WAVES; ++wv) mine += wave_red[wv][lane];
+    double red[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) red[k] += wave_red[wv][k];
+    for (int k = 0; k < 4; ++k) {
+      const unsigned long long bits = __builtin_bit_cast(unsigned long long, mine);
+      const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, k), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), k);
+      red[k] = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+    }
+    if (lane != 0) return;
     const double pixel = red[0], ssim = red[1], smooth = red[2], expl = red[3];
     const double a = (double)A.alpha;
     loss5[0] = (float)((1.0 - a) * pixel + a * ssim + smooth + expl);   // base_model.py:117-118
@@ -617,6 +697,7 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const Los
     loss5[2] = (float)smooth;
     loss5[3] = (float)expl;
     loss5[4] = (float)ssim;
+    SFM_FSTAMP(11);
   }
 }
 

@@ -424,17 +424,7 @@ __device__ __forceinline__ void pose_sums_expand(const SsimCtx& C, const PoseAcc
     for (int j = 0; j < 3; ++j) v[k * 4 + j] = fmaf(K1[j], acc[3 + k], kx[j] * acc[k]);
     v[k * 4 + 3] = acc[6 + k];
   }
-#define SFM_DPP_STAGE(ctrl, rmask)                                                                                              \
-  _Pragma("unroll") for (int i = 0; i < 12; ++i)                                                                                \
-      v[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[i]), ctrl, rmask, 0xf, true));  \
-  __builtin_amdgcn_sched_barrier(0)
-  SFM_DPP_STAGE(0x111, 0xf);   // row_shr:1
-  SFM_DPP_STAGE(0x112, 0xf);   // row_shr:2
-  SFM_DPP_STAGE(0x114, 0xf);   // row_shr:4
-  SFM_DPP_STAGE(0x118, 0xf);   // row_shr:8   -> lane 15 of every row of 16 holds the row sum
-  SFM_DPP_STAGE(0x142, 0xa);   // row_bcast:15 into rows 1 and 3
-  SFM_DPP_STAGE(0x143, 0xc);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
-#undef SFM_DPP_STAGE
+  wave_sums_lockstep(v);
   // lane 63 holds the twelve totals: it writes them (three 16-byte stores)
   if (C.lane == 63) {
     float4* o = reinterpret_cast<float4*>(gpm_out);
