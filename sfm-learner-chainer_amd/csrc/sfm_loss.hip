@@ -53,20 +53,25 @@ struct ScaleArgs {
 };
 
 struct LossArgs {
-  ScaleArgs sc[SFM_MAX_SCALES];
-  const float* pose[SFM_MAX_SRC];
-  float* d_pose[SFM_MAX_SRC];
+  // Header: what every wave of every kernel needs before anything else, in two 64-byte lines.  The argument block lives in memory
+  // the scalar cache has not seen when a launch starts; every further line a wave touches before its first data load is another
+  // round trip in front of it (0.2 - 0.7 us each: tools/trace_finalize.py), and all waves of a launch wait for it together.
+  int B, n_src, n_scales, items;
+  int simds_per_xcd;           // SIMDs of one XCD (dispatch rounds -> age rank, see loss_kernel)
+  int prio_top;                // resident waves per SIMD - 1, at most 3
+  unsigned prio_tab;           // issue priority levels: 2 bits per (phase, rank), phase = first / second half of the sources
+  float alpha;                 // ssim_rate
+  int tiles_of[SFM_MAX_SCALES];        // sc[s].tiles, 0 beyond n_scales
+  int item_begin_of[SFM_MAX_SCALES];   // sc[s].item_begin
   const float* intrinsics;
   Geom* geom;        // [B][n_scales][n_src]
   float* part_loss;  // [items][4]   pixel, ssim, smooth, exp
   float* part_gpm;   // [items][n_src][12]
-  int B, n_src, n_scales, items;
   float gy;          // upstream gradient on total_loss
-  float alpha;       // ssim_rate
   unsigned long long* trace;   // diagnostics: per item {t_start, t_end (100 MHz), HW_ID, XCC_ID}; normally nullptr
-  int simds_per_xcd;           // SIMDs of one XCD (dispatch rounds -> age rank, see loss_kernel)
-  int prio_top;                // resident waves per SIMD - 1, at most 3
-  unsigned prio_tab;           // issue priority levels: 2 bits per (phase, rank), phase = first / second half of the sources
+  const float* pose[SFM_MAX_SRC];
+  float* d_pose[SFM_MAX_SRC];
+  ScaleArgs sc[SFM_MAX_SCALES];
 };
 
 template <bool SSIM, bool GRAD, int SMODE>
@@ -292,6 +297,14 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
   // With fewer than 8 samples the items are dealt out as 8 contiguous ranges instead.  Placement only affects
   // speed, never the result (the partial sums are indexed by the item id, not by the block).
   static_assert(WAVES_PER_BLOCK == 1, "item mapping assumes one wavefront per workgroup");
+  // The header of the argument block is fetched in ONE batch of scalar loads, before anything branches on it: left to where each
+  // field is first used, the loads end up behind one another's branches -- eight dependent round trips to a cold scalar cache at the
+  // start of every wave, with the whole chip waiting.
+#ifndef SFM_NO_ARG_BATCH
+  asm volatile("" ::"s"(A.B), "s"(A.n_src), "s"(A.n_scales), "s"(A.items), "s"(A.simds_per_xcd), "s"(A.prio_top), "s"(A.prio_tab),
+               "s"(A.tiles_of[0]), "s"(A.tiles_of[1]), "s"(A.tiles_of[2]), "s"(A.tiles_of[3]), "s"(A.tiles_of[4]), "s"(A.tiles_of[5]),
+               "s"(A.tiles_of[6]), "s"(A.tiles_of[7]), "s"(A.geom), "s"(A.trace));
+#endif
   const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
   int s = 0, b, t;
   if (A.B >= 8) {
@@ -301,14 +314,17 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
 #pragma unroll
     for (int k = 0; k < SFM_MAX_SCALES; ++k) {
       if (k < A.n_scales && !found) {
-        const int cnt = nb * A.sc[k].tiles;
+        const int cnt = nb * A.tiles_of[k];
         if (rem < cnt) { s = k; found = true; }
         else rem -= cnt;
       }
     }
     if (!found) return;   // whole wavefront leaves; no block-level synchronisation anywhere in this kernel
-    const int bl = rem / A.sc[s].tiles;
-    t = rem - bl * A.sc[s].tiles;
+    int tls = A.tiles_of[0];
+#pragma unroll
+    for (int k = 1; k < SFM_MAX_SCALES; ++k) tls = (s == k) ? A.tiles_of[k] : tls;
+    const int bl = rem / tls;
+    t = rem - bl * tls;
     b = xcd + 8 * bl;
   } else {
     const int per = (int)(gridDim.x >> 3);
@@ -316,12 +332,20 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
     if (it >= A.items) return;
 #pragma unroll
     for (int k = 1; k < SFM_MAX_SCALES; ++k)
-      if (k < A.n_scales && it >= A.sc[k].item_begin) s = k;
-    const int idx = it - A.sc[s].item_begin;
-    b = idx / A.sc[s].tiles;
-    t = idx - b * A.sc[s].tiles;
+      if (k < A.n_scales && it >= A.item_begin_of[k]) s = k;
+    int tls = A.tiles_of[0], ibs = A.item_begin_of[0];
+#pragma unroll
+    for (int k = 1; k < SFM_MAX_SCALES; ++k) { tls = (s == k) ? A.tiles_of[k] : tls; ibs = (s == k) ? A.item_begin_of[k] : ibs; }
+    const int idx = it - ibs;
+    b = idx / tls;
+    t = idx - b * tls;
   }
   const ScaleArgs& S = A.sc[s];
+#ifndef SFM_NO_ARG_BATCH
+  // ... and the scale's entry in a second one
+  asm volatile("" ::"s"(S.tgt), "s"(S.src), "s"(S.disp), "s"(S.d_disp), "s"(S.h), "s"(S.w), "s"(S.strips), "s"(S.tiles), "s"(S.item_begin),
+               "s"(S.chunk_rows), "s"(S.inv_cnt), "s"(S.k_pix), "s"(S.kq));
+#endif
   const int item = S.item_begin + b * S.tiles + t;
   unsigned long long t_start = 0;
   if (A.trace) t_start = __builtin_amdgcn_s_memrealtime();
@@ -542,7 +566,7 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const Los
     // rotation (euler2mat: ~150 dependent instructions) under the shadow of the partials.
     int tl[SFM_MAX_SCALES], ib[SFM_MAX_SCALES];
 #pragma unroll
-    for (int k = 0; k < SFM_MAX_SCALES; ++k) { tl[k] = A.sc[k].tiles; ib[k] = A.sc[k].item_begin; }
+    for (int k = 0; k < SFM_MAX_SCALES; ++k) { tl[k] = A.tiles_of[k]; ib[k] = A.item_begin_of[k]; }
     const float* pp = nullptr;
     float* dp = nullptr;
 #pragma unroll
@@ -906,6 +930,8 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
     S.chunks = (h + rows[s] - 1) / rows[s];
     S.tiles = S.strips * S.chunks;
     S.item_begin = items;
+    A.tiles_of[s] = S.tiles;
+    A.item_begin_of[s] = items;
     items += d->B * S.tiles;
     const double nb = (double)d->norm_B;
     S.inv_cnt = (float)(1.0 / (nb * 3.0 * h * w));
