@@ -685,6 +685,145 @@ __global__ void pyramid_hwc_fwd_kernel(const PyramidArgs A) {
   *reinterpret_cast<Float3*>(yout[s] + ((size_t)ng * oH * oW + jj) * 3) = t;
 }
 
+// The same pyramid with every input pixel read ONCE: a workgroup owns a band of input rows of one image, brings it (plus
+// one row below) into LDS with 16-byte loads, writes the band's own rows of scale 0 (the planar -> pixel-interleaved
+// transposition) and every output row of the smaller scales whose upper tap row v0 lies in the band (then v0 + 1 is in LDS too).
+// pyramid_hwc_fwd_kernel fetches the input once per scale -- 2.75x the image in cache lines at four scales, from other XCDs' L2.
+// Per output pixel the arithmetic is that kernel's, statement by statement: the values agree bit for bit.
+struct BandArgs {
+  PyramidArgs P;
+  int band_rows;      // input rows per band (the LDS holds band_rows + 1 rows of three planes)
+  int n_bands;
+};
+
+__device__ __forceinline__ int pyr_v0(const PyramidArgs& A, const int s, const int oy) {
+#pragma clang fp contract(off)
+  const float v = (float)((double)oy * A.step_v[s]);
+  return min(max((int)floorf(v), 0), max(A.H - 2, 0));
+}
+
+template <bool PAIR, int NT>
+__global__ void __launch_bounds__(NT) pyramid_band_hwc_kernel(const BandArgs B) {
+#pragma clang fp contract(off)
+  extern __shared__ float band[];   // [3][rows_here][W]
+  const PyramidArgs& A = B.P;
+  int ng = blockIdx.y;   // n * G + g
+  const float* xin = A.x;
+  float* const* yout = A.y;
+  if (PAIR && ng >= A.n_first) { ng -= A.n_first; xin = A.x2; yout = A.y2; }   // block-uniform
+  const int H = A.H, W = A.W;
+  const size_t P = (size_t)H * W;
+  const float* img = xin + (size_t)ng * 3 * P;
+  const int r0 = blockIdx.x * B.band_rows;
+  const int own = min(B.band_rows, H - r0);             // rows of scale 0 this band writes
+  const int rows = min(B.band_rows + 1, H - r0);        // rows in LDS (one more than owned, unless the image ends)
+  const int span = rows * W;                            // floats per plane, contiguous in memory
+  const int tid = threadIdx.x;
+  // ---- load: three contiguous spans (host guarantees W % 4 == 0 and 16-byte aligned tensors for this kernel)
+  {
+    const int q4 = span >> 2;
+    const float4* g[3];
+    float4* l[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      g[c] = reinterpret_cast<const float4*>(img + c * P + (size_t)r0 * W);
+      l[c] = reinterpret_cast<float4*>(band + c * span);
+    }
+    // (a plain copy loop: each 16 bytes are waited for before the next load goes out.  With 1, 2, 4 float4 per plane in flight per
+    //  thread the pair at B=32 takes 31.8 / 43.1 / 48.7 us against 29.4 for this loop -- a workgroup that loads its band in one burst
+    //  and then stores in one burst does worse than twelve waves per CU trickling; 256 threads: 128 / 512 / 1024 give 34.4 / 30.5 / 37.8)
+    for (int q = tid; q < q4; q += NT) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) l[c][q] = g[c][q];
+    }
+  }
+  __syncthreads();
+  // ---- scale 0: own * W texels of 12 bytes, contiguous in the output; 16-byte stores whose addresses run across the lanes
+  {
+    float4* o = reinterpret_cast<float4*>(yout[0] + ((size_t)ng * P + (size_t)r0 * W) * 3);
+    const int n4 = own * W * 3 / 4;                     // W % 4 == 0
+    for (int q = tid; q < n4; q += NT) {
+      const int e = q * 4;                              // element e = 3 * pixel + channel
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int px = (e + k) / 3, c = (e + k) - 3 * px;
+        v[k] = band[c * span + px];
+      }
+      o[q] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+  // ---- smaller scales: the output rows whose upper tap row lies in [r0, r0 + band_rows)
+  for (int s = 1; s < A.n_scales; ++s) {
+    const int oW = A.oW[s], oH = A.oH[s];
+    // v0(oy) is monotone in oy: first row with v0 >= r0 and first row with v0 >= r0 + band_rows, found from an estimate
+    int lo, hi;
+    {
+      const double sv = A.step_v[s];
+      int e = sv > 0.0 ? (int)((double)r0 / sv) : 0;
+      e = min(max(e - 2, 0), oH);
+      while (e > 0 && pyr_v0(A, s, e - 1) >= r0) --e;    // (never taken for a down-scaling step; keeps the search exact for any step)
+      while (e < oH && pyr_v0(A, s, e) < r0) ++e;
+      lo = e;
+      e = sv > 0.0 ? (int)((double)(r0 + B.band_rows) / sv) : oH;
+      e = min(max(e - 2, lo), oH);
+      while (e > lo && pyr_v0(A, s, e - 1) >= r0 + B.band_rows) --e;
+      while (e < oH && pyr_v0(A, s, e) < r0 + B.band_rows) ++e;
+      hi = e;
+    }
+    const int cnt = (hi - lo) * oW;
+    for (int idx = tid; idx < cnt; idx += NT) {
+      const int dy = idx / oW, ox = idx - dy * oW, oy = lo + dy;
+      const float u = (float)((double)ox * A.step_u[s]);
+      const float v = (float)((double)oy * A.step_v[s]);
+      const int u0 = min(max((int)floorf(u), 0), max(W - 2, 0)), v0 = min(max((int)floorf(v), 0), max(H - 2, 0));
+      const int v1 = min(v0 + 1, H - 1);
+      const float wu1 = u - (float)u0, wv1 = v - (float)v0;
+      const float wu0 = 1.0f - wu1, wv0 = 1.0f - wv1;
+      Float3 t;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float* pl = band + c * span;
+        const float a0 = pl[(v0 - r0) * W + u0], a1 = pl[(v0 - r0) * W + u0 + 1];     // (W >= 2 for this kernel: u1 = u0 + 1)
+        const float b0 = pl[(v1 - r0) * W + u0], b1 = pl[(v1 - r0) * W + u0 + 1];
+        const float top = a0 * wu0 + a1 * wu1;
+        const float bot = b0 * wu0 + b1 * wu1;
+        t.c[c] = top * wv0 + bot * wv1;
+      }
+      *reinterpret_cast<Float3*>(yout[s] + ((size_t)ng * oH * oW + (size_t)oy * oW + ox) * 3) = t;
+    }
+  }
+}
+
+// Launches the band kernel when its preconditions hold (returns false otherwise: the caller uses the per-pixel kernel).
+template <bool PAIR>
+static bool launch_pyramid_band(const PyramidArgs& A, int images, hipStream_t st) {
+  const int H = A.H, W = A.W;
+  if (getenv("SFM_PYRAMID_PER_PIXEL")) return false;                      // A/B switch
+  if (H < 2 || W < 4 || (W & 3)) return false;
+  uintptr_t al = (uintptr_t)A.x | (uintptr_t)A.y[0];
+  if (PAIR) al |= (uintptr_t)A.x2 | (uintptr_t)A.y2[0];
+  if (al & 15) return false;
+  const int lds_budget = 48 * 1024;                                        // three workgroups per CU
+  int band_rows = lds_budget / (12 * W) - 1;
+  if (band_rows < 1) return false;
+  if (band_rows > 8) band_rows = 8;
+  if (const char* e = getenv("SFM_PYRAMID_BAND_ROWS")) {                   // tuning: rows per band (LDS permitting)
+    const int v = atoi(e);
+    if (v >= 1 && (size_t)3 * (v + 1) * W * sizeof(float) <= 64 * 1024) band_rows = v;
+  }
+  BandArgs B;
+  B.P = A;
+  B.band_rows = band_rows;
+  B.n_bands = (H + band_rows - 1) / band_rows;
+  const size_t lds = (size_t)3 * (band_rows + 1) * W * sizeof(float);
+  int nt = 256;
+  if (const char* e = getenv("SFM_PYRAMID_THREADS")) nt = atoi(e);       // tuning
+  if (nt == 512) hipLaunchKernelGGL((pyramid_band_hwc_kernel<PAIR, 512>), dim3(B.n_bands, images), dim3(512), lds, st, B);
+  else hipLaunchKernelGGL((pyramid_band_hwc_kernel<PAIR, 256>), dim3(B.n_bands, images), dim3(256), lds, st, B);
+  return true;
+}
+
 // ------------------------------------------------------------------------------------------
 // data_augmentation (datasets/kitti/kitti_raw_transformed.py:23-74) as one gather: random scaling
 // (F.resize_images to (int(H*ys), int(W*xs)), :32-45), random crop back to (H, W) at (oy, ox) (:48-59)
@@ -941,7 +1080,8 @@ int sfm_pyramid_hwc_fwd(const float* x, float* const* y, int N, int G, int H, in
   A.quads0 = A.begin[1];
   pyramid_steps(A);
   const int total = A.begin[n_scales];
-  hipLaunchKernelGGL(pyramid_hwc_fwd_kernel<false>, dim3((total + 255) / 256, N * G), dim3(256), 0, (hipStream_t)stream, A);
+  if (!launch_pyramid_band<false>(A, N * G, (hipStream_t)stream))
+    hipLaunchKernelGGL(pyramid_hwc_fwd_kernel<false>, dim3((total + 255) / 256, N * G), dim3(256), 0, (hipStream_t)stream, A);
   return check_launch("sfm_pyramid_hwc_fwd");
 }
 
@@ -969,7 +1109,8 @@ int sfm_pyramid_pair_hwc_fwd(const float* tgt, const float* src, float* const* y
   A.quads0 = A.begin[1];
   pyramid_steps(A);
   const int total = A.begin[n_scales];
-  hipLaunchKernelGGL(pyramid_hwc_fwd_kernel<true>, dim3((total + 255) / 256, N * (1 + n_src)), dim3(256), 0, (hipStream_t)stream, A);
+  if (!launch_pyramid_band<true>(A, N * (1 + n_src), (hipStream_t)stream))
+    hipLaunchKernelGGL(pyramid_hwc_fwd_kernel<true>, dim3((total + 255) / 256, N * (1 + n_src)), dim3(256), 0, (hipStream_t)stream, A);
   return check_launch("sfm_pyramid_pair_hwc_fwd");
 }
 

@@ -190,7 +190,11 @@ def test_pyramid_matches_oracle_resizes(ops, dev, shape, n_scales):
         np.testing.assert_array_equal(to_np(outs[s]), to_np(ops.resize(to_dev(x, dev), (H >> s, W >> s))))
 
 
-@pytest.mark.parametrize("shape,n_scales", [((2, 3, 32, 48), 4), ((3, 6, 37, 70), 3), ((1, 12, 128, 416), 4), ((2, 3, 9, 11), 1)])
+@pytest.mark.parametrize("shape,n_scales", [((2, 3, 32, 48), 4), ((3, 6, 37, 70), 3), ((1, 12, 128, 416), 4), ((2, 3, 9, 11), 1),
+                                            # the band kernel (W % 4 == 0): bands of 3 rows at W = 832, a ragged last band, the two-row image,
+                                            # a tall narrow one, and a row too long for the band's LDS (per-pixel kernel)
+                                            ((1, 6, 256, 832), 4), ((2, 3, 37, 72), 3), ((1, 3, 2, 8), 1), ((1, 3, 131, 20), 3),
+                                            ((1, 3, 16, 4096), 2)])
 def test_pyramid_hwc_is_the_planar_pyramid_interleaved(ops, dev, shape, n_scales):
     """sfm_pyramid_hwc_fwd: the values of sfm_pyramid_fwd (bit for bit), laid out (N,G,h,w,3), scale 0 included"""
     rng = np.random.RandomState(6)
@@ -218,6 +222,23 @@ def test_pyramid_pair_is_the_two_pyramids_in_one_launch(ops, dev, N, n_src, H, W
     with pytest.raises(TypeError):
         import torch
         ops.pyramid_pair_hwc(torch.cat([tgt, tgt], 1), src, n_scales)        # the target is one image
+
+
+def test_band_and_per_pixel_pyramid_kernels_agree_bitwise(ops, dev):
+    """The band kernel (every input pixel read once, through LDS) and the per-pixel kernel it replaces for aligned shapes
+    (SFM_PYRAMID_PER_PIXEL=1 selects it; read at every launch) compute every output pixel with the same statements."""
+    import os
+    rng = np.random.RandomState(8)
+    tgt = to_dev(rng.uniform(-1, 1, size=(3, 3, 128, 416)).astype(np.float32), dev)
+    src = to_dev(rng.uniform(-1, 1, size=(3, 6, 128, 416)).astype(np.float32), dev)
+    band = [to_np(a).copy() for pyr in ops.pyramid_pair_hwc(tgt, src, 4) for a in pyr]
+    os.environ["SFM_PYRAMID_PER_PIXEL"] = "1"
+    try:
+        per_pixel = [to_np(a).copy() for pyr in ops.pyramid_pair_hwc(tgt, src, 4) for a in pyr]
+    finally:
+        del os.environ["SFM_PYRAMID_PER_PIXEL"]
+    for a, b in zip(band, per_pixel):
+        np.testing.assert_array_equal(a, b)
 
 
 def test_type_checks(ops, dev):
