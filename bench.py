@@ -50,6 +50,8 @@ WORKLOADS = {
              "BASELINE cfg1: B=1, 128x416, 1 scale, 2 src, L1 only (the CPU baseline's workload)"),
     "cfg2": (8, 128, 416, 2, 4, dict(smooth_reg=0.1),
              "BASELINE cfg2: B=8, 128x416, 4 scales, 2 src, L1 + smoothness"),
+    "l1_b32": (32, 128, 416, 2, 4, dict(smooth_reg=0.1),
+               "cfg2's loss (L1 + smoothness) at B=32: the L1 kernels at full occupancy (development: tools/ab_inproc.py)"),
     "cfg3_edge": (32, 128, 416, 2, 4, dict(smooth_reg=0.1, ssim_rate=0.15, smooth_mode="edge_aware"),
                   "BASELINE cfg3 as written: B=32/GPU, 128x416, 4 scales, 2 src, L1+SSIM(0.15)+EDGE-AWARE smoothness(0.1) (base_model.py:144-155)"),
     "cfg5": (8, 256, 832, 4, 4, dict(smooth_reg=0.1, ssim_rate=0.15),

@@ -284,8 +284,12 @@ __device__ __forceinline__ void set_issue_prio(const int p) {   // s_setprio tak
   else __builtin_amdgcn_s_setprio(3);
 }
 
+// WIDE: the L1 gradient kernels compiled a second time for three waves per SIMD (168 registers instead of 128).  A small launch
+// (BASELINE cfg1 / cfg2: fewer waves than three rounds of SIMDs even at the smallest chunk height) is bound by how fast ONE wave
+// gets through its instructions, not by how many waves a SIMD holds: cfg2's kernel 14.3 -> 13.4 us.  At B = 32 the same build is
+// 8.7 % slower than the four-wave one (profiles/r03_ab_small_kernels.txt), so the plan picks per launch (Plan::wide).
 template <bool SSIM, bool GRAD, bool LOSS, bool EXPL, int SMODE, bool HWC>
-__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) loss_kernel(const LossArgs A) {
+__device__ __forceinline__ void loss_body(const LossArgs& A) {
   using HH = Halo<SSIM, GRAD, SMODE>;
   __shared__ float gacc_all[GRAD ? WAVES_PER_BLOCK * MAX_CHUNK_ROWS * 64 : 64];
   const int wave = threadIdx.x >> 6;
@@ -503,11 +507,11 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
     o[2] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
     o[3] = (__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) & 0xf) | ((unsigned long long)blockIdx.x << 8);   // HW_REG_XCC_ID, workgroup
 #ifdef SFM_STAMPS
-    if constexpr (SSIM) {
+    {
       unsigned long long* q = A.trace + (size_t)A.items * 4 + (size_t)item * 8;
       unsigned long long ts3 = 0;
       SFM_STAMP(ts3);
-      q[0] = st.a_fin; q[1] = st.a_iss; q[2] = st.b; q[3] = st.c; q[4] = st.steps;
+      q[0] = st.a_fin; q[1] = st.a_iss; q[2] = st.b; q[3] = st.c; q[4] = st.steps > 0 ? st.steps : 1;   // (the L1 passes carry no per-stage stamps)
       q[5] = cyc_smooth;   // the smoothness pass
       q[6] = cyc_src;      // the source passes, everything included (context set-up, prologue, row loop, pose sums)
       q[7] = ts3 - ts0;    // the whole wave in shader cycles (start-up and d_disp write-out = the rest)
@@ -524,6 +528,16 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) 
       o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3;
     }
   }
+}
+
+template <bool SSIM, bool GRAD, bool LOSS, bool EXPL, int SMODE, bool HWC>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) loss_kernel(const LossArgs A) {
+  loss_body<SSIM, GRAD, LOSS, EXPL, SMODE, HWC>(A);
+}
+// (WIDE, see above: L1 gradient kernels only)
+template <bool LOSS, int SMODE, bool HWC>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 3) loss_kernel_wide(const LossArgs A) {
+  loss_body<false, true, LOSS, false, SMODE, HWC>(A);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -732,6 +746,7 @@ struct Plan {
   LossArgs args;
   size_t off_geom, off_loss, off_gpm, total;
   bool ssim, expl, hwc;
+  bool wide;     // the three-waves-per-SIMD build of an L1 gradient kernel (see loss_kernel)
   int smode;
 };
 
@@ -750,7 +765,7 @@ static thread_local unsigned long long* g_trace = nullptr;   // sfm_loss_debug_t
 // and the 32-waves-per-CU cap allow more) and from the CU count of the device -- no occupancy query, nothing
 // that differs between a CPU-only host and the GPU box.
 template <bool GRAD, bool LOSS>
-static const void* kernel_ptr(bool ssim, bool expl, int smode, bool hwc);
+static const void* kernel_ptr(bool ssim, bool expl, int smode, bool hwc, bool wide);
 
 constexpr int MI355X_CUS = 256;   // 8 XCDs x 32 CUs (MI355X_MICROARCH.md); used when no device is visible
 
@@ -766,7 +781,7 @@ static int device_cus() {
   return cus_of[dev];
 }
 
-static int waves_per_simd_of(bool ssim, bool grad) { return (ssim && grad) ? 3 : 4; }   // = __launch_bounds__ of loss_kernel
+static int waves_per_simd_of(bool ssim, bool grad, bool wide) { return ((ssim && grad) || wide) ? 3 : 4; }   // = __launch_bounds__ of loss_kernel
 
 // tuning overrides (development only), read from the environment ONCE per process
 struct Tuning {
@@ -892,7 +907,9 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
   for (int s = 0; s < d->n_scales; ++s)
     if (d->H[s] < 3 || d->W[s] < 3) return fail(SFM_ERR_SHAPE, "sfm_loss: scale %d is %dx%d, need H,W >= 3", s, d->H[s], d->W[s]);
   const int cus = device_cus();
-  const int waves_per_simd = waves_per_simd_of(p.ssim, grad);
+  // (a launch is "small" when even at the smallest chunk height its waves fit the SIMDs three deep)
+  p.wide = grad && !p.ssim && !p.expl && !getenv("SFM_NO_WIDE") && max_items(d, sw) <= (long long)cus * 4 * 3;
+  const int waves_per_simd = waves_per_simd_of(p.ssim, grad, p.wide);
   const int slots = cus * 4 * waves_per_simd;
   A.simds_per_xcd = (cus % 8 == 0) ? cus / 8 * 4 : 128;   // gfx950: 8 XCDs, 4 SIMDs per CU
   A.prio_top = waves_per_simd - 1 < 3 ? waves_per_simd - 1 : 3;
@@ -975,7 +992,14 @@ static void bind_workspace(Plan& p, void* ws) {
 }
 
 template <bool GRAD, bool LOSS>
-static const void* kernel_ptr(bool ssim, bool expl, int smode, bool hwc) {
+static const void* kernel_ptr(bool ssim, bool expl, int smode, bool hwc, bool wide) {
+  if (GRAD && wide && !ssim && !expl) {
+#define SFM_KWIDE(SM) return hwc ? (const void*)&loss_kernel_wide<LOSS, SM, true> : (const void*)&loss_kernel_wide<LOSS, SM, false>
+    if (smode == 0) SFM_KWIDE(0);
+    else if (smode == 1) SFM_KWIDE(1);
+    else SFM_KWIDE(2);
+#undef SFM_KWIDE
+  }
 #define SFM_KPTR(SS, EX, SM) return hwc ? (const void*)&loss_kernel<SS, GRAD, LOSS, EX, SM, true> : (const void*)&loss_kernel<SS, GRAD, LOSS, EX, SM, false>
   if (expl) {
     if (smode == 0) SFM_KPTR(false, true, 0);
@@ -1001,7 +1025,7 @@ static hipError_t launch_main(const Plan& p, hipStream_t st, hipEvent_t ev_start
   int tiles_per_sample = 0;
   for (int s = 0; s < p.args.n_scales; ++s) tiles_per_sample += p.args.sc[s].tiles;
   const int per_xcd = p.args.B >= 8 ? ((p.args.B + 7) / 8) * tiles_per_sample : (p.args.items + 7) / 8;
-  const void* fn = kernel_ptr<GRAD, LOSS>(p.ssim, p.expl, p.smode, p.hwc);
+  const void* fn = kernel_ptr<GRAD, LOSS>(p.ssim, p.expl, p.smode, p.hwc, p.wide);
   // With profiling events the kernel is launched through hipExtLaunchKernel: the events then carry the begin / end
   // timestamps of THIS dispatch (what rocprofv3's kernel trace reports), and no marker packets are put between the
   // launches of a step (hipEventRecord on either side of the kernel costs the step several microseconds).

@@ -15,7 +15,7 @@ if os.environ.get("SFM_TRACE_ZERO"):   # DVFS probe (MI355X_MICROARCH.md, DVFS g
         d[k] = [np.zeros_like(a) for a in d[k]]
 layout = os.environ.get("SFM_LAYOUT", "hwc")
 cv = (lambda a: ops.to_hwc(t(a))) if layout == "hwc" else t
-fl = ops.FusedLoss(smooth_reg=0.1, ssim_rate=0.15, smooth_mode=os.environ.get("SFM_TRACE_SMOOTH", "second_order")).bind([cv(a) for a in d["tgt_pyr"]], [cv(a) for a in d["src_pyr"]], t(d["intrinsics"]),
+fl = ops.FusedLoss(smooth_reg=0.1, ssim_rate=float(os.environ.get("SFM_TRACE_SSIM_RATE", "0.15")), smooth_mode=os.environ.get("SFM_TRACE_SMOOTH", "second_order")).bind([cv(a) for a in d["tgt_pyr"]], [cv(a) for a in d["src_pyr"]], t(d["intrinsics"]),
                                                         [t(a) for a in d["disps"]], [t(a) for a in d["poses"]], layout=layout)
 run = {"fused": fl.forward_backward, "fwd": fl.forward, "bwd": lambda: fl.backward(1.0)}[mode]
 for _ in range(5): run()
