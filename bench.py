@@ -365,6 +365,11 @@ def profile_facts(workload, layout, mode, kernel_name):
         try:
             summ = json.load(open(os.path.join(ROOT, "profiles", "%s_summary.json" % tag)))
             var = summ["variants"]["%s_%s_%s" % (workload, layout, mode)]
+            if kernel_name not in var["kernels"]:        # a small launch of an L1 gradient kernel runs its three-waves-per-SIMD build
+                mw = re.match(r"void sfm::loss_kernel<false, true, (\w+), false, (\d), (\w+)>", kernel_name)
+                wide = "void sfm::loss_kernel_wide<%s, %s, %s>(sfm::LossArgs)" % mw.groups() if mw else None
+                if wide in var["kernels"]:
+                    kernel_name = wide
             kv = var["kernels"][kernel_name]
             out.update(tag=tag, counters=kv.get("counters_per_launch"), traffic_raw=kv.get("hbm_bytes_raw"), traffic_x2=kv.get("hbm_bytes_fetch_x2"),
                        rocprof_avg_ns=kv.get("avg_ns"))

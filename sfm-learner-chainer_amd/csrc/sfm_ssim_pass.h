@@ -174,8 +174,9 @@ __device__ __forceinline__ float vhadd(float v) { return v; }
 
 struct RowS {            // a warped row as the later stages need it (per lane = per pixel)
   Ch3 ih, it;            // I^ (0 where not in view / outside the image), I (0 outside the image)
-  f2 dup, dvp;           // dI^/du, dI^/dv of channels 0, 1 (of whatever the tap registers held where the sample is not in view: rzi masks them)
-  f2 duv_s;              // (dI^/du, dI^/dv) of channel 2: paired, so that the contraction to dL/d(u,v) ends in packed instructions
+  f2 duv0, duv1, duv_s;  // (dI^/du, dI^/dv) of channels 0, 1, 2 (of whatever the tap registers held where the sample is not in view: rzi
+                         // masks them): one register pair per channel, so that the contraction to dL/d(u,v) is three packed
+                         // multiply-adds with the channel's dL/dI^ broadcast -- no horizontal adds, no register shuffles
   f2 UV;                 // q0/z, q1/z: one register pair, so that everything per-coordinate is one packed instruction
   float D;               // depth
   float rzi;             // 1/z where the sample is in view AND the lane is an output lane, else 0: the factor that takes
@@ -196,7 +197,7 @@ struct Pipe {            // a row whose gathers are in flight
 };
 
 __device__ __forceinline__ void zero(RowS& s) {
-  s.ih = s.it = ch3_zero(); s.dup = s.dvp = s.duv_s = T_of<f2>(0.f);
+  s.ih = s.it = ch3_zero(); s.duv0 = s.duv1 = s.duv_s = T_of<f2>(0.f);
   s.UV = T_of<f2>(0.f); s.D = s.rzi = s.nm = 0.f;
 }
 __device__ __forceinline__ void zero(RowG& s) { s.a = s.b = s.e = ch3_zero(); }
@@ -215,7 +216,7 @@ __device__ __forceinline__ Ch3 ch3_opaque_zero() {
 }
 __device__ __forceinline__ void zero_rare(RowS& s) {
   s.ih = ch3_opaque_zero(); s.it = ch3_opaque_zero();
-  s.dup.x = opaque_zero(); s.dup.y = opaque_zero(); s.dvp.x = opaque_zero(); s.dvp.y = opaque_zero(); s.duv_s.x = opaque_zero(); s.duv_s.y = opaque_zero();
+  s.duv0.x = opaque_zero(); s.duv0.y = opaque_zero(); s.duv1.x = opaque_zero(); s.duv1.y = opaque_zero(); s.duv_s.x = opaque_zero(); s.duv_s.y = opaque_zero();
   s.UV.x = opaque_zero(); s.UV.y = opaque_zero(); s.D = opaque_zero(); s.rzi = opaque_zero(); s.nm = opaque_zero();
 }
 
@@ -335,7 +336,7 @@ __device__ __forceinline__ void finish_row(const SsimCtx& C, const Pipe& ps, Row
   }
   s.ih = ch3(ih[0], ih[1], ih[2]);
   s.it = ch3(it[0], it[1], it[2]);
-  s.dup.x = du[0]; s.dup.y = du[1]; s.dvp.x = dv[0]; s.dvp.y = dv[1];
+  s.duv0.x = du[0]; s.duv0.y = dv[0]; s.duv1.x = du[1]; s.duv1.y = dv[1];
   s.duv_s.x = du[2]; s.duv_s.y = dv[2];
   s.UV = ps.UV; s.D = ps.D;
   s.rzi = ps.inview_o ? ps.rz : 0.f;   // halo lanes get no gradient of their own
@@ -368,7 +369,10 @@ __device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& 
   // V are homogeneous of degree 0 in q (with z = q2 + 1e-10 it is (gq0 U + gq1 V) 1e-10: ten orders below gq . P3), so
   // gD = -(gq . P3) / D and dL/d(disp) = -gD D^2 (depth = 1/disp, base_model.py:60) = (gq . P3) D: three products with
   // wave-uniform factors instead of rebuilding the ray -- and without the cancellation of a0 - U a2 for small translations.
-  const float gdisp = fmaf(gq.x, C.P3[0], fmaf(gq.y, C.P3[1], gq2 * C.P3[2])) * s2.D;
+  // (with t = gq D, which the pose sums below need anyway: three products, the factor D is already inside)
+  const f2 t = gq * s2.D;
+  const float t2 = gq2 * s2.D;
+  const float gdisp = fmaf(t.x, C.P3[0], fmaf(t.y, C.P3[1], t2 * C.P3[2]));
   float* ga = gacc + (rc - C.y0) * 64 + C.lane;
   // the tile is private to this wave: a plain store for the first contribution, then read-add-write through a register
   // (an LDS add without return value, ds_add_f32, has nothing to wait for but costs the launch 3 % at cfg3: it is a slow LDS op)
@@ -377,8 +381,6 @@ __device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& 
   // dL/dPm[k][j] = sum over pixels of gq_k * c_j with c = D * (K1 y + kx) (the back-projected point), c_3 = 1.  The ray
   // is linear in the row, so a lane only accumulates  A_k = sum gq_k D,  B_k = sum y gq_k D,  C_k = sum gq_k  (9 values
   // instead of 12) and expands them once per pass: gpm[k][j] = K1[j] B_k + kx[j] A_k, K1 = Kinv[:,1], kx = Kinv[:,0] x + Kinv[:,2]   (pose_sums_expand)
-  const f2 t = gq * s2.D;
-  const float t2 = gq2 * s2.D;
   gpm.A += t; gpm.A2 += t2;
   gpm.B = vfma(T_of<f2>(yf), t, gpm.B); gpm.B2 = fmaf(yf, t2, gpm.B2);
   gpm.Cq += gq; gpm.C2 += gq2;
@@ -495,15 +497,16 @@ __device__ __forceinline__ void ssim_value_partials(const SsimSums<T>& p, const 
 // term (the contraction with dI^/du, dI^/dv and 1/z follows for all channels together: contract_uv)
 template <typename T>
 __device__ __forceinline__ void ssim_stage_c(const T a2, const T a1, const T a0, const T b2, const T b1, const T b0, const T e2,
-                                             const T e1, const T e0, const T ih, const T it, const float kpn, T& g) {
+                                             const T e1, const T e0, const T ih, const T it, const float kpn, T& g, T& diff) {
   const T Aq = a2 + a1 + a0, Bq = b2 + b1 + b0, Eq = e2 + e1 + e0;
+  diff = ih - it;
   // dL/dI^ = A + 2 I^ B + I E in the partials' own scaling (ssim_value_partials): A + 9 (I E' - I^ B')
-  g = add_ksign(vfma(vfma(it, Eq, -(ih * Bq)), T_of<T>(9.f), Aq), kpn, ih - it);
+  g = add_ksign(vfma(vfma(it, Eq, -(ih * Bq)), T_of<T>(9.f), Aq), kpn, diff);
 }
 
 // Stage B at centre row rb (rows rb-1, rb, rb+1 in s2, s1, s0): SSIM value and, with GRAD, the horizontal 3-sums of its
 // partials into g0.  `count` = whether the row's loss terms belong to this wave (a halo row gets weight 0 -- branch-free: a
-// branch here would split the block and un-fold the DPP adds).
+// branch here splits the block and un-folds the DPP adds into moves + adds: 232 -> 249 vector instructions per step).
 template <bool GRAD, bool LOSS>
 __device__ __forceinline__ void ssim_stage_b_row(const SsimCtx& C, const RowS& s2, const RowS& s1, const RowS& s0, RowG& g0,
                                                  const bool count, float& acc_pix, float& acc_ssim) {
@@ -522,28 +525,48 @@ __device__ __forceinline__ void ssim_stage_b_row(const SsimCtx& C, const RowS& s
   if (LOSS) {
     const float wgt = count ? s1.nm * C.outf : 0.f;
     acc_ssim = fmaf(ssum, wgt, acc_ssim);                            // base_model.py:114-115
-    const float e1 = vabs_sum(s1.ih.p - s1.it.p) + vabs_sum(s1.ih.s - s1.it.s);   // :95
-    acc_pix = fmaf(e1, wgt, acc_pix);                                // :98-100,:111
+#ifndef SFM_L1_LOSS_IN_B
+    if (!GRAD)                                                       // (with gradients stage C adds this term: it forms I^ - I anyway)
+#endif
+    {
+      const float e1 = vabs_sum(s1.ih.p - s1.it.p) + vabs_sum(s1.ih.s - s1.it.s);   // :95
+      acc_pix = fmaf(e1, wgt, acc_pix);                              // :98-100,:111
+    }
   }
 }
 
 // dL/dI^ of the three channels (gp: channels 0, 1; gs: channel 2) contracted with dI^/du, dI^/dv and 1/z: (dL/dq0, dL/dq1) as a pair
 __device__ __forceinline__ f2 contract_uv(const RowS& s, const f2 gp, const float gs) {
-  const f2 pu = gp * s.dup, pv = gp * s.dvp;
+#ifdef SFM_CONTRACT_HADD   // the round-2 form: channels 0, 1 as a pair against (du0, du1) and (dv0, dv1), then two horizontal adds
+  f2 dup, dvp;
+  dup.x = s.duv0.x; dup.y = s.duv1.x; dvp.x = s.duv0.y; dvp.y = s.duv1.y;
+  const f2 pu = gp * dup, pv = gp * dvp;
   f2 hq;
   hq.x = pu.x + pu.y; hq.y = pv.x + pv.y;
   return vfma(T_of<f2>(gs), s.duv_s, hq) * s.rzi;
+#else
+  f2 hq = T_of<f2>(gp.x) * s.duv0;
+  hq = vfma(T_of<f2>(gp.y), s.duv1, hq);
+  hq = vfma(T_of<f2>(gs), s.duv_s, hq);
+  return hq * s.rzi;
+#endif
 }
 
 // Stage C at row rc (the row in s2; partials of the rows rc-1, rc, rc+1 in g2, g1, g0): dL/dI^ -> dL/d(u,v) -> dL/dq -> d_depth
 // tile and the sums of dL/dPm.
+template <bool LOSS>
 __device__ __forceinline__ void ssim_stage_c_row(const SsimCtx& C, const int rc, const RowS& s2, const RowG& g2, const RowG& g1,
-                                                 const RowG& g0, float* gacc, const bool first, PoseAcc& gpm) {
+                                                 const RowG& g0, float* gacc, const bool first, PoseAcc& gpm, float& acc_pix) {
   const float kpn = C.k_pix * s2.nm;
-  f2 gp;
-  float gs;
-  ssim_stage_c(g2.a.p, g1.a.p, g0.a.p, g2.b.p, g1.b.p, g0.b.p, g2.e.p, g1.e.p, g0.e.p, s2.ih.p, s2.it.p, kpn, gp);
-  ssim_stage_c(g2.a.s, g1.a.s, g0.a.s, g2.b.s, g1.b.s, g0.b.s, g2.e.s, g1.e.s, g0.e.s, s2.ih.s, s2.it.s, kpn, gs);
+  f2 gp, dp;
+  float gs, ds;
+  ssim_stage_c(g2.a.p, g1.a.p, g0.a.p, g2.b.p, g1.b.p, g0.b.p, g2.e.p, g1.e.p, g0.e.p, s2.ih.p, s2.it.p, kpn, gp, dp);
+  ssim_stage_c(g2.a.s, g1.a.s, g0.a.s, g2.b.s, g1.b.s, g0.b.s, g2.e.s, g1.e.s, g0.e.s, s2.ih.s, s2.it.s, kpn, gs, ds);
+#ifndef SFM_L1_LOSS_IN_B
+  // the L1 term of this row (base_model.py:95-100,:111): stage C runs on exactly the rows whose loss terms belong to this wave,
+  // and I^ - I is at hand (with the fused kernel stage B would form it a second time, one row earlier)
+  if (LOSS) acc_pix = fmaf(vabs_sum(dp) + vabs_sum(ds), s2.nm * C.outf, acc_pix);
+#endif
   const float gI[3] = {gp.x, gp.y, gs};
   geometry_backward(C, s2, rc, contract_uv(s2, gp, gs), gI, gacc, first, gpm);
 }
@@ -614,7 +637,7 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const StepMasks&
 #else
     if (step_bit(M.c, k)) {
 #endif
-      ssim_stage_c_row(C, r - 2, s2, g2, g1, g0, gacc, first, gpm);
+      ssim_stage_c_row<LOSS>(C, r - 2, s2, g2, g1, g0, gacc, first, gpm, acc_pix);
     }
   }
   SFM_STAMP(t4);

@@ -78,14 +78,19 @@ def main():
     subprocess.check_call(["/opt/rocm/bin/hipcc"] + [f for f in flags if f != "-fPIC"] + ["-S", "--cuda-device-only", "sfm_loss.hip", "-o", asm],
                           cwd=CSRC, stderr=subprocess.DEVNULL)
     lines = open(asm).read().split("\n")
-    starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN3sfm11loss_kernel.*:", l)]
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN3sfm(11loss_kernel|16loss_kernel_wide)I.*:", l)]
     out = {"tag": tag, "kernels": {}}
     for n, st in enumerate(starts):
         name = lines[st].split(":")[0]
         m = re.match(r"_ZN3sfm11loss_kernelILb(\d)ELb(\d)ELb(\d)ELb(\d)ELi(\d)ELb(\d)EEE", name)
-        ssim, grad, loss, expl, smode, hwc = [int(v) for v in m.groups()]
+        wide = m is None
+        if wide:      # loss_kernel_wide<LOSS, SMODE, HWC>: the L1 gradient kernels built for three waves per SIMD
+            mw = re.match(r"_ZN3sfm16loss_kernel_wideILb(\d)ELi(\d)ELb(\d)EEE", name)
+            ssim, grad, loss, expl, smode, hwc = 0, 1, int(mw.group(1)), 0, int(mw.group(2)), int(mw.group(3))
+        else:
+            ssim, grad, loss, expl, smode, hwc = [int(v) for v in m.groups()]
         body = lines[st:(starts[n + 1] if n + 1 < len(starts) else len(lines))]
-        waves = 3 if (ssim and grad) else 4
+        waves = 3 if ((ssim and grad) or wide) else 4
         costs, src = op_costs(waves)
         # basic blocks with their innermost-loop annotation
         blocks, cur = [], None
@@ -127,6 +132,8 @@ def main():
         steps = 3.0 if ssim else 1.0                       # the SSIM pass instantiates the row step three times (ring rotation)
         full = "void sfm::loss_kernel<%s>(sfm::LossArgs)" % ", ".join(
             [("true" if v else "false") for v in (ssim, grad, loss, expl)] + [str(smode), "true" if hwc else "false"])
+        if wide:
+            full = "void sfm::loss_kernel_wide<%s, %d, %s>(sfm::LossArgs)" % ("true" if loss else "false", smode, "true" if hwc else "false")
         out["kernels"][full] = {
             "waves_per_simd": waves, "valu_per_row_step": round(n_valu / steps, 1), "issue_cycles_per_row_step": round(cyc / steps, 1),
             "mean_issue_cycles_per_valu": round(cyc / max(n_valu, 1), 4),

@@ -55,6 +55,9 @@ def summarize(raw, variant):
             t["hbm_bytes_fetch_x2"] = (2 * fetch_kb + write_kb) * 1024
         m = re.search(r"loss_kernel<(\w+), (\w+), (\w+)", k)     # <SSIM, GRAD, LOSS, ...>: fused = 28 + 32 B per warped px
         grad, loss = (m.group(2) == "true", m.group(3) == "true") if m else (True, True)
+        mw = re.search(r"loss_kernel_wide<(\w+)", k)             # <LOSS, SMODE, HWC>: the L1 gradient kernels' build for small launches
+        if mw:
+            grad, loss = True, mw.group(1) == "true"
         t["entry_point"] = "sfm_loss_fwd_bwd" if (grad and loss) else ("sfm_loss_bwd" if grad else "sfm_loss_fwd")
         t["algorithmic_bytes"] = ((28 if loss else 0) + (32 if grad else 0)) * px
         if k in summary["kernels"] and "avg_ns" in summary["kernels"][k]:
