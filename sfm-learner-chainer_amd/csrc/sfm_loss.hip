@@ -475,6 +475,8 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
     C.disp_first = disp_first;
     C.disp_second = disp_second;
     C.xc12 = 12u * C.xc;
+    C.x12 = 12u * (unsigned)x;
+    C.img12 = 12u * (unsigned)h * (unsigned)w;
     C.w12 = 12u * (unsigned)w;
     C.w12f = (float)(12 * w);
     C.xin = xin;

@@ -58,6 +58,8 @@ struct SsimCtx {
   float disp_first, disp_second;   // disparity of the first row a pass fetches (row y0 - halo, clamped into the image) and of the next
   unsigned xc;          // column, clamped into the image (address-safe for halo lanes)
   unsigned xc12;        // 12 xc: byte offset of the lane's texel in a pixel-interleaved row
+  unsigned x12;         // 12 x as it is (NOT clamped; wraps for the lanes left of the image): lane offset of the range-checked target load
+  unsigned img12;       // 12 h w (uniform): bytes of a pixel-interleaved image
   unsigned w12;         // 12 w (uniform): bytes of a pixel-interleaved row
   float w12f;           // ... as a float
   bool xin;             // column inside the image
@@ -266,9 +268,19 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
     p = project(a0, a1, a2, C.P3[0], C.P3[1], C.P3[2], ps.D, C.sc, C.h, C.w);
     UV.x = p.U; UV.y = p.V; fr.x = p.fu; fr.y = p.fv; rz = p.rz;
   }
-  ps.UV = UV; ps.f = fr; ps.rz = rz;
-  ps.inview = p.inview && C.xin;
-  ps.inview_o = p.inview && C.outb;
+  ps.UV = UV; ps.f = fr;
+#ifndef SFM_GATHER_GLOBAL
+  if constexpr (HWC) {
+    // (nothing of the masks crosses the step: out-of-view taps arrive as zeros, and 1/z is masked here)
+    ps.rz = (p.inview && C.outb) ? rz : 0.f;
+    ps.inview = ps.inview_o = true;
+  } else
+#endif
+  {
+    ps.rz = rz;
+    ps.inview = p.inview && C.xin;
+    ps.inview_o = p.inview && C.outb;
+  }
 #ifdef SFM_ABLATE_MEM   // timing experiment only: every access hits the same few cache lines
   const unsigned off = (unsigned)((p.v0 * C.w + p.u0) & 63);
   const unsigned offt = (unsigned)((r * C.w + C.xc) & 63);
@@ -294,10 +306,41 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
     // row below is the same address + 12 w.
     const f2 cell = UV - fr;
     const float bof = fmaf(cell.y, C.w12f, cell.x * 12.f);
+#ifdef SFM_GATHER_GLOBAL   // the round-2 form: global loads, out-of-view lanes fetch texel 0 and are masked afterwards
     const unsigned o12 = p.inview ? (unsigned)bof : 0u;
-    const char* q = reinterpret_cast<const char*>(C.sp[0]) + o12;   // (the source base lives in a vector register pair: the scalar file is full)
-    const Rgb2 T = *reinterpret_cast<const Rgb2*>(q), Bt = *reinterpret_cast<const Rgb2*>(q + C.w12);
+    const Rgb2 T = ld_off<Rgb2>(C.sp[0], o12), Bt = ld_off<Rgb2>(C.sp[0], o12 + C.w12);
     const Rgb I = ld_off<Rgb>(C.tp[0], (unsigned)r * C.w12 + C.xc12);
+#else
+    // Range-checked buffer loads (MUBUF, raw descriptor): a lane whose offset is not below num_records gets ZEROS.
+    //  * source taps: num_records = the image; a lane that is not in view is given an offset outside it, so all its taps are 0 and
+    //    with them the value and both derivatives -- no select per channel in finish_row (base_model.py:96's mask wants exactly 0);
+    //    the row below is the same lane offset against a descriptor that starts one row further down (the instruction's scalar
+    //    offset would do the same, but it takes part in the range check)
+    //  * target texel: the descriptor is ONE row (base = that row, num_records = its bytes: scalar arithmetic per step); the lane
+    //    offset is 12 x, which is out of range exactly for the columns outside the image (x < 0 wraps) -- no clamped column, no
+    //    multiply by the column mask
+    const char* sp8 = reinterpret_cast<const char*>(C.sp[0]);
+    const char* tp8 = reinterpret_cast<const char*>(C.tp[0]) + (size_t)((unsigned)r * C.w12);
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(sp8), 0, (int)C.img12, 0x00027000);
+    const __amdgpu_buffer_rsrc_t srs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(sp8 + C.w12), 0, (int)(C.img12 - C.w12), 0x00027000);
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(tp8), 0, (int)C.w12, 0x00027000);
+    const unsigned o12 = (p.inview && C.xin) ? (unsigned)bof : 0x80000000u;   // (a column outside the image is not a pixel: its I^ is 0)
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    typedef unsigned u3v __attribute__((ext_vector_type(3)));
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    const u4v t0 = __builtin_amdgcn_raw_buffer_load_b128(srs, o12, 0, 0);
+    const u2v t1 = __builtin_amdgcn_raw_buffer_load_b64(srs, o12 + 16u, 0, 0);
+    const u4v b0 = __builtin_amdgcn_raw_buffer_load_b128(srs2, o12, 0, 0);
+    const u2v b1 = __builtin_amdgcn_raw_buffer_load_b64(srs2, o12 + 16u, 0, 0);
+    const u3v i0 = __builtin_amdgcn_raw_buffer_load_b96(trs, C.x12, 0, 0);
+    Rgb2 T, Bt;
+    Rgb I;
+    T.c[0] = __uint_as_float(t0.x); T.c[1] = __uint_as_float(t0.y); T.c[2] = __uint_as_float(t0.z); T.c[3] = __uint_as_float(t0.w);
+    T.c[4] = __uint_as_float(t1.x); T.c[5] = __uint_as_float(t1.y);
+    Bt.c[0] = __uint_as_float(b0.x); Bt.c[1] = __uint_as_float(b0.y); Bt.c[2] = __uint_as_float(b0.z); Bt.c[3] = __uint_as_float(b0.w);
+    Bt.c[4] = __uint_as_float(b1.x); Bt.c[5] = __uint_as_float(b1.y);
+    I.c[0] = __uint_as_float(i0.x); I.c[1] = __uint_as_float(i0.y); I.c[2] = __uint_as_float(i0.z);
+#endif
     (void)off; (void)offt;
 #pragma unroll
     for (int c = 0; c < 3; ++c) { ps.ta[c] = T.c[c]; ps.tb[c] = T.c[3 + c]; ps.ba[c] = Bt.c[c]; ps.bb[c] = Bt.c[3 + c]; ps.it[c] = I.c[c]; }
@@ -318,6 +361,9 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
 }
 
 // stage A, second half: bilinear value and derivatives from the gathered taps
+// (PREMASKED: the taps of a sample that is not in view and the target texel of a column outside the image arrived as zeros, and
+//  ps.rz is already masked: the pixel-interleaved path's range-checked loads, see issue_row)
+template <bool PREMASKED>
 __device__ __forceinline__ void finish_row(const SsimCtx& C, const Pipe& ps, RowS& s) {
   unsigned nz = 0;
   float ih[3], it[3], du[3], dv[3];
@@ -327,11 +373,11 @@ __device__ __forceinline__ void finish_row(const SsimCtx& C, const Pipe& ps, Row
     const float top = fmaf(ps.f.x, dxt, ps.ta[c]);
     const float bot = fmaf(ps.f.x, dxb, ps.ba[c]);
     const float dvv = bot - top;
-    const float val = ps.inview ? fmaf(ps.f.y, dvv, top) : 0.f;
+    const float val = (PREMASKED || ps.inview) ? fmaf(ps.f.y, dvv, top) : 0.f;
     ih[c] = val;
     dv[c] = dvv;
     du[c] = fmaf(ps.f.y, dxb - dxt, dxt);
-    it[c] = ps.it[c] * C.xinf;       // 0 outside the image (the load came from the clamped column)
+    it[c] = PREMASKED ? ps.it[c] : ps.it[c] * C.xinf;       // 0 outside the image (planar: the load came from the clamped column)
     nz |= __float_as_uint(val);
   }
   s.ih = ch3(ih[0], ih[1], ih[2]);
@@ -339,7 +385,7 @@ __device__ __forceinline__ void finish_row(const SsimCtx& C, const Pipe& ps, Row
   s.duv0.x = du[0]; s.duv0.y = dv[0]; s.duv1.x = du[1]; s.duv1.y = dv[1];
   s.duv_s.x = du[2]; s.duv_s.y = dv[2];
   s.UV = ps.UV; s.D = ps.D;
-  s.rzi = ps.inview_o ? ps.rz : 0.f;   // halo lanes get no gradient of their own
+  s.rzi = (PREMASKED || ps.inview_o) ? ps.rz : 0.f;   // halo lanes get no gradient of their own
   // base_model.py:96: mask = all three channels exactly 0 (+-0 both count).  nz without its sign bit, read as a float, is 0 or
   // at least the smallest magnitude among the channels: the clamped product with 2^127 is the 0 / 1 indicator (one full-rate
   // instruction; shift + compare + select are three of the slow class)
@@ -607,7 +653,11 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const StepMasks&
   // ---------------- A: finish row r, put row r+1 in flight ----------------
   // (the arithmetic always runs -- on whatever the tap registers hold when the row lies outside the image -- and the rare case
   // overwrites the slot: an if / else costs five more scalar instructions per step than an if)
-  finish_row(C, ps, s0);
+#ifdef SFM_GATHER_GLOBAL
+  finish_row<false>(C, ps, s0);
+#else
+  finish_row<HWC>(C, ps, s0);
+#endif
   if (!step_bit(M.fin, k)) zero_rare(s0);
   SFM_STAMP(t1);
   if (step_bit(M.iss, k)) {
@@ -705,7 +755,11 @@ __device__ __forceinline__ void l1_source_pass(const SsimCtx& C, float* gacc, co
   if (rbeg + 1 < rend) disp_next = C.disp_second;
   for (int r = rbeg; r < rend; ++r) {
     RowS s0;
-    finish_row(C, ps, s0);
+#ifdef SFM_GATHER_GLOBAL
+    finish_row<false>(C, ps, s0);
+#else
+    finish_row<HWC>(C, ps, s0);
+#endif
     const float lg = ps.lg;
     if (r + 1 < rend) issue_row<HWC>(C, r + 1, disp_next, ps);
     disp_next = ldf(C.dp, (unsigned)min(r + 2, C.h - 1) * (unsigned)C.w + C.xc);
