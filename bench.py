@@ -415,7 +415,7 @@ def main():
                          "interleaved, as sfm_pyramid_hwc_fwd writes them (default); planar = the reference's (B,3,h,w)")
     ap.add_argument("--min-time", type=float, default=0.3, help="seconds of timed steps at least (blocks of --steps are repeated)")
     ap.add_argument("--max-blocks", type=int, default=400)
-    ap.add_argument("--event-every", type=int, default=10, help="attach the kernel-timing events to every n-th timed step (1 = every step)")
+    ap.add_argument("--event-every", type=int, default=20, help="attach the kernel-timing events to every n-th timed step (1 = every step)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
