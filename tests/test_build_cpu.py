@@ -49,3 +49,14 @@ def test_loss_kernels_fit_their_register_budget(tmp_path):
     for k, v in loss.items():
         ssim_grad = "loss_kernelILb1ELb1E" in k or "loss_kernel_wide" in k   # loss_kernel<SSIM=true, GRAD=true, ...>, loss_kernel_wide<...>
         assert v["VGPRs"] <= (168 if ssim_grad else 128), (k, v["VGPRs"])
+
+
+@pytest.mark.timeout(600)
+def test_committed_issue_model_is_the_one_of_these_sources():
+    """bench.py's `roofline_valu` prices the counted vector instructions with profiles/r03_issue_model.json: the file must be the
+    model of the kernels as they are in the tree (tools/issue_model.py --check recompiles and compares)."""
+    import sys
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "issue_model.py"), "r03", "--check"], capture_output=True, text=True, timeout=580)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])

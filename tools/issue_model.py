@@ -19,7 +19,9 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+CHECK = "--check" in sys.argv          # recompute from the sources and compare with the committed JSON instead of writing it
+_args = [a for a in sys.argv[1:] if not a.startswith("--")]
+tag = _args[0] if _args else "r03"
 CSRC = os.path.join(ROOT, "sfm-learner-chainer_amd", "csrc")
 
 # instruction -> row of the op-cost table whose measured cost it takes
@@ -139,6 +141,16 @@ def main():
             "mean_issue_cycles_per_valu": round(cyc / max(n_valu, 1), 4),
             "classes_per_row_step": {k: round(v / steps, 1) for k, v in sorted(classes.items())},
             "op_cost_source": src}
+    if CHECK:
+        have = json.load(open(os.path.join(ROOT, "profiles", "%s_issue_model.json" % tag)))["kernels"]
+        stale = [k for k, v in out["kernels"].items() if k not in have or have[k]["valu_per_row_step"] != v["valu_per_row_step"]
+                 or have[k]["issue_cycles_per_row_step"] != v["issue_cycles_per_row_step"]]
+        if stale:
+            print("profiles/%s_issue_model.json is stale for %d kernels, e.g. %s: committed %s, sources %s" % (
+                tag, len(stale), stale[0], have.get(stale[0]), out["kernels"][stale[0]]))
+            sys.exit(1)
+        print("profiles/%s_issue_model.json matches the sources (%d kernels)" % (tag, len(out["kernels"])))
+        return
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "profiles", "%s_issue_model.json" % tag), "w"), indent=1, sort_keys=True)
     with open(os.path.join(ROOT, "profiles", "%s_issue_model.md" % tag), "w") as f:
