@@ -104,6 +104,20 @@ def test_high_resolution_config5_shape(ops, synth, dev):
     _check_grads(fl, ref, 4, what="cfg5 B=1", ref64=ref64)
 
 
+def test_image_just_below_the_interleaved_layout_limit(ops, synth, dev):
+    """SFM_LAYOUT_HWC takes images of fewer than 2^24 / 12 pixels (byte offsets formed in fp32, 32-bit lane offsets of the
+    range-checked gathers): 896 x 1536 = 1.376 Mpixel is 16.5 of the 16.78 MB; one scale, one source, against the oracle.
+    (The margins of the knife mask scale with the coordinates: near u = 1536 one fp32 ulp is 1.2e-4 px and both evaluations
+    carry several, so a sample within 1e-3 px of a lattice line may sit in either cell -- 1e-4 at W = 416 -- and the sampled
+    value moves by that times the image slope: |I^ - I| below 1.5e-4 may take either sign -- 3e-5 at W = 416.)"""
+    d = synth.make_inputs(B=1, H=896, W=1536, n_src=1, n_scales=1, seed=3)
+    ref = _oracle(d, CFG)
+    fl = _bind(ops, dev, d, CFG, layout="hwc")
+    _check_losses(fl.forward_backward(), ref)
+    ref64 = lambda: O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], backward=True, dtype=np.float64, **CFG)
+    _check_grads(fl, ref, 1, what="896x1536", ref64=ref64, cell_thr=1e-3, abs_thr=1.5e-4)
+
+
 def _random_cases(n, seed=2024):
     """Ragged shapes (odd sizes, partial strips and chunks), batch sizes on both sides of the XCD-striping threshold, every
     source count and loss mode.  The smallest scale keeps at least 12 x 24 pixels: below that a single knife-edge pixel is

@@ -191,9 +191,10 @@ def pose_explained_by_discontinuities(d, cfg, ref, i, got, norm_B=None, cell_thr
     return out, named
 
 
-def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=True, what="", ref64=None, cell_thr=1e-4, explain=None):
+def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=True, what="", ref64=None, cell_thr=1e-4, explain=None,
+                 abs_thr=3e-5):
     """`ref64`: optional callable returning the fp64 oracle's result; consulted only for an array that misses the fp32
-    criterion (see _judged64), and every such use is reported.  `cell_thr`: see _knife.  `explain`: optional callable
+    criterion (see _judged64), and every such use is reported.  `cell_thr`, `abs_thr`: see _knife.  `explain`: optional callable
     (i, got) -> pose_explained_by_discontinuities(...), consulted for a d_pose array that misses everything else."""
     worst = 0.0
     r64 = []
@@ -233,14 +234,14 @@ def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=T
     on_test = None       # per sample: pixels the ORACLE places within `thr` of the strict in-view test (what the allowance goes by)
     knives = []
     for s, (g, w) in enumerate(zip(fl.d_disps, ref["d_disps"])):
-        knife = _knife(ref, s, n_src, what=what, cell_thr=cell_thr)
+        knife = _knife(ref, s, n_src, what=what, cell_thr=cell_thr, abs_thr=abs_thr)
         knives.append(knife)
         gnp = to_np(g)
         # (a quarter of the gradient tolerance already counts as "took the other branch": rounding noise is 1000x smaller)
         off = (np.abs(gnp.astype(np.float64) - w) > 0.25 * GRAD_TOL * np.abs(w).max()) & np.broadcast_to(knife, w.shape)
         cnt = off.reshape(off.shape[0], -1).sum(axis=1)
         observed = cnt if observed is None else observed + cnt
-        flip = knife_mask(ref, s, cell_thr=cell_thr)[1]                # (B,h,w): from the oracle's own margins only
+        flip = knife_mask(ref, s, cell_thr=cell_thr, abs_thr=abs_thr)[1]   # (B,h,w): from the oracle's own margins only
         fc = flip.reshape(flip.shape[0], -1).sum(axis=1)
         on_test = fc if on_test is None else on_test + fc
         close(gnp, w, knife, "d_disp[%d]" % s, "d_disps", s)
