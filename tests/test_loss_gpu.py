@@ -7,6 +7,8 @@ Tolerances (fp32, north_star: 1e-4 relative on the loss):
     outside knife-edge pixels (see tests/util.py); they are sums of many fp32 terms whose
     order differs between the oracle (NumPy) and the wave-level reductions.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -136,7 +138,7 @@ def pose_explained_by_discontinuities(d, cfg, ref, i, got, norm_B=None, cell_thr
     """Third opinion for d_pose[i] (B,6): is the kernel's value the ORACLE's with a few named pixels on the other side of a
     discontinuity they sit on?  For every sample whose d_pose row is off by more than a quarter of the gradient tolerance, the
     fp32 oracle is re-run on that sample and source alone (same normalisation: norm_batch) with ONE knife-edge pixel's disparity
-    nudged by +-1e-3 / +-1e-2 of its value; a nudge that makes d_pose JUMP (by more than 1e-4 of its maximum; the smooth response
+    nudged by +-1e-3 / +-1e-2 of its value (or its target texel by +-1e-4: the kink of |I^ - I|); a nudge that makes d_pose JUMP (by more than 1e-4 of its maximum; the smooth response
     to such a nudge is <= 1e-2 of one pixel's share, 1e-5) is that pixel taking its other branch.  Jumps are then picked greedily
     (each pixel once, only while the distance to the kernel's row shrinks by > 10 %).  Returns the oracle's array with the
     picked jumps added and the list of pixels; the caller judges the kernel against it with the flat criteria."""
@@ -153,9 +155,9 @@ def pose_explained_by_discontinuities(d, cfg, ref, i, got, norm_B=None, cell_thr
         base_in = dict(tgt_pyr=[a[sl] for a in d["tgt_pyr"]], src_pyr=[a[sl, 3 * i:3 * i + 3] for a in d["src_pyr"]], intrinsics=d["intrinsics"][sl],
                        poses=[d["poses"][i][sl]], masks=[a[sl, i:i + 1] for a in d["masks"]] if (d["masks"] is not None and cfg.get("exp_reg")) else None)
 
-        def pose_grad(disps):
-            r = O.sfm_loss(base_in["tgt_pyr"], base_in["src_pyr"], base_in["intrinsics"], disps, base_in["poses"], base_in["masks"],
-                           backward=True, norm_batch=Bn, **kw)
+        def pose_grad(disps, tgt=None):
+            r = O.sfm_loss(base_in["tgt_pyr"] if tgt is None else tgt, base_in["src_pyr"], base_in["intrinsics"], disps, base_in["poses"],
+                           base_in["masks"], backward=True, norm_batch=Bn, **kw)
             return np.asarray(r["d_poses"][0][0], np.float64)
 
         disps0 = [a[sl].copy() for a in d["disps"]]
@@ -169,13 +171,31 @@ def pose_explained_by_discontinuities(d, cfg, ref, i, got, norm_B=None, cell_thr
         if len(cands) > max_px:
             return None, "sample %d has %d knife-edge pixels (> %d): too many to probe" % (b, len(cands), max_px)
         jumps = []
+
+        def note(p_, dlt):
+            if np.abs(dlt).max() > 1e-4 * scale and not any(p == p_ and np.abs(dlt - q).max() < 1e-5 * scale for p, q in jumps):
+                jumps.append((p_, dlt))
+
         for (s, y, x) in cands:
             for rel in (1e-3, -1e-3, 1e-2, -1e-2):
                 disps = [a.copy() for a in disps0]
                 disps[s][0, 0, y, x] *= np.float32(1 + rel)
-                dlt = pose_grad(disps) - base
-                if np.abs(dlt).max() > 1e-4 * scale and not any(p == (s, y, x) and np.abs(dlt - q).max() < 1e-5 * scale for p, q in jumps):
-                    jumps.append(((s, y, x), dlt))
+                note((s, y, x), pose_grad(disps) - base)
+            # the kink of |I^ - I| is crossed most directly from the target's side: the pixel's three channels moved by +-1e-4
+            # (more than the 3e-5 within which the knife mask puts a pixel on the kink, 1e-4 of the image range)
+            for dt in (1e-4, -1e-4):
+                tgt = [a.copy() for a in base_in["tgt_pyr"]]
+                tgt[s][0, :, y, x] += np.float32(dt)
+                dlt = pose_grad(disps0, tgt) - base
+                note((s, y, x), dlt)
+                # ... and the kink has a value of its own: F.absolute's backward is sign(0) = 0 where one evaluation finds
+                # I^ - I == 0 exactly -- half way between the two signs
+                if ref["abs_margin"][s][b, i, y, x] < 3e-5:
+                    note((s, y, x), 0.5 * dlt)
+        if os.environ.get("SFM_EXPLAIN_DEBUG"):
+            print("explain sample %d: residual/scale %s" % (b, (got[b] - want[b]) / scale))
+            for p_, dlt in jumps:
+                print("   jump at %s: %s" % (p_, dlt / scale))
         res, used = got[b] - want[b], set()
         while True:
             best = None
