@@ -312,7 +312,9 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
   const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
   int s = 0, b, t;
   if (A.B >= 8) {
-    const int nb = (A.B - xcd + 7) >> 3;          // samples owned by this XCD
+    // whole groups of eight samples: one sample of each group per XCD; the samples left over (B not a multiple of 8) are dealt out
+    // item by item, round-robin over the XCDs (before round 3 they went to the first XCDs whole: B = 11 ran at 11/16)
+    const int nb = A.B >> 3;                      // samples of the whole groups owned by this XCD
     int rem = loc;
     bool found = false;
 #pragma unroll
@@ -323,13 +325,33 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
         else rem -= cnt;
       }
     }
-    if (!found) return;   // whole wavefront leaves; no block-level synchronisation anywhere in this kernel
-    int tls = A.tiles_of[0];
+    if (found) {
+      int tls = A.tiles_of[0];
 #pragma unroll
-    for (int k = 1; k < SFM_MAX_SCALES; ++k) tls = (s == k) ? A.tiles_of[k] : tls;
-    const int bl = rem / tls;
-    t = rem - bl * tls;
-    b = xcd + 8 * bl;
+      for (int k = 1; k < SFM_MAX_SCALES; ++k) tls = (s == k) ? A.tiles_of[k] : tls;
+      const int bl = rem / tls;
+      t = rem - bl * tls;
+      b = xcd + 8 * bl;
+    } else {
+      int T = 0;
+#pragma unroll
+      for (int k = 0; k < SFM_MAX_SCALES; ++k) T += A.tiles_of[k];     // (0 beyond n_scales)
+      const int q = rem * 8 + xcd;                // index among the left-over samples' items
+      const int left = A.B & 7;
+      if (q >= left * T) return;   // whole wavefront leaves; no block-level synchronisation anywhere in this kernel
+      const int br = q / T;
+      int wi = q - br * T;
+      b = (A.B & ~7) + br;
+      bool hit = false;
+#pragma unroll
+      for (int k = 0; k < SFM_MAX_SCALES; ++k) {
+        if (!hit) {
+          if (wi < A.tiles_of[k]) { s = k; hit = true; }
+          else wi -= A.tiles_of[k];
+        }
+      }
+      t = wi;
+    }
   } else {
     const int per = (int)(gridDim.x >> 3);
     const int it = xcd * per + loc;
@@ -1026,7 +1048,7 @@ static hipError_t launch_main(const Plan& p, hipStream_t st, hipEvent_t ev_start
   // 8 x (items of the busiest XCD): see the item mapping at the top of loss_kernel
   int tiles_per_sample = 0;
   for (int s = 0; s < p.args.n_scales; ++s) tiles_per_sample += p.args.sc[s].tiles;
-  const int per_xcd = p.args.B >= 8 ? ((p.args.B + 7) / 8) * tiles_per_sample : (p.args.items + 7) / 8;
+  const int per_xcd = p.args.B >= 8 ? (p.args.B / 8) * tiles_per_sample + ((p.args.B % 8) * tiles_per_sample + 7) / 8 : (p.args.items + 7) / 8;
   const void* fn = kernel_ptr<GRAD, LOSS>(p.ssim, p.expl, p.smode, p.hwc, p.wide);
   // With profiling events the kernel is launched through hipExtLaunchKernel: the events then carry the begin / end
   // timestamps of THIS dispatch (what rocprofv3's kernel trace reports), and no marker packets are put between the
