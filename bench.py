@@ -435,13 +435,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit("bench.py --gpus %d, but WORLD_SIZE=%d" % (args.gpus, world))
+    # SFM_BENCH_REHEARSE_ONE_GPU=1: a rehearsal of the N > 1 code path on a box with ONE GPU -- every rank runs on cuda:0 and the
+    # collectives go through gloo (RCCL refuses two ranks on one device).  The line it prints says so and is not a measurement.
+    rehearse = bool(os.environ.get("SFM_BENCH_REHEARSE_ONE_GPU")) and world > 1
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ     # under torch.distributed.run, also at N = 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     ops = importlib.import_module(PKG + ".ops")
     synth = importlib.import_module(PKG + ".synth")
@@ -626,6 +634,10 @@ def main():
             out["interval_variant"] = {"ms_per_step": round(interval_ms, 5), "value": round(R.warped_px * world / (interval_ms * 1e-3) / 1e6, 1),
                                        "note": "ONE all-reduce of the K rows per K steps (reporting per LogReport interval)"}
             out["allreduce_160MB"] = allreduce_probe
+        if rehearse:
+            out["rehearsal"] = ("SFM_BENCH_REHEARSE_ONE_GPU: all %d ranks ran on ONE GPU and the collectives went through gloo -- this line "
+                                "exercises the N > 1 code path, it is NOT a measurement" % world)
+            out["config"]["parallelism"] = "REHEARSAL on one GPU (gloo): " + out["config"]["parallelism"]
         out.update(secondary)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
