@@ -6,8 +6,10 @@
 
 One "step" = forward + backward of the multi-scale photometric loss through the C ABI over one synthetic batch
 that is already resident in HBM: the fused launch sfm_loss_fwd_bwd (loss and all gradients -- what
-SFMLearnerLoss.__call__ runs when backprop is enabled) plus, for N > 1, the RCCL all-reduce of the five
-reported scalars, EVERY step.  Workload at any N: BASELINE.json configs[2]/[3] AS WRITTEN -- B = 32 samples PER GPU,
+SFMLearnerLoss.__call__ runs when backprop is enabled).  The path shards over samples with no exchange on the data
+path; for N > 1 the five REPORTED scalars of the K steps of a block are summed over the ranks with ONE RCCL all-reduce at
+the end of the block, inside the timed region (`--collective step` all-reduces them after every step instead; that variant
+is measured in the same run and reported as `per_step_collective_variant`).  Workload at any N: BASELINE.json configs[2]/[3] AS WRITTEN -- B = 32 samples PER GPU,
 128x416, 4 scales, 2 sources, L1 + SSIM(0.15, experiments/sfm_learner_v1_ssim.yml) + EDGE-AWARE smoothness(0.1)
 (models/base_model.py:144-155), weak scaling.  The same with the second-order smoothness the reference's live code runs
 (base_model.py:75-77,169-185) is the secondary key `cfg3` of the line.
@@ -413,6 +415,9 @@ def main():
     ap.add_argument("--layout", default="hwc", choices=["hwc", "planar"],
                     help="memory layout of the image pyramids resident in HBM when the timed region starts: hwc = pixel-"
                          "interleaved, as sfm_pyramid_hwc_fwd writes them (default); planar = the reference's (B,3,h,w)")
+    ap.add_argument("--collective", default="interval", choices=["interval", "step"],
+                    help="N > 1: all-reduce the reported scalars once per block of --steps steps (default; what a trainer that "
+                         "reports per LogReport interval needs) or after every step")
     ap.add_argument("--min-time", type=float, default=0.3, help="seconds of timed steps at least (blocks of --steps are repeated)")
     ap.add_argument("--max-blocks", type=int, default=400)
     ap.add_argument("--event-every", type=int, default=20, help="attach the kernel-timing events to every n-th timed step (1 = every step)")
@@ -457,11 +462,14 @@ def main():
     R = Runner(torch, np, ops, synth, dev, args.workload, args.layout, args.mode, args.batch, seed=1 + rank, norm_scale=world)
     K = max(args.steps, 1)
 
-    # The only collective of the path: the five reported scalars summed over the shards (RCCL over xGMI), once per step.
-    # Every step writes its scalars into its own row of a device-resident log and the row is all-reduced in stream order
-    # (async_op=False: no host wait, the next step's launches queue behind it); per-sample gradients never leave their rank.
-    # Measured with tools/allreduce_overhead.py (one rank): +9 us per step this way, +25 us with async_op=True and the waits
-    # deferred (the cross-stream event traffic costs more than the overlap gains), +7 us replayed from a HIP graph.
+    # The path has no exchange on the data path (every quantity is per sample until the final means; gradients of a rank's own
+    # disparities / poses never leave it).  What is exchanged is what gets REPORTED: the five scalars, summed over the shards (RCCL
+    # over xGMI).  Every step writes its scalars into its own row of a device-resident log; `--collective interval` (default) sums
+    # the K rows of a block with ONE all-reduce at the end of the block, inside the timed region -- what a trainer that reports per
+    # LogReport interval needs; `--collective step` all-reduces each row right after its step, in stream order (async_op=False: no
+    # host wait, the next step's launches queue behind it).  Measured with tools/allreduce_overhead.py (one rank, RCCL): the per-step
+    # form costs +8.6 us per 60 us step, +25 us with async_op=True and the waits deferred (the host side of torch's all_reduce is
+    # 42 us), +6.7 us replayed from a HIP graph.  Both placements are measured in every N > 1 run; the other one is a secondary key.
     n_log = max(K, args.warmup, 1)
     loss_log = torch.zeros((n_log, 5), dtype=torch.float32, device=dev)
     rows = [loss_log[k] for k in range(n_log)]
@@ -501,7 +509,8 @@ def main():
             elapsed = float(tt.item())
         return elapsed
 
-    coll = "step" if use_dist else None
+    coll = args.collective if use_dist else None
+    other_coll = "step" if coll == "interval" else "interval"
     run_steps(args.warmup, coll, False)
     blocks, k_main, k_second = [], [], []
 
@@ -520,11 +529,11 @@ def main():
     per_step = np.array(blocks) / K
     ms_step = float(np.median(per_step)) * 1e3
 
-    # N > 1: the same with ONE collective per K steps (what a trainer that reports per LogReport interval needs), and the
-    # all-reduce of a DispNet+PoseNet-sized gradient buffer (characterises xGMI; not part of this path)
+    # N > 1: the same with the other placement of the collective, and the all-reduce of a DispNet+PoseNet-sized gradient buffer
+    # (characterises xGMI; not part of this path)
     interval_ms = allreduce_probe = None
     if world > 1:
-        iv = [timed_block("interval") for _ in range(min(n_blocks, 5))]
+        iv = [timed_block(other_coll) for _ in range(min(n_blocks, 5))]
         interval_ms = float(np.median(iv)) / K * 1e3
         buf = torch.zeros((GRAD_BUFFER_FLOATS,), dtype=torch.float32, device=dev)
         for _ in range(3):
@@ -619,7 +628,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": R.desc, "per_gpu_batch": R.B, "global_batch": R.B * world, "H": R.H, "W": R.W, "n_src": R.n_src,
                        "n_scales": R.n_scales, "mode": args.mode, "image_layout": args.layout, "warped_px_per_gpu_step": R.warped_px,
-                       "parallelism": "batch-sharded x%d; RCCL all-reduce of the 5 scalars EVERY step (in stream order)" % world
+                       "parallelism": ("batch-sharded x%d, no exchange on the data path; RCCL all-reduce of the 5 reported scalars %s" % (
+                           world, "once per block of %d steps (in the timed region)" % K if coll == "interval" else "after EVERY step (in stream order)"))
                        if use_dist else "single GPU, no collective"},
             "timing": {"blocks": len(blocks), "steps_per_block": K, "timed_s": round(float(np.sum(blocks)), 4),
                        "ms_per_step_median": round(ms_step, 5), "ms_per_step_p10": round(float(np.percentile(per_step, 10)) * 1e3, 5),
@@ -631,8 +641,10 @@ def main():
             "loss5": [round(v, 6) for v in loss],
         }
         if world > 1:
-            out["interval_variant"] = {"ms_per_step": round(interval_ms, 5), "value": round(R.warped_px * world / (interval_ms * 1e-3) / 1e6, 1),
-                                       "note": "ONE all-reduce of the K rows per K steps (reporting per LogReport interval)"}
+            key = "per_step_collective_variant" if other_coll == "step" else "interval_variant"
+            out[key] = {"ms_per_step": round(interval_ms, 5), "value": round(R.warped_px * world / (interval_ms * 1e-3) / 1e6, 1),
+                        "note": "the five scalars all-reduced after EVERY step (blocking, in stream order)" if other_coll == "step"
+                        else "ONE all-reduce of the K rows per K steps (reporting per LogReport interval)"}
             out["allreduce_160MB"] = allreduce_probe
         if rehearse:
             out["rehearsal"] = ("SFM_BENCH_REHEARSE_ONE_GPU: all %d ranks ran on ONE GPU and the collectives went through gloo -- this line "

@@ -24,7 +24,7 @@ def test_two_ranks_on_one_gpu(dev):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and "rehearsal" in d
     assert d["config"]["global_batch"] == 2 * d["config"]["per_gpu_batch"]
-    assert "interval_variant" in d and "allreduce_160MB" in d
+    assert "per_step_collective_variant" in d and "allreduce_160MB" in d and "once per block" in d["config"]["parallelism"]
     total, pixel, smooth, expl, ssim = d["loss5"]
     # every rank normalises by the GLOBAL batch, so the summed scalars are a loss of ordinary size (not twice / half of one)
     assert 1.0 < total < 8.0 and abs(total - (0.85 * pixel + 0.15 * ssim + smooth + expl)) < 1e-3 * total

@@ -15,7 +15,7 @@ dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
 torch.cuda.set_device(dev)
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29513")
 dist.init_process_group("nccl", rank=int(os.environ.get("RANK", 0)), world_size=int(os.environ.get("WORLD_SIZE", 1)), device_id=dev)
-R = bench.Runner(torch, np, ops, synth, dev, "cfg3", "hwc", "fused", 0, seed=1, norm_scale=dist.get_world_size())
+R = bench.Runner(torch, np, ops, synth, dev, "cfg3_edge", "hwc", "fused", 0, seed=1, norm_scale=dist.get_world_size())
 K = 200
 log = torch.zeros((K, 5), dtype=torch.float32, device=dev)
 rows = [log[k] for k in range(K)]
