@@ -477,7 +477,9 @@ def main():
     # `--event-every`-th step: a dispatch that carries events costs the step about 5 us (the runtime brackets it with
     # barrier packets), which is the step's business on the sampled steps only.
     ev_every = max(1, args.event_every)
-    sampled = [k for k in range(K) if k % ev_every == 0]
+    # (the sampled steps sit in the MIDDLE of their stretch of ev_every steps: the first step of a block starts on an idle GPU, behind
+    #  the barrier + synchronize that opens the block, and is not representative of the steps the block is timed over)
+    sampled = [k for k in range(K) if k % ev_every == min(ev_every, K) // 2]
     events = {k: [ev.create() for _ in range(4)] for k in sampled}
 
     def run_steps(n, collective, timed):
