@@ -41,7 +41,7 @@ PKG = "sfm-learner-chainer_amd"
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_FWD, BYTES_BWD = 28, 32   # algorithmic bytes per warped pixel, SURVEY.md 8(d)
 N_SIMD = 1024                   # 256 CUs x 4 SIMDs
-PROFILE_TAGS = ("r03",)         # profiles/<tag>_summary.json, _issue_model.json, _wave_stage_stamps.txt: what roofline_valu is built from
+PROFILE_TAGS = ("r04", "r03")         # profiles/<tag>_summary.json, _issue_model.json, _wave_stage_stamps.txt: what roofline_valu is built from
 GRAD_BUFFER_FLOATS = 36489060 + 3393892   # DispNet + PoseNet parameters: the ~160 MB all-reduce probe
 
 WORKLOADS = {
@@ -367,9 +367,11 @@ def profile_facts(workload, layout, mode, kernel_name):
         try:
             summ = json.load(open(os.path.join(ROOT, "profiles", "%s_summary.json" % tag)))
             var = summ["variants"]["%s_%s_%s" % (workload, layout, mode)]
+            if kernel_name not in var["kernels"] and kernel_name.replace(", false>(sfm", ">(sfm") in var["kernels"]:
+                kernel_name = kernel_name.replace(", false>(sfm", ">(sfm")     # profiles of round 3: before the WARPED template argument
             if kernel_name not in var["kernels"]:        # a small launch of an L1 gradient kernel runs its three-waves-per-SIMD build
-                mw = re.match(r"void sfm::loss_kernel<false, true, (\w+), false, (\d), (\w+)>", kernel_name)
-                wide = "void sfm::loss_kernel_wide<%s, %s, %s>(sfm::LossArgs)" % mw.groups() if mw else None
+                mw = re.match(r"void sfm::loss_kernel<false, true, (\w+), false, (\d), (\w+?)(, false)?>", kernel_name)
+                wide = "void sfm::loss_kernel_wide<%s, %s, %s%s>(sfm::LossArgs)" % (mw.group(1), mw.group(2), mw.group(3), mw.group(4) or "") if mw else None
                 if wide in var["kernels"]:
                     kernel_name = wide
             kv = var["kernels"][kernel_name]
@@ -397,7 +399,7 @@ def kernel_symbol(cfg, layout, mode):
     smode = 0 if not cfg.get("smooth_reg") else (2 if cfg.get("smooth_mode") == "edge_aware" else 1)
     grad, loss = (True, True) if mode == "fused" else (True, False)
     tf = lambda v: "true" if v else "false"
-    return "void sfm::loss_kernel<%s, %s, %s, %s, %d, %s>(sfm::LossArgs)" % (tf(ssim), tf(grad), tf(loss), tf(expl), smode, tf(layout == "hwc"))
+    return "void sfm::loss_kernel<%s, %s, %s, %s, %d, %s, false>(sfm::LossArgs)" % (tf(ssim), tf(grad), tf(loss), tf(expl), smode, tf(layout == "hwc"))
 
 
 def main():

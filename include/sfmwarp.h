@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SFM_ABI_VERSION 3
+#define SFM_ABI_VERSION 4
 
 #define SFM_OK 0
 #define SFM_ERR_NULL (-1)      /* a required pointer is NULL                       */
@@ -141,6 +141,10 @@ typedef struct SfmLossDesc {
   float *d_mask[SFM_MAX_SCALES]; /* (B,n_src,h,w) overwritten; required iff exp_reg != 0      */
   float *d_src[SFM_MAX_SCALES];  /* (B,3*n_src,h,w) or NULL; ACCUMULATED (atomics)            */
   int32_t image_layout;          /* SFM_LAYOUT_* of tgt[] and src[]                           */
+  /* optional output of sfm_loss_fwd and sfm_loss_fwd_bwd (ignored by sfm_loss_bwd): the warped source images the loss
+   * was computed on, curr_proj_img of models/base_model.py:90-94, i.e. what projective_inverse_warp returns for source i
+   * at scale s -- exactly 0 where the sample is not in view (:96).  Planar in both image layouts. (ABI v4) */
+  float *warped[SFM_MAX_SCALES]; /* (B,n_src,3,h,w) or NULL; overwritten                      */
 } SfmLossDesc;
 
 /* scratch needed by the three calls below for this descriptor (0 on a bad descriptor) */
@@ -184,6 +188,10 @@ int sfm_pyramid_fwd(const float *x, float *const *y, int N, int C, int H, int W,
  * (1 for the target, n_src for the sources, base_model.py:50-57) -> y[s] (N,G,H>>s,W>>s,3) for s = 0..n_scales-1
  * (scale 0 is the re-laid-out input).  Values are identical to sfm_pyramid_fwd's. */
 int sfm_pyramid_hwc_fwd(const float *x, float *const *y, int N, int G, int H, int W, int n_scales, void *stream);
+/* Development / test hook: which kernel the NEXT sfm_pyramid_hwc_fwd / sfm_pyramid_pair_hwc_fwd call of the calling thread runs,
+ * then back to automatic.  0 = automatic (the band kernel that reads every input pixel once, where the shape allows),
+ * 1 = the one-thread-per-output-pixel kernel.  Same values bit for bit. */
+int sfm_pyramid_variant(int variant);
 /* Both pyramids of a step in ONE launch: tgt (N,3,H,W) and src (N,3*n_src,H,W) (base_model.py:50-57) ->
  * y_tgt[s] (N,1,h,w,3), y_src[s] (N,n_src,h,w,3), s = 0..n_scales-1: the whole loop head :69-72. */
 int sfm_pyramid_pair_hwc_fwd(const float *tgt, const float *src, float *const *y_tgt, float *const *y_src, int N, int n_src,

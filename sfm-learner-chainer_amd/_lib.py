@@ -16,7 +16,7 @@ import torch  # noqa: F401
 
 SFM_MAX_SCALES = 8
 SFM_MAX_SRC = 8
-SFM_ABI_VERSION = 3
+SFM_ABI_VERSION = 4
 SFM_LAYOUT_PLANAR, SFM_LAYOUT_HWC = 0, 1
 
 SMOOTH_NONE, SMOOTH_SECOND_ORDER, SMOOTH_EDGE_AWARE = 0, 1, 2
@@ -39,6 +39,7 @@ class SfmLossDesc(C.Structure):
         ("d_disp", _FP * SFM_MAX_SCALES), ("d_pose", _FP * SFM_MAX_SRC), ("d_mask", _FP * SFM_MAX_SCALES),
         ("d_src", _FP * SFM_MAX_SCALES),
         ("image_layout", C.c_int32),
+        ("warped", _FP * SFM_MAX_SCALES),
     ]
 
 
@@ -71,6 +72,7 @@ SYMBOLS = {
     "sfm_disp_act_bwd": (_I, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_longlong), _I, _V]),
     "sfm_augment_fwd": (_I, [_FP, _FP, _FP, _I, _I, _I, _I, _I, _V]),
     "sfm_pyramid_fwd": (_I, [_FP, C.POINTER(C.c_void_p), _I, _I, _I, _I, _I, _V]),
+    "sfm_pyramid_variant": (_I, [_I]),
     "sfm_pyramid_hwc_fwd": (_I, [_FP, C.POINTER(C.c_void_p), _I, _I, _I, _I, _I, _V]),
     "sfm_pyramid_pair_hwc_fwd": (_I, [_FP, _FP, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I, _I, _I, _I, _I, _V]),
 }

@@ -82,11 +82,7 @@ __device__ __forceinline__ void euler2mat(const float* r, Rot& o) {
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     float a = fminf(fmaxf(r[k], -pi), pi);
-#ifdef SFM_LIBRARY_SINCOS   // the library's sincosf instead
-    sincosf(a, &o.s[k], &o.c[k]);
-#else
     sincos_pi(a, &o.s[k], &o.c[k]);
-#endif
   }
   const float Z[9] = {o.c[2], -o.s[2], 0.f, o.s[2], o.c[2], 0.f, 0.f, 0.f, 1.f};
   const float Y[9] = {o.c[1], 0.f, o.s[1], 0.f, 1.f, 0.f, -o.s[1], 0.f, o.c[1]};
@@ -194,12 +190,6 @@ __device__ __forceinline__ float rcp_refined(float b) {
 }
 
 // lane l receives the value of lane l-1; lane 0 receives 0   (DPP wave_shr:1)
-#ifdef SFM_ABLATE_DPP   // timing experiment only (wrong results): no cross-lane traffic
-__device__ __forceinline__ float from_left(float x) { return x * 1.5f; }
-__device__ __forceinline__ float from_right(float x) { return x * 0.5f; }
-#define from_left from_left_real
-#define from_right from_right_real
-#endif
 __device__ __forceinline__ float from_left(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, true));
 }
@@ -207,10 +197,6 @@ __device__ __forceinline__ float from_left(float x) {
 __device__ __forceinline__ float from_right(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, true));
 }
-#ifdef SFM_ABLATE_DPP
-#undef from_left
-#undef from_right
-#endif
 __device__ __forceinline__ float hsum3(float x) {
   asm("" : "+v"(x));   // keep x a materialised value: an FMA contraction of its producer into the adds would block the DPP operand folding
   return (x + from_left(x)) + from_right(x);
@@ -261,11 +247,7 @@ __device__ __forceinline__ float signf(float t) { return (t != 0.f) ? __builtin_
 struct __attribute__((packed, aligned(4))) Tap2 {
   float a, b;
 };
-#ifdef SFM_TAP_DWORDS   // timing experiment only: two 4-byte loads per tap pair (the laundered pointer keeps them from being re-merged)
-__device__ __forceinline__ Tap2 load_tap2(const float* p) { Tap2 t; t.a = p[0]; const float* q = p + 1; asm("" : "+v"(q)); t.b = *q; return t; }
-#else
 __device__ __forceinline__ Tap2 load_tap2(const float* p) { return *reinterpret_cast<const Tap2*>(p); }
-#endif
 
 // ------------------------------------------------------------------------------------------
 // Per-lane accesses to a wave-uniform array: base pointer (uniform, SGPR pair) + zero-extended 32-bit BYTE offset (VGPR).
@@ -287,11 +269,7 @@ __device__ __forceinline__ void stf(float* base, const unsigned idx, const float
 // charged for and the next kernel waits for (MI355X_MICROARCH.md, 'boundary': + B / 6 TB/s for B dirty bytes); written through,
 // the bytes leave while the other waves still compute.
 __device__ __forceinline__ void stf_wt(float* base, const unsigned idx, const float v) {
-#ifdef SFM_PLAIN_OUTPUT_STORES
-  stf(base, idx, v);
-#else
   __hip_atomic_store(reinterpret_cast<float*>(reinterpret_cast<char*>(base) + idx * 4u), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------

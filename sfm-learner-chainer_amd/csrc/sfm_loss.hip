@@ -40,6 +40,7 @@ struct ScaleArgs {
   float* d_disp;
   float* d_mask;
   float* d_src;
+  float* warped;               // optional output (B,n_src,3,h,w): the warped sources, base_model.py:90-94
   int h, w, strips, chunks, tiles, item_begin, chunk_rows;
   float inv_cnt;               // 1 / (norm_B * 3 * h * w)                 base_model.py:111,115
   float c_dx2, c_dy2, c_dxy;   // smooth_reg / 2^s / element count         base_model.py:76,184-185
@@ -98,9 +99,6 @@ __global__ void geom_kernel(const LossArgs A) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int total = A.B * A.n_scales * A.n_src;
   if (t >= total) return;
-#ifdef SFM_ABLATE_GEOM_EMPTY   // timing experiment only: the floor of this launch
-  if (A.gy != 12345.f) return;
-#endif
   const int i = t % A.n_src;
   const int bs = t / A.n_src;  // b * n_scales + s
   const int b = bs / A.n_scales;
@@ -288,8 +286,10 @@ __device__ __forceinline__ void set_issue_prio(const int p) {   // s_setprio tak
 // (BASELINE cfg1 / cfg2: fewer waves than three rounds of SIMDs even at the smallest chunk height) is bound by how fast ONE wave
 // gets through its instructions, not by how many waves a SIMD holds: cfg2's kernel 14.3 -> 13.4 us.  At B = 32 the same build is
 // 8.7 % slower than the four-wave one (profiles/r03_ab_small_kernels.txt), so the plan picks per launch (Plan::wide).
-template <bool SSIM, bool GRAD, bool LOSS, bool EXPL, int SMODE, bool HWC>
+// WARPED: the instantiations that also write the warped source images (SfmLossDesc.warped; LOSS kernels only).
+template <bool SSIM, bool GRAD, bool LOSS, bool EXPL, int SMODE, bool HWC, bool WARPED>
 __device__ __forceinline__ void loss_body(const LossArgs& A) {
+  static_assert(LOSS || !WARPED, "the warped images are an output of the forward and the fused entry points");
   using HH = Halo<SSIM, GRAD, SMODE>;
   __shared__ float gacc_all[GRAD ? WAVES_PER_BLOCK * MAX_CHUNK_ROWS * 64 : 64];
   const int wave = threadIdx.x >> 6;
@@ -304,11 +304,9 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
   // The header of the argument block is fetched in ONE batch of scalar loads, before anything branches on it: left to where each
   // field is first used, the loads end up behind one another's branches -- eight dependent round trips to a cold scalar cache at the
   // start of every wave, with the whole chip waiting.
-#ifndef SFM_NO_ARG_BATCH
   asm volatile("" ::"s"(A.B), "s"(A.n_src), "s"(A.n_scales), "s"(A.items), "s"(A.simds_per_xcd), "s"(A.prio_top), "s"(A.prio_tab),
                "s"(A.tiles_of[0]), "s"(A.tiles_of[1]), "s"(A.tiles_of[2]), "s"(A.tiles_of[3]), "s"(A.tiles_of[4]), "s"(A.tiles_of[5]),
                "s"(A.tiles_of[6]), "s"(A.tiles_of[7]), "s"(A.geom), "s"(A.trace));
-#endif
   const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
   int s = 0, b, t;
   if (A.B >= 8) {
@@ -367,11 +365,9 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
     t = idx - b * tls;
   }
   const ScaleArgs& S = A.sc[s];
-#ifndef SFM_NO_ARG_BATCH
   // ... and the scale's entry in a second one
   asm volatile("" ::"s"(S.tgt), "s"(S.src), "s"(S.disp), "s"(S.d_disp), "s"(S.h), "s"(S.w), "s"(S.strips), "s"(S.tiles), "s"(S.item_begin),
                "s"(S.chunk_rows), "s"(S.inv_cnt), "s"(S.k_pix), "s"(S.kq));
-#endif
   const int item = S.item_begin + b * S.tiles + t;
   unsigned long long t_start = 0;
   if (A.trace) t_start = __builtin_amdgcn_s_memrealtime();
@@ -489,6 +485,7 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
     C.h = h; C.w = w; C.y0 = y0p; C.y1 = y1p;
     C.dp = S.disp + (size_t)b * P;
     C.dsp = (GRAD && S.d_src) ? S.d_src + ((size_t)b * A.n_src + i) * 3 * P : nullptr;
+    C.wp = WARPED ? S.warped + ((size_t)b * A.n_src + i) * 3 * P : nullptr;
     C.mp = EXPL ? S.mlog + ((size_t)b * A.n_src + i) * P : nullptr;
     C.dmp = (EXPL && GRAD) ? S.d_mask + ((size_t)b * A.n_src + i) * P : nullptr;
     C.P = P;
@@ -508,9 +505,9 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
     C.lane = lane;
     float* gpm_out = GRAD ? A.part_gpm + ((size_t)item * A.n_src + i) * 12 : nullptr;
     if constexpr (SSIM) {
-      ssim_source_pass<GRAD, LOSS, HWC>(C, gacc, first, acc_pix, acc_ssim, gpm_out SFM_STAMPS_PASS);
+      ssim_source_pass<GRAD, LOSS, HWC, WARPED>(C, gacc, first, acc_pix, acc_ssim, gpm_out SFM_STAMPS_PASS);
     } else {
-      l1_source_pass<GRAD, LOSS, EXPL, HWC>(C, gacc, first, acc_pix, acc_exp, gpm_out);
+      l1_source_pass<GRAD, LOSS, EXPL, HWC, WARPED>(C, gacc, first, acc_pix, acc_exp, gpm_out);
     }
     first = false;
 #ifdef SFM_STAMPS
@@ -554,14 +551,14 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
   }
 }
 
-template <bool SSIM, bool GRAD, bool LOSS, bool EXPL, int SMODE, bool HWC>
+template <bool SSIM, bool GRAD, bool LOSS, bool EXPL, int SMODE, bool HWC, bool WARPED = false>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) loss_kernel(const LossArgs A) {
-  loss_body<SSIM, GRAD, LOSS, EXPL, SMODE, HWC>(A);
+  loss_body<SSIM, GRAD, LOSS, EXPL, SMODE, HWC, WARPED>(A);
 }
 // (WIDE, see above: L1 gradient kernels only)
-template <bool LOSS, int SMODE, bool HWC>
+template <bool LOSS, int SMODE, bool HWC, bool WARPED = false>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 3) loss_kernel_wide(const LossArgs A) {
-  loss_body<false, true, LOSS, false, SMODE, HWC>(A);
+  loss_body<false, true, LOSS, false, SMODE, HWC, WARPED>(A);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -585,9 +582,6 @@ constexpr int FINALIZE_WAVES = 16;   // waves of the block that sums the loss pa
 
 __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const LossArgs A, float* __restrict__ loss5, const int n_pose_blocks) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#ifdef SFM_ABLATE_FINALIZE_EMPTY   // timing experiment only: the floor of this launch
-  if (A.gy != 12345.f) return;
-#endif
   if ((int)blockIdx.x < n_pose_blocks) {
     // d_pose of (b, i): every lane folds its tiles of every scale into K_s^T . gPm (linear), one in-register wave reduction (DPP).
     // A sample with many tiles (308 at cfg2, 376 at cfg5) is spread over the sixteen waves of the block, so that its partials are
@@ -771,6 +765,7 @@ struct Plan {
   size_t off_geom, off_loss, off_gpm, total;
   bool ssim, expl, hwc;
   bool wide;     // the three-waves-per-SIMD build of an L1 gradient kernel (see loss_kernel)
+  bool warped;   // the instantiation that also writes SfmLossDesc.warped
   int smode;
 };
 
@@ -789,7 +784,7 @@ static thread_local unsigned long long* g_trace = nullptr;   // sfm_loss_debug_t
 // and the 32-waves-per-CU cap allow more) and from the CU count of the device -- no occupancy query, nothing
 // that differs between a CPU-only host and the GPU box.
 template <bool GRAD, bool LOSS>
-static const void* kernel_ptr(bool ssim, bool expl, int smode, bool hwc, bool wide);
+static const void* kernel_ptr(bool ssim, bool expl, int smode, bool hwc, bool wide, bool warped);
 
 constexpr int MI355X_CUS = 256;   // 8 XCDs x 32 CUs (MI355X_MICROARCH.md); used when no device is visible
 
@@ -813,7 +808,9 @@ struct Tuning {
   int rows_list[SFM_MAX_SCALES] = {0};      // SFM_CHUNK_ROWS_LIST: chunk height per scale, "13,13,16,8"
   bool has_prio = false;
   unsigned prio_tab = 0;                    // SFM_PRIO_TABLE: "0123,3210" = levels of ranks 0.. in phase 1, phase 2
+  bool no_wide = false;                     // SFM_NO_WIDE: small L1 launches on the four-wave build too
   Tuning() {
+    no_wide = getenv("SFM_NO_WIDE") != nullptr;
     if (const char* e = getenv("SFM_CHUNK_ROWS")) chunk_rows = atoi(e);
     if (const char* rl = getenv("SFM_CHUNK_ROWS_LIST")) {
       for (int k = 0; *rl && k < SFM_MAX_SCALES; ++k) {
@@ -924,6 +921,14 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
       A.d_pose[i] = d->d_pose[i];
     }
   }
+  // the optional warped-image output: an array for every scale or for none
+  p.warped = false;
+  if (need_loss && need_outputs) {
+    int n_w = 0;
+    for (int s = 0; s < d->n_scales; ++s) n_w += d->warped[s] != nullptr;
+    if (n_w != 0 && n_w != d->n_scales) return fail(SFM_ERR_NULL, "sfm_loss: warped[] is set for %d of %d scales (all or none)", n_w, d->n_scales);
+    p.warped = n_w != 0;
+  }
   const int sw = strip_width(p.ssim, grad, p.smode);
   const int hs = p.ssim ? (grad ? 2 : 1) : 0;
   const int hm = p.smode == 1 ? 2 : (p.smode == 2 ? 1 : 0);
@@ -932,7 +937,7 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
     if (d->H[s] < 3 || d->W[s] < 3) return fail(SFM_ERR_SHAPE, "sfm_loss: scale %d is %dx%d, need H,W >= 3", s, d->H[s], d->W[s]);
   const int cus = device_cus();
   // (a launch is "small" when even at the smallest chunk height its waves fit the SIMDs three deep)
-  p.wide = grad && !p.ssim && !p.expl && !getenv("SFM_NO_WIDE") && max_items(d, sw) <= (long long)cus * 4 * 3;
+  p.wide = grad && !p.ssim && !p.expl && !tuning().no_wide && max_items(d, sw) <= (long long)cus * 4 * 3;
   const int waves_per_simd = waves_per_simd_of(p.ssim, grad, p.wide);
   const int slots = cus * 4 * waves_per_simd;
   A.simds_per_xcd = (cus % 8 == 0) ? cus / 8 * 4 : 128;   // gfx950: 8 XCDs, 4 SIMDs per CU
@@ -957,6 +962,7 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
     S.src = d->src[s];
     S.disp = d->disp[s];
     S.mlog = p.expl ? d->mask_logits[s] : nullptr;
+    S.warped = (need_loss && need_outputs) ? d->warped[s] : nullptr;
     if (grad && need_outputs) {
       if (!d->d_disp[s]) return fail(SFM_ERR_NULL, "sfm_loss: d_disp[%d] is NULL", s);
       if (p.expl && !d->d_mask[s]) return fail(SFM_ERR_NULL, "sfm_loss: exp_reg > 0 but d_mask[%d] is NULL", s);
@@ -1016,29 +1022,34 @@ static void bind_workspace(Plan& p, void* ws) {
 }
 
 template <bool GRAD, bool LOSS>
-static const void* kernel_ptr(bool ssim, bool expl, int smode, bool hwc, bool wide) {
+static const void* kernel_ptr(bool ssim, bool expl, int smode, bool hwc, bool wide, bool warped) {
+  // (WARPED only exists for the LOSS entry points: W = LOSS && warped is a constant false elsewhere, and those variants are not built)
+#define SFM_KPICK(NAME, ...)                                                                                              \
+  do {                                                                                                                    \
+    if constexpr (LOSS) {                                                                                                 \
+      if (warped) return hwc ? (const void*)&NAME<__VA_ARGS__, true, true> : (const void*)&NAME<__VA_ARGS__, false, true>; \
+    }                                                                                                                     \
+    return hwc ? (const void*)&NAME<__VA_ARGS__, true, false> : (const void*)&NAME<__VA_ARGS__, false, false>;            \
+  } while (0)
   if (GRAD && wide && !ssim && !expl) {
-#define SFM_KWIDE(SM) return hwc ? (const void*)&loss_kernel_wide<LOSS, SM, true> : (const void*)&loss_kernel_wide<LOSS, SM, false>
-    if (smode == 0) SFM_KWIDE(0);
-    else if (smode == 1) SFM_KWIDE(1);
-    else SFM_KWIDE(2);
-#undef SFM_KWIDE
+    if (smode == 0) SFM_KPICK(loss_kernel_wide, LOSS, 0);
+    else if (smode == 1) SFM_KPICK(loss_kernel_wide, LOSS, 1);
+    else SFM_KPICK(loss_kernel_wide, LOSS, 2);
   }
-#define SFM_KPTR(SS, EX, SM) return hwc ? (const void*)&loss_kernel<SS, GRAD, LOSS, EX, SM, true> : (const void*)&loss_kernel<SS, GRAD, LOSS, EX, SM, false>
   if (expl) {
-    if (smode == 0) SFM_KPTR(false, true, 0);
-    else if (smode == 1) SFM_KPTR(false, true, 1);
-    else SFM_KPTR(false, true, 2);
+    if (smode == 0) SFM_KPICK(loss_kernel, false, GRAD, LOSS, true, 0);
+    else if (smode == 1) SFM_KPICK(loss_kernel, false, GRAD, LOSS, true, 1);
+    else SFM_KPICK(loss_kernel, false, GRAD, LOSS, true, 2);
   } else if (ssim) {
-    if (smode == 0) SFM_KPTR(true, false, 0);
-    else if (smode == 1) SFM_KPTR(true, false, 1);
-    else SFM_KPTR(true, false, 2);
+    if (smode == 0) SFM_KPICK(loss_kernel, true, GRAD, LOSS, false, 0);
+    else if (smode == 1) SFM_KPICK(loss_kernel, true, GRAD, LOSS, false, 1);
+    else SFM_KPICK(loss_kernel, true, GRAD, LOSS, false, 2);
   } else {
-    if (smode == 0) SFM_KPTR(false, false, 0);
-    else if (smode == 1) SFM_KPTR(false, false, 1);
-    else SFM_KPTR(false, false, 2);
+    if (smode == 0) SFM_KPICK(loss_kernel, false, GRAD, LOSS, false, 0);
+    else if (smode == 1) SFM_KPICK(loss_kernel, false, GRAD, LOSS, false, 1);
+    else SFM_KPICK(loss_kernel, false, GRAD, LOSS, false, 2);
   }
-#undef SFM_KPTR
+#undef SFM_KPICK
 }
 
 template <bool GRAD, bool LOSS>
@@ -1049,7 +1060,7 @@ static hipError_t launch_main(const Plan& p, hipStream_t st, hipEvent_t ev_start
   int tiles_per_sample = 0;
   for (int s = 0; s < p.args.n_scales; ++s) tiles_per_sample += p.args.sc[s].tiles;
   const int per_xcd = p.args.B >= 8 ? (p.args.B / 8) * tiles_per_sample + ((p.args.B % 8) * tiles_per_sample + 7) / 8 : (p.args.items + 7) / 8;
-  const void* fn = kernel_ptr<GRAD, LOSS>(p.ssim, p.expl, p.smode, p.hwc, p.wide);
+  const void* fn = kernel_ptr<GRAD, LOSS>(p.ssim, p.expl, p.smode, p.hwc, p.wide, p.warped);
   // With profiling events the kernel is launched through hipExtLaunchKernel: the events then carry the begin / end
   // timestamps of THIS dispatch (what rocprofv3's kernel trace reports), and no marker packets are put between the
   // launches of a step (hipEventRecord on either side of the kernel costs the step several microseconds).

@@ -3,6 +3,7 @@
 // The multi-scale fused loss lives in sfm_loss.hip.  gfx950 only.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "sfm_common.h"
 
@@ -795,11 +796,27 @@ __global__ void __launch_bounds__(NT) pyramid_band_hwc_kernel(const BandArgs B) 
   }
 }
 
+// tuning overrides of the pyramid launch (development only), read from the environment ONCE per process
+struct PyramidTuning {
+  int band_rows = 0;     // SFM_PYRAMID_BAND_ROWS: input rows per band (LDS permitting)
+  int threads = 256;     // SFM_PYRAMID_THREADS: 256 or 512
+  PyramidTuning() {
+    if (const char* e = getenv("SFM_PYRAMID_BAND_ROWS")) band_rows = atoi(e);
+    if (const char* e = getenv("SFM_PYRAMID_THREADS")) threads = atoi(e);
+  }
+};
+static const PyramidTuning& pyramid_tuning() { static const PyramidTuning t; return t; }
+
+// sfm_pyramid_variant(): which kernel the NEXT pixel-interleaved pyramid call of this thread runs (then back to 0 = automatic)
+static thread_local int g_pyramid_variant = 0;
+
 // Launches the band kernel when its preconditions hold (returns false otherwise: the caller uses the per-pixel kernel).
 template <bool PAIR>
 static bool launch_pyramid_band(const PyramidArgs& A, int images, hipStream_t st) {
   const int H = A.H, W = A.W;
-  if (getenv("SFM_PYRAMID_PER_PIXEL")) return false;                      // A/B switch
+  const int variant = g_pyramid_variant;
+  g_pyramid_variant = 0;
+  if (variant == 1) return false;                                          // the per-pixel kernel was asked for
   if (H < 2 || W < 4 || (W & 3)) return false;
   uintptr_t al = (uintptr_t)A.x | (uintptr_t)A.y[0];
   if (PAIR) al |= (uintptr_t)A.x2 | (uintptr_t)A.y2[0];
@@ -808,18 +825,14 @@ static bool launch_pyramid_band(const PyramidArgs& A, int images, hipStream_t st
   int band_rows = lds_budget / (12 * W) - 1;
   if (band_rows < 1) return false;
   if (band_rows > 8) band_rows = 8;
-  if (const char* e = getenv("SFM_PYRAMID_BAND_ROWS")) {                   // tuning: rows per band (LDS permitting)
-    const int v = atoi(e);
-    if (v >= 1 && (size_t)3 * (v + 1) * W * sizeof(float) <= 64 * 1024) band_rows = v;
-  }
+  const PyramidTuning& T = pyramid_tuning();
+  if (T.band_rows >= 1 && (size_t)3 * (T.band_rows + 1) * W * sizeof(float) <= 64 * 1024) band_rows = T.band_rows;
   BandArgs B;
   B.P = A;
   B.band_rows = band_rows;
   B.n_bands = (H + band_rows - 1) / band_rows;
   const size_t lds = (size_t)3 * (band_rows + 1) * W * sizeof(float);
-  int nt = 256;
-  if (const char* e = getenv("SFM_PYRAMID_THREADS")) nt = atoi(e);       // tuning
-  if (nt == 512) hipLaunchKernelGGL((pyramid_band_hwc_kernel<PAIR, 512>), dim3(B.n_bands, images), dim3(512), lds, st, B);
+  if (T.threads == 512) hipLaunchKernelGGL((pyramid_band_hwc_kernel<PAIR, 512>), dim3(B.n_bands, images), dim3(512), lds, st, B);
   else hipLaunchKernelGGL((pyramid_band_hwc_kernel<PAIR, 256>), dim3(B.n_bands, images), dim3(256), lds, st, B);
   return true;
 }
@@ -1034,6 +1047,12 @@ int sfm_sampler_interp_bwd(const float* x, const float* grid, const float* gy, f
   hipLaunchKernelGGL(interp_bwd_kernel, dim3((oH * oW + 255) / 256, N), dim3(256), 0, (hipStream_t)stream, x, grid, gy, ggrid, C,
                      H, W, oH * oW);
   return check_launch("sfm_sampler_interp_bwd");
+}
+
+int sfm_pyramid_variant(int variant) {
+  SFM_REQUIRE(variant >= 0 && variant <= 1, SFM_ERR_CONFIG, "sfm_pyramid_variant: %d (0 = automatic, 1 = per-pixel kernel)", variant);
+  sfm::g_pyramid_variant = variant;
+  return SFM_OK;
 }
 
 int sfm_pyramid_fwd(const float* x, float* const* y, int N, int C, int H, int W, int n_scales, void* stream) {

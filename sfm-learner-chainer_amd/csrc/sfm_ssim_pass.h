@@ -45,6 +45,7 @@ struct SsimCtx {
   const float* sp[3];   // source planes of this (sample, source)
   const float* dp;      // disparity plane
   float* dsp;           // d_src planes of this (sample, source) or nullptr
+  float* wp;            // planes of the optional warped-image output of this (sample, source), or nullptr   base_model.py:90-94
   const float* mp;      // explainability logits of this (sample, source) or nullptr     base_model.py:104
   float* dmp;           // their gradient plane or nullptr
   float k_exp;          // gy * exp_reg / (norm_B h w)                                  base_model.py:105,167
@@ -269,35 +270,17 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
     UV.x = p.U; UV.y = p.V; fr.x = p.fu; fr.y = p.fv; rz = p.rz;
   }
   ps.UV = UV; ps.f = fr;
-#ifndef SFM_GATHER_GLOBAL
   if constexpr (HWC) {
     // (nothing of the masks crosses the step: out-of-view taps arrive as zeros, and 1/z is masked here)
     ps.rz = (p.inview && C.outb) ? rz : 0.f;
     ps.inview = ps.inview_o = true;
-  } else
-#endif
-  {
+  } else {
     ps.rz = rz;
     ps.inview = p.inview && C.xin;
     ps.inview_o = p.inview && C.outb;
   }
-#ifdef SFM_ABLATE_MEM   // timing experiment only: every access hits the same few cache lines
-  const unsigned off = (unsigned)((p.v0 * C.w + p.u0) & 63);
-  const unsigned offt = (unsigned)((r * C.w + C.xc) & 63);
-#elif defined(SFM_ABLATE_ALIGN)   // timing experiment only: 8-byte aligned taps
-  const unsigned off = (unsigned)(p.v0 * C.w + p.u0) & ~1u;
-  const unsigned offt = (unsigned)r * (unsigned)C.w + C.xc;
-#else
   const unsigned off = (unsigned)(p.v0 * C.w + p.u0);
   const unsigned offt = (unsigned)r * (unsigned)C.w + C.xc;
-#endif
-#ifdef SFM_ABLATE_NOLOAD   // timing experiment only (wrong values): no vector memory loads in the row loop at all
-  {
-    const float f = __uint_as_float(0x3f800000u | (off & 0xffffu)), g = __uint_as_float(0x3f800000u | (offt & 0xffffu));
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { ps.ta[c] = f; ps.tb[c] = f + 0.25f * c; ps.ba[c] = f * 0.5f; ps.bb[c] = f - 0.125f * c; ps.it[c] = g + c; }
-  }
-#else
   if constexpr (HWC) {
     // Byte offset of the top-left tap, 12 (v0 w + u0), formed in FLOAT from the integer parts U - fu, V - fv (exact: an image has
     // fewer than 2^24 bytes, make_plan checks) and converted once: two full-rate subtractions, a multiply and a multiply-add
@@ -306,11 +289,6 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
     // row below is the same address + 12 w.
     const f2 cell = UV - fr;
     const float bof = fmaf(cell.y, C.w12f, cell.x * 12.f);
-#ifdef SFM_GATHER_GLOBAL   // the round-2 form: global loads, out-of-view lanes fetch texel 0 and are masked afterwards
-    const unsigned o12 = p.inview ? (unsigned)bof : 0u;
-    const Rgb2 T = ld_off<Rgb2>(C.sp[0], o12), Bt = ld_off<Rgb2>(C.sp[0], o12 + C.w12);
-    const Rgb I = ld_off<Rgb>(C.tp[0], (unsigned)r * C.w12 + C.xc12);
-#else
     // Range-checked buffer loads (MUBUF, raw descriptor): a lane whose offset is not below num_records gets ZEROS.
     //  * source taps: num_records = the image; a lane that is not in view is given an offset outside it, so all its taps are 0 and
     //    with them the value and both derivatives -- no select per channel in finish_row (base_model.py:96's mask wants exactly 0);
@@ -340,23 +318,17 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
     Bt.c[0] = __uint_as_float(b0.x); Bt.c[1] = __uint_as_float(b0.y); Bt.c[2] = __uint_as_float(b0.z); Bt.c[3] = __uint_as_float(b0.w);
     Bt.c[4] = __uint_as_float(b1.x); Bt.c[5] = __uint_as_float(b1.y);
     I.c[0] = __uint_as_float(i0.x); I.c[1] = __uint_as_float(i0.y); I.c[2] = __uint_as_float(i0.z);
-#endif
     (void)off; (void)offt;
 #pragma unroll
     for (int c = 0; c < 3; ++c) { ps.ta[c] = T.c[c]; ps.tb[c] = T.c[3 + c]; ps.ba[c] = Bt.c[c]; ps.bb[c] = Bt.c[3 + c]; ps.it[c] = I.c[c]; }
   } else {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-#ifdef SFM_TAP_DWORDS
-      const Tap2 t = load_tap2(C.sp[c] + off), b = load_tap2(C.sp[c] + off + (unsigned)C.w);
-#else
       const Tap2 t = ld_off<Tap2>(C.sp[c], 4u * off), b = ld_off<Tap2>(C.sp[c], 4u * (off + (unsigned)C.w));
-#endif
       ps.ta[c] = t.a; ps.tb[c] = t.b; ps.ba[c] = b.a; ps.bb[c] = b.b;
       ps.it[c] = ldf(C.tp[c], offt);
     }
   }
-#endif
   if (C.mp != nullptr) ps.lg = ldf(C.mp, offt);
 }
 
@@ -393,6 +365,20 @@ __device__ __forceinline__ void finish_row(const SsimCtx& C, const Pipe& ps, Row
     const float big = 0x1p127f;
     const float mag = __uint_as_float(nz & 0x7fffffffu);
     asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(s.nm) : "v"(mag), "s"(big));
+  }
+}
+
+// Optional output (SfmLossDesc.warped): the warped image I^ of row r, as the loss sees it (curr_proj_img, base_model.py:90-94;
+// exactly 0 where the sample is not in view) -- the output lanes of the rows of this wave's chunk, written through the L2.
+// Compiled into the WARPED instantiations only (picked by the host when the descriptor asks for the output): the kernels of a
+// launch without it are instruction for instruction what they were -- this kernel sits at its register limit, and two more live
+// scalar registers in the row loop showed up as 14 more scalar spills into vector-register lanes.
+__device__ __forceinline__ void store_warped_row(const SsimCtx& C, const int r, const RowS& s) {
+  if ((unsigned)(r - C.y0) < (unsigned)(C.y1 - C.y0) && C.outb) {
+    const unsigned o = (unsigned)r * (unsigned)C.w + C.xc;
+    stf_wt(C.wp, o, s.ih.p.x);
+    stf_wt(C.wp + C.P, o, s.ih.p.y);
+    stf_wt(C.wp + 2 * C.P, o, s.ih.s);
   }
 }
 
@@ -571,10 +557,7 @@ __device__ __forceinline__ void ssim_stage_b_row(const SsimCtx& C, const RowS& s
   if (LOSS) {
     const float wgt = count ? s1.nm * C.outf : 0.f;
     acc_ssim = fmaf(ssum, wgt, acc_ssim);                            // base_model.py:114-115
-#ifndef SFM_L1_LOSS_IN_B
-    if (!GRAD)                                                       // (with gradients stage C adds this term: it forms I^ - I anyway)
-#endif
-    {
+    if (!GRAD) {                                                     // (with gradients stage C adds this term: it forms I^ - I anyway)
       const float e1 = vabs_sum(s1.ih.p - s1.it.p) + vabs_sum(s1.ih.s - s1.it.s);   // :95
       acc_pix = fmaf(e1, wgt, acc_pix);                              // :98-100,:111
     }
@@ -583,19 +566,10 @@ __device__ __forceinline__ void ssim_stage_b_row(const SsimCtx& C, const RowS& s
 
 // dL/dI^ of the three channels (gp: channels 0, 1; gs: channel 2) contracted with dI^/du, dI^/dv and 1/z: (dL/dq0, dL/dq1) as a pair
 __device__ __forceinline__ f2 contract_uv(const RowS& s, const f2 gp, const float gs) {
-#ifdef SFM_CONTRACT_HADD   // the round-2 form: channels 0, 1 as a pair against (du0, du1) and (dv0, dv1), then two horizontal adds
-  f2 dup, dvp;
-  dup.x = s.duv0.x; dup.y = s.duv1.x; dvp.x = s.duv0.y; dvp.y = s.duv1.y;
-  const f2 pu = gp * dup, pv = gp * dvp;
-  f2 hq;
-  hq.x = pu.x + pu.y; hq.y = pv.x + pv.y;
-  return vfma(T_of<f2>(gs), s.duv_s, hq) * s.rzi;
-#else
   f2 hq = T_of<f2>(gp.x) * s.duv0;
   hq = vfma(T_of<f2>(gp.y), s.duv1, hq);
   hq = vfma(T_of<f2>(gs), s.duv_s, hq);
   return hq * s.rzi;
-#endif
 }
 
 // Stage C at row rc (the row in s2; partials of the rows rc-1, rc, rc+1 in g2, g1, g0): dL/dI^ -> dL/d(u,v) -> dL/dq -> d_depth
@@ -608,11 +582,9 @@ __device__ __forceinline__ void ssim_stage_c_row(const SsimCtx& C, const int rc,
   float gs, ds;
   ssim_stage_c(g2.a.p, g1.a.p, g0.a.p, g2.b.p, g1.b.p, g0.b.p, g2.e.p, g1.e.p, g0.e.p, s2.ih.p, s2.it.p, kpn, gp, dp);
   ssim_stage_c(g2.a.s, g1.a.s, g0.a.s, g2.b.s, g1.b.s, g0.b.s, g2.e.s, g1.e.s, g0.e.s, s2.ih.s, s2.it.s, kpn, gs, ds);
-#ifndef SFM_L1_LOSS_IN_B
   // the L1 term of this row (base_model.py:95-100,:111): stage C runs on exactly the rows whose loss terms belong to this wave,
   // and I^ - I is at hand (with the fused kernel stage B would form it a second time, one row earlier)
   if (LOSS) acc_pix = fmaf(vabs_sum(dp) + vabs_sum(ds), s2.nm * C.outf, acc_pix);
-#endif
   const float gI[3] = {gp.x, gp.y, gs};
   geometry_backward(C, s2, rc, contract_uv(s2, gp, gs), gI, gacc, first, gpm);
 }
@@ -636,7 +608,7 @@ __device__ __forceinline__ unsigned step_range(int lo, int hi) {   // bits lo ..
 }
 __device__ __forceinline__ bool step_bit(const unsigned m, const int k) { return ((m >> k) & 1u) != 0u; }
 
-template <bool GRAD, bool LOSS, bool HWC>
+template <bool GRAD, bool LOSS, bool HWC, bool WARPED>
 __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const StepMasks& M, const int k, const int r, Pipe& ps, float& disp_next,
                                               RowS& s0, const RowS& s1, const RowS& s2,
                                               RowG& g0, const RowG& g1, const RowG& g2, float* gacc, const bool first,
@@ -646,19 +618,12 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const StepMasks&
   unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
 #endif
   SFM_STAMP(t0);
-#ifdef SFM_EXTRA_SALU   // timing experiment only: what a scalar instruction costs the row step
-#pragma unroll
-  for (int q = 0; q < SFM_EXTRA_SALU; ++q) asm volatile("s_cmp_eq_u32 0, 0" ::: "scc");
-#endif
   // ---------------- A: finish row r, put row r+1 in flight ----------------
   // (the arithmetic always runs -- on whatever the tap registers hold when the row lies outside the image -- and the rare case
   // overwrites the slot: an if / else costs five more scalar instructions per step than an if)
-#ifdef SFM_GATHER_GLOBAL
-  finish_row<false>(C, ps, s0);
-#else
   finish_row<HWC>(C, ps, s0);
-#endif
   if (!step_bit(M.fin, k)) zero_rare(s0);
+  if constexpr (WARPED) store_warped_row(C, r, s0);
   SFM_STAMP(t1);
   if (step_bit(M.iss, k)) {
     issue_row<HWC>(C, r + 1, disp_next, ps);
@@ -671,22 +636,14 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const StepMasks&
   // The first two steps of a pass only fill the ring: their centre rows lie above every row whose SSIM value
   // (forward) or SSIM partials (gradient, one more row) anything will read, so the whole stage is skipped
   // (wave-uniform branch).
-#ifdef SFM_ABLATE_NO_B   // timing experiment only (wrong values)
-  if (false) {
-#else
   if (step_bit(M.b, k)) {
-#endif
     ssim_stage_b_row<GRAD, LOSS>(C, s2, s1, s0, g0, step_bit(M.cnt, k), acc_pix, acc_ssim);
   }
 
   SFM_STAMP(t3);
   // ---------------- C: gradients at row r-2 ----------------
   if (GRAD) {
-#ifdef SFM_ABLATE_NO_C   // timing experiment only (wrong values)
-    if (false) {
-#else
     if (step_bit(M.c, k)) {
-#endif
       ssim_stage_c_row<LOSS>(C, r - 2, s2, g2, g1, g0, gacc, first, gpm, acc_pix);
     }
   }
@@ -697,14 +654,10 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const StepMasks&
 }
 
 // One source of one wave.  HS = halo of this pass (2 with gradients, 1 forward only).
-template <bool GRAD, bool LOSS, bool HWC>
+template <bool GRAD, bool LOSS, bool HWC, bool WARPED>
 __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, const bool first, float& acc_pix, float& acc_ssim,
                                                  float* gpm_out /* 12 floats in global memory, or nullptr */ SFM_STAMPS_ARG) {
-#ifdef SFM_ABLATE_HALO   // timing experiment only (wrong values): no halo rows recomputed above / below the chunk
-  constexpr int HS = 0;
-#else
   constexpr int HS = GRAD ? 2 : 1;
-#endif
   const int rbeg = C.y0 - HS, rend = C.y1 + HS;
   const int rload = min(rend, C.h);   // rows below are neither inside the image nor part of this pass: never fetched
   PoseAcc gpm;    // A_k, B_k, C_k of geometry_backward
@@ -731,18 +684,18 @@ __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, 
   disp_next = C.disp_second;
   for (int k = 0; k < n; k += 3) {
     const int r = rbeg + k;
-    ssim_row_step<GRAD, LOSS, HWC>(C, M, k, r, ps, disp_next, S0, S2, S1, G0, G2, G1, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
+    ssim_row_step<GRAD, LOSS, HWC, WARPED>(C, M, k, r, ps, disp_next, S0, S2, S1, G0, G2, G1, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
     if (k + 1 < n)
-      ssim_row_step<GRAD, LOSS, HWC>(C, M, k + 1, r + 1, ps, disp_next, S1, S0, S2, G1, G0, G2, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
+      ssim_row_step<GRAD, LOSS, HWC, WARPED>(C, M, k + 1, r + 1, ps, disp_next, S1, S0, S2, G1, G0, G2, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
     if (k + 2 < n)
-      ssim_row_step<GRAD, LOSS, HWC>(C, M, k + 2, r + 2, ps, disp_next, S2, S1, S0, G2, G1, G0, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
+      ssim_row_step<GRAD, LOSS, HWC, WARPED>(C, M, k + 2, r + 2, ps, disp_next, S2, S1, S0, G2, G1, G0, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
   }
   if (GRAD) pose_sums_expand(C, gpm, gpm_out);
 }
 
 // Photometric pass WITHOUT SSIM for one (wave, source): L1 (+ explainability weighting, base_model.py:103-109).
 // Everything is per pixel, so there is no ring; the loads of row r+1 are in flight while row r is finished.
-template <bool GRAD, bool LOSS, bool EXPL, bool HWC>
+template <bool GRAD, bool LOSS, bool EXPL, bool HWC, bool WARPED>
 __device__ __forceinline__ void l1_source_pass(const SsimCtx& C, float* gacc, const bool first, float& acc_pix, float& acc_exp,
                                                float* gpm_out) {
   PoseAcc gpm;    // A_k, B_k, C_k of geometry_backward
@@ -755,11 +708,8 @@ __device__ __forceinline__ void l1_source_pass(const SsimCtx& C, float* gacc, co
   if (rbeg + 1 < rend) disp_next = C.disp_second;
   for (int r = rbeg; r < rend; ++r) {
     RowS s0;
-#ifdef SFM_GATHER_GLOBAL
-    finish_row<false>(C, ps, s0);
-#else
     finish_row<HWC>(C, ps, s0);
-#endif
+    if constexpr (WARPED) store_warped_row(C, r, s0);
     const float lg = ps.lg;
     if (r + 1 < rend) issue_row<HWC>(C, r + 1, disp_next, ps);
     disp_next = ldf(C.dp, (unsigned)min(r + 2, C.h - 1) * (unsigned)C.w + C.xc);

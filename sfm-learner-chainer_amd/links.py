@@ -58,7 +58,30 @@ class _FusedLossFunction(Function):
 
 class _Cached:
     """What one link keeps between calls for one set of shapes."""
-    __slots__ = ("fused", "pyr", "graph", "graph_key", "graph_stream", "calls")
+    __slots__ = ("fused", "pyr", "layout", "graph", "graph_key", "graph_stream", "calls")
+
+
+# SFM_LAYOUT_HWC forms the byte offset of a gather inside one image exactly in fp32 (include/sfmwarp.h): an image of a scale
+# must have fewer than 2^24 / 12 pixels there.  Larger frames take the reference's planar layout (same results).
+HWC_MAX_PIXELS = (1 << 24) // 12
+
+
+def _build_pyramids(st, tgt, stacked, n_scales):
+    """models/base_model.py:69-72: curr_tgt_img / curr_src_imgs of every scale into the buffers the bound loss reads."""
+    if st.layout == "hwc":
+        # ONE launch for both tensors, written pixel-interleaved (the layout the fused loss kernels fetch with the fewest loads;
+        # values identical to the planar pyramid)
+        st.pyr = ops.pyramid_pair_hwc(tgt, stacked, n_scales, out=st.pyr)
+        return
+    # planar: scales 1.. in one launch per tensor; scale 0 is the frame itself, copied into the bound buffer when the caller's
+    # array is not the one the descriptor was bound to
+    if st.pyr is None:
+        st.pyr = (ops.pyramid(tgt.clone(), n_scales), ops.pyramid(stacked.clone(), n_scales))
+        return
+    for x, pyr in ((tgt, st.pyr[0]), (stacked, st.pyr[1])):
+        if x.data_ptr() != pyr[0].data_ptr():
+            pyr[0].copy_(x)
+        ops.pyramid(pyr[0], n_scales, out=pyr)
 
 
 class SFMLearnerLoss:
@@ -95,10 +118,12 @@ class SFMLearnerLoss:
         st = self._cache.get(key) if self.cache_buffers else None
         if st is None:
             st = _Cached()
-            st.pyr = ops.pyramid_pair_hwc(tgt, stacked, len(disps))
+            st.layout = "hwc" if tgt.shape[2] * tgt.shape[3] < HWC_MAX_PIXELS else "planar"
+            st.pyr = None
+            _build_pyramids(st, tgt, stacked, len(disps))
             st.fused = ops.FusedLoss(smooth_reg=self.smooth_reg or 0.0, exp_reg=self.exp_reg or 0.0,
                                      ssim_rate=self.ssim_rate or 0.0, smooth_mode=self.smooth_mode)
-            st.fused.bind(st.pyr[0], st.pyr[1], intrinsics, disps, poses, masks, norm_B=norm_batch, layout="hwc")
+            st.fused.bind(st.pyr[0], st.pyr[1], intrinsics, disps, poses, masks, norm_B=norm_batch, layout=st.layout)
             st.graph = st.graph_key = st.graph_stream = None
             st.calls = 0
             if self.cache_buffers:
@@ -143,9 +168,7 @@ class SFMLearnerLoss:
         if self.use_graph and self.cache_buffers:
             run = self._graph_step(st, tgt, stacked_src_imgs, n_scales, need_grad, fresh)
         if run is None and not fresh:
-            # :69-72 -- curr_tgt_img / curr_src_imgs of every scale, ONE launch for both tensors, written pixel-interleaved
-            # (the layout the fused loss kernels fetch with the fewest loads; values identical to the planar pyramid)
-            ops.pyramid_pair_hwc(tgt, stacked_src_imgs, n_scales, out=st.pyr)
+            _build_pyramids(st, tgt, stacked_src_imgs, n_scales)                # :69-72
         st.calls += 1
         node = _FusedLossFunction(fused, n_scales, n_sources, do_exp, need_grad, run, st if self.cache_buffers else None)
         total_loss = node(*inputs)
@@ -173,7 +196,7 @@ class SFMLearnerLoss:
         side.wait_stream(torch.cuda.current_stream(tgt.device))
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=side):
-            ops.pyramid_pair_hwc(tgt, stacked, n_scales, out=st.pyr)
+            _build_pyramids(st, tgt, stacked, n_scales)
             f.forward_backward() if need_grad else f.forward()
         torch.cuda.current_stream(tgt.device).wait_stream(side)
         st.graph = g

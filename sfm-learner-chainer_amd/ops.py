@@ -162,13 +162,20 @@ def resize(x, out_hw):
     return y
 
 
-def pyramid(x, n_scales):
-    """[x, resize(x, (H>>1, W>>1)), ...]: all scales of models/base_model.py:69-72 in one launch."""
+def pyramid(x, n_scales, out=None):
+    """[x, resize(x, (H>>1, W>>1)), ...]: all scales of models/base_model.py:69-72 in one launch.
+    `out`: the list an earlier call with the same shapes returned -- scales 1.. are written in place and scale 0 becomes `x`
+    (a caller that needs scale 0 at a fixed address copies it)."""
     x = _dev(x, "x", 4)
     N, Cc, H, W = x.shape
     if not 1 <= n_scales <= _lib.SFM_MAX_SCALES:
         raise TypeError("n_scales must be in [1, %d]" % _lib.SFM_MAX_SCALES)
-    outs = [x] + [torch.empty((N, Cc, H >> s, W >> s), dtype=torch.float32, device=x.device) for s in range(1, n_scales)]
+    if out is not None:
+        if len(out) != n_scales or any(tuple(out[s].shape) != (N, Cc, H >> s, W >> s) for s in range(n_scales)):
+            raise TypeError("pyramid: `out` does not match the input")
+        outs = [x] + list(out[1:])
+    else:
+        outs = [x] + [torch.empty((N, Cc, H >> s, W >> s), dtype=torch.float32, device=x.device) for s in range(1, n_scales)]
     ptrs = (C.c_void_p * n_scales)(*[t.data_ptr() for t in outs])
     with torch.cuda.device(x.device):
         check(lib.sfm_pyramid_fwd(_p(x), ptrs, N, Cc, H, W, n_scales, _stream()))
@@ -192,10 +199,11 @@ def pyramid_hwc(x, n_scales):
     return outs
 
 
-def pyramid_pair_hwc(tgt, src, n_scales, out=None):
+def pyramid_pair_hwc(tgt, src, n_scales, out=None, per_pixel=False):
     """Both pixel-interleaved pyramids of a step in one launch: tgt (N,3,H,W), src (N,3*n_src,H,W) ->
     ([tgt_s (N,1,h,w,3)], [src_s (N,n_src,h,w,3)]) -- the loop head models/base_model.py:69-72.
-    `out` = (yt, ys) of an earlier call with the same shapes: written in place instead of allocating."""
+    `out` = (yt, ys) of an earlier call with the same shapes: written in place instead of allocating.
+    `per_pixel`: run the one-thread-per-output-pixel kernel instead of the band kernel (same values bit for bit; A/B tests)."""
     tgt, src = _dev(tgt, "tgt", 4), _dev(src, "src", 4)
     N, Ct, H, W = tgt.shape
     if Ct != 3 or src.shape[0] != N or tuple(src.shape[2:]) != (H, W) or src.shape[1] % 3 != 0 or src.shape[1] == 0:
@@ -211,6 +219,8 @@ def pyramid_pair_hwc(tgt, src, n_scales, out=None):
         yt = [torch.empty((N, 1, H >> s, W >> s, 3), dtype=torch.float32, device=tgt.device) for s in range(n_scales)]
         ys = [torch.empty((N, n_src, H >> s, W >> s, 3), dtype=torch.float32, device=tgt.device) for s in range(n_scales)]
     with torch.cuda.device(tgt.device):
+        if per_pixel:
+            check(lib.sfm_pyramid_variant(1))
         check(lib.sfm_pyramid_pair_hwc_fwd(_p(tgt), _p(src), _ptr_array(yt), _ptr_array(ys), N, n_src, H, W, n_scales, _stream()))
     return yt, ys
 
@@ -262,9 +272,12 @@ class FusedLoss:
         self.desc = None
         self._keep = None
 
-    def bind(self, tgt_pyr, src_pyr, intrinsics, disps, poses, masks=None, norm_B=None, want_d_src=False, layout="planar"):
+    def bind(self, tgt_pyr, src_pyr, intrinsics, disps, poses, masks=None, norm_B=None, want_d_src=False, layout="planar",
+             want_warped=False):
         """layout: "planar" -- tgt (B,3,h,w), src (B,3*n_src,h,w) as in the reference; "hwc" -- tgt (B,1,h,w,3),
-        src (B,n_src,h,w,3) as written by `pyramid_hwc` (the faster layout for these kernels; same results)."""
+        src (B,n_src,h,w,3) as written by `pyramid_hwc` (the faster layout for these kernels; same results).
+        want_warped: `forward` / `forward_backward` also write `self.warped[s]` (B,n_src,3,h,w), the warped source images the
+        loss was computed on (curr_proj_img, models/base_model.py:90-94; planar in both layouts)."""
         if layout not in ("planar", "hwc"):
             raise ValueError("layout must be 'planar' or 'hwc', got %r" % (layout,))
         hwc = layout == "hwc"
@@ -293,7 +306,7 @@ class FusedLoss:
         d.smooth_reg, d.exp_reg, d.ssim_rate, d.smooth_mode = self.smooth_reg, self.exp_reg, self.ssim_rate, self.smooth_mode
         d.intrinsics = intrinsics.data_ptr()
         d.image_layout = _lib.SFM_LAYOUT_HWC if hwc else _lib.SFM_LAYOUT_PLANAR
-        d_disps, d_masks, d_srcs = [], [], []
+        d_disps, d_masks, d_srcs, warped = [], [], [], []
         for s in range(S):
             h, w = disps[s].shape[2:]
             if hwc:
@@ -316,6 +329,9 @@ class FusedLoss:
             if want_d_src:      # always planar
                 d_srcs.append(torch.zeros((B, 3 * n_src, h, w), dtype=torch.float32, device=dev))
                 d.d_src[s] = d_srcs[-1].data_ptr()
+            if want_warped:     # always planar
+                warped.append(torch.empty((B, n_src, 3, h, w), dtype=torch.float32, device=dev))
+                d.warped[s] = warped[-1].data_ptr()
         d_poses = []
         for i in range(n_src):
             if tuple(poses[i].shape) != (B, 6):
@@ -336,6 +352,7 @@ class FusedLoss:
         self._desc_ref, self._ws_arg, self._loss5_arg = C.byref(d), C.c_void_p(self._ws_ptr), _p(self.loss5)
         self.d_disps, self.d_poses, self.d_masks, self.d_srcs = d_disps, d_poses, (d_masks if use_masks else None), \
             (d_srcs if want_d_src else None)
+        self.warped = warped if want_warped else None
         self._keep = (tgt_pyr, src_pyr, intrinsics, disps, poses, masks)
         return self
 

@@ -29,10 +29,12 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_descriptor_layout_matches_the_header():
-    # 4 + 8 + 8 int32, 3 float, 1 int32, then 4*8 + 1 + 8 + 8 + 8 + 8 + 8 pointers, then image_layout (int32, padded to 8)
-    assert C.sizeof(_lib.SfmLossDesc) == 4 * (4 + 8 + 8 + 3 + 1) + 8 * (8 * 4 + 1 + 8 + 8 * 3 + 8) + 8
+    # 4 + 8 + 8 int32, 3 float, 1 int32, then 4*8 + 1 + 8 + 8 + 8 + 8 + 8 pointers, then image_layout (int32, padded to 8),
+    # then the 8 pointers of `warped` (ABI v4)
+    assert C.sizeof(_lib.SfmLossDesc) == 4 * (4 + 8 + 8 + 3 + 1) + 8 * (8 * 4 + 1 + 8 + 8 * 3 + 8) + 8 + 8 * 8
     assert _lib.SfmLossDesc.tgt.offset % 8 == 0
-    assert _lib.SfmLossDesc.image_layout.offset == C.sizeof(_lib.SfmLossDesc) - 8
+    assert _lib.SfmLossDesc.image_layout.offset == C.sizeof(_lib.SfmLossDesc) - 8 - 8 * 8
+    assert _lib.SfmLossDesc.warped.offset == C.sizeof(_lib.SfmLossDesc) - 8 * 8
 
 
 def _desc(**kw):

@@ -39,8 +39,9 @@ def test_loss_kernels_fit_their_register_budget(tmp_path):
             kernels[name][m.group(1).strip()] = int(m.group(2))
     loss = {k: v for k, v in kernels.items() if "loss_kernel" in k}
     # {fwd, bwd, fused} x {l1, ssim, explain} x {no, 2nd-order, edge-aware smoothness} x {planar, hwc}, and the L1 gradient kernels
-    # ({bwd, fused} x 3 x 2) a second time for three waves per SIMD (loss_kernel_wide: small launches)
-    assert len(loss) == 54 + 12
+    # ({bwd, fused} x 3 x 2) a second time for three waves per SIMD (loss_kernel_wide: small launches); the {fwd, fused} ones of both
+    # kinds once more with the warped-image output (SfmLossDesc.warped, ABI v4): 36 + 6
+    assert len(loss) == 54 + 12 + 36 + 6
     for k, v in kernels.items():
         assert v["VGPRs Spill"] == 0, (k, v)
         # no frame at all, in any variant: scalar registers that do not fit are parked in vector-register lanes (counted in the
@@ -53,10 +54,10 @@ def test_loss_kernels_fit_their_register_budget(tmp_path):
 
 @pytest.mark.timeout(600)
 def test_committed_issue_model_is_the_one_of_these_sources():
-    """bench.py's `roofline_valu` prices the counted vector instructions with profiles/r03_issue_model.json: the file must be the
+    """bench.py's `roofline_valu` prices the counted vector instructions with profiles/r04_issue_model.json: the file must be the
     model of the kernels as they are in the tree (tools/issue_model.py --check recompiles and compares)."""
     import sys
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "issue_model.py"), "r03", "--check"], capture_output=True, text=True, timeout=580)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "issue_model.py"), "r04", "--check"], capture_output=True, text=True, timeout=580)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])

@@ -163,7 +163,7 @@ def test_bench_workloads_follow_baseline_json():
     assert 'default="cfg3_edge"' in default
     Be, He, We, ne, se, cfge, desc = bench.WORKLOADS["cfg3_edge"]
     assert (Be, He, We, ne, se) == (32, 128, 416, 2, 4) and cfge["smooth_mode"] == "edge_aware" and cfge["ssim_rate"] == 0.15
-    assert bench.kernel_symbol(cfge, "hwc", "fused") == "void sfm::loss_kernel<true, true, true, false, 2, true>(sfm::LossArgs)"
+    assert bench.kernel_symbol(cfge, "hwc", "fused") == "void sfm::loss_kernel<true, true, true, false, 2, true, false>(sfm::LossArgs)"
 
 
 def test_augmentation_parameters_follow_the_reference_rng_order():

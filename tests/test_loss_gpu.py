@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 
 from oracle import sfm_oracle as O
+from oracle.parity import knife_mask, rel_l2
 from util import assert_close_masked, dilate, parity_note, to_dev, to_np
 
 pytestmark = pytest.mark.gpu
@@ -27,7 +28,7 @@ def _oracle(d, cfg, norm_B=None, want_d_src=False):
                       backward=True, want_d_src=want_d_src, keep_warped=True, norm_batch=norm_B, **cfg)
 
 
-def _bind(ops, dev, d, cfg, norm_B=None, want_d_src=False, layout="planar"):
+def _bind(ops, dev, d, cfg, norm_B=None, want_d_src=False, layout="planar", want_warped=False):
     fl = ops.FusedLoss(**cfg)
     tgt, src = [to_dev(a, dev) for a in d["tgt_pyr"]], [to_dev(a, dev) for a in d["src_pyr"]]
     if layout == "hwc":      # the same values, pixel-interleaved (SFM_LAYOUT_HWC)
@@ -35,8 +36,57 @@ def _bind(ops, dev, d, cfg, norm_B=None, want_d_src=False, layout="planar"):
     fl.bind(tgt, src, to_dev(d["intrinsics"], dev), [to_dev(a, dev) for a in d["disps"]],
             [to_dev(a, dev) for a in d["poses"]],
             [to_dev(a, dev) for a in d["masks"]] if d["masks"] is not None else None,
-            norm_B=norm_B, want_d_src=want_d_src, layout=layout)
+            norm_B=norm_B, want_d_src=want_d_src, layout=layout, want_warped=want_warped)
     return fl
+
+
+WARP_TOL = 1e-4      # north_star: warped pixels within 1e-4 (of the image range, [-1, 1]) of the reference
+FLIP_THR = 8e-6      # |x_n| within this of 1: the strict `-1 < x < 1` test (transform.py:129) is decided by the last bits
+
+
+def _check_warped(fl, ref, what, ref64=None):
+    """The warped images the FUSED kernel computed its loss on (SfmLossDesc.warped, written by the kernel that is benchmarked)
+    against the oracle's curr_proj_img (models/base_model.py:90-94), pixel for pixel:
+      * the sets of exactly-zero (not in view, :96) pixels agree except at pixels the ORACLE places within FLIP_THR of the strict
+        in-view test -- those that differ are counted and printed;
+      * everywhere else |I^ - I^_oracle| <= WARP_TOL of the image range.  `ref64` (callable -> fp64 oracle result with `warped`):
+        consulted only if a pixel misses that -- where the projection is ill-conditioned (|z| small: the sample position is a
+        quotient of two small numbers) the fp32 oracle itself is off, and the kernel may be off by 3x the fp32 oracle's own
+        error; every such pixel is counted and printed.
+    Returns the number of pixels zeroed differently."""
+    assert fl.warped is not None
+    n_flip = n_soft = 0
+    worst = 0.0
+    w64 = None
+    for s, (g, w) in enumerate(zip(fl.warped, ref["warped"])):
+        g = to_np(g)
+        assert g.shape == w.shape, (g.shape, w.shape)
+        assert np.isfinite(g).all(), "%s: non-finite warped pixels at scale %d" % (what, s)
+        kz, oz = (g == 0).all(axis=2), (w == 0).all(axis=2)                   # (B,n,h,w)
+        mism = kz != oz
+        near = ref["margin"][s] < FLIP_THR
+        assert not (mism & ~near).any(), "%s scale %d: %d pixels zeroed differently from the oracle AWAY from the strict in-view test" % (
+            what, s, int((mism & ~near).sum()))
+        n_flip += int(mism.sum())
+        scale = max(float(np.abs(w).max()), 1.0)
+        err = np.abs(g.astype(np.float64) - w).max(axis=2)
+        err[mism] = 0.0
+        bad = err > WARP_TOL * scale
+        if bad.any():
+            assert ref64 is not None, "%s scale %d: %d warped pixels off by more than %g (max %.3g)" % (what, s, int(bad.sum()), WARP_TOL, err.max())
+            if w64 is None:
+                w64 = ref64()["warped"]
+            own = np.abs(np.asarray(w, np.float64) - w64[s]).max(axis=2)
+            e64 = np.abs(g.astype(np.float64) - w64[s]).max(axis=2)
+            still = bad & (e64 > np.maximum(WARP_TOL * scale, 3.0 * own))
+            assert not still.any(), "%s scale %d: %d warped pixels off by more than max(%g, 3x the fp32 oracle's own error) vs the fp64 oracle" % (
+                what, s, int(still.sum()), WARP_TOL)
+            n_soft += int(bad.sum())
+            err[bad] = 0.0
+        worst = max(worst, float(err.max()) / scale)
+    parity_note("warped pixels %s: max |I^ - I^_oracle| %.2e of the range (tol %.0e); %d pixels zeroed differently (all within %.0e of the "
+                "strict test); %d ill-conditioned pixels judged against the fp64 oracle" % (what, worst, WARP_TOL, n_flip, FLIP_THR, n_soft))
+    return n_flip
 
 
 def _check_losses(loss5, ref, slack=0.0):
@@ -58,14 +108,6 @@ def knife_cap(n_px):
     return KNIFE_CAP_LARGE if n_px >= KNIFE_SMALL_PX else KNIFE_CAP_SMALL
 
 
-def knife_mask(ref, s, thr=8e-6, cell_thr=1e-4, abs_thr=3e-5, clip_thr=5e-5):
-    """The knife-edge pixels of scale s with their footprints (see _knife), and the three classes before dilation."""
-    flip = (ref["margin"][s] < thr).any(axis=1)
-    clip = (ref["clip_margin"][s] < clip_thr).any(axis=1)
-    own = (ref["cell_margin"][s] < cell_thr).any(axis=1) | (ref["abs_margin"][s] < abs_thr).any(axis=1)
-    return dilate(flip, 2) | dilate(clip, 1) | own, flip, clip, own
-
-
 def _knife(ref, s, n_src, thr=8e-6, cell_thr=1e-4, abs_thr=3e-5, clip_thr=5e-5, what=""):
     """Pixels of scale s where the reference's function itself is discontinuous in (disp, pose), so that two
     fp32 evaluations of it may legitimately land on different sides; excluded from ELEMENT-WISE gradient
@@ -84,12 +126,6 @@ def _knife(ref, s, n_src, thr=8e-6, cell_thr=1e-4, abs_thr=3e-5, clip_thr=5e-5, 
         what, s, m.size, n_src, 100 * share, 100 * cap, int(flip.sum()), int(clip.sum()), int(own.sum())))
     assert share <= cap, "too many knife-edge pixels (%.3f%% > %.0f%%): the exclusion would hide real errors" % (100 * share, 100 * cap)
     return m[:, None]                                 # (B,1,h,w)
-
-
-def rel_l2(got, want, knife=None):
-    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
-    keep = np.ones(got.shape, bool) if knife is None else ~np.broadcast_to(knife, got.shape)
-    return float(np.sqrt((((got - want) * keep) ** 2).sum()) / max(np.sqrt(((want * keep) ** 2).sum()), 1e-30))
 
 
 def _judged64(got, w32, w64, knife, what, extra=0.0):
@@ -450,10 +486,17 @@ def test_baseline_configs_vs_oracle(ops, synth, dev, cfg_name, B, H, W, n_src, n
     cfg = CONFIGS[cfg_name]
     d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=n_scales, seed=1)
     ref = _oracle(d, cfg)
-    fl = _bind(ops, dev, d, cfg, layout=layout)
-    _check_losses(fl.forward(), ref)
-    _check_losses(fl.forward_backward(), ref)
+    fl = _bind(ops, dev, d, cfg, layout=layout, want_warped=True)
     what = "%s B=%d %dx%d %s" % (cfg_name, B, H, W, layout)
+    _check_losses(fl.forward(), ref)
+    _check_warped(fl, ref, what + " [sfm_loss_fwd]")
+    w_fwd = [to_np(t).copy() for t in fl.warped]
+    for t in fl.warped:
+        t.fill_(7.0)
+    _check_losses(fl.forward_backward(), ref)
+    _check_warped(fl, ref, what + " [sfm_loss_fwd_bwd]")
+    for a, t in zip(w_fwd, fl.warped):      # the two entry points warp with the same statements
+        np.testing.assert_array_equal(a, to_np(t))
     _check_grads(fl, ref, n_src, what=what)
     a, b = count_in_view_mismatches(ops, dev, d, ref, layout, what)
     # every pixel the two evaluations treat differently sits on the strict test (the knife mask covers it): a handful per image
@@ -471,9 +514,15 @@ def test_full_batch_vs_oracle(ops, synth, dev, cfg_name, B, H, W, n_src):
     cfg = CONFIGS[cfg_name]
     d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=4, seed=1)
     ref = _oracle(d, cfg)
-    fl = _bind(ops, dev, d, cfg, layout="hwc")
+    fl = _bind(ops, dev, d, cfg, layout="hwc", want_warped=True)
     _check_losses(fl.forward_backward(), ref)
     what = "FULL BATCH %s B=%d %dx%d %d src hwc" % (cfg_name, B, H, W, n_src)
+    _check_warped(fl, ref, what + " [sfm_loss_fwd_bwd]")
+    # the launch without the warped output (another instantiation of the same template: what bench.py times) gives the same loss and gradients
+    plain = _bind(ops, dev, d, cfg, layout="hwc")
+    np.testing.assert_array_equal(to_np(plain.forward_backward()), to_np(fl.loss5))
+    for a, b in zip(plain.d_disps + plain.d_poses, fl.d_disps + fl.d_poses):
+        np.testing.assert_array_equal(to_np(a), to_np(b))
     # (the fp64 oracle is only evaluated if an array misses the fp32 criterion -- an ill-conditioned far point among 1.7 million
     # pixels -- and every such use is printed)
     ref64 = lambda: O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], None, backward=True,
@@ -483,6 +532,89 @@ def test_full_batch_vs_oracle(ops, synth, dev, cfg_name, B, H, W, n_src):
     # (11, 397), U = 361.9999), so at the full batch the cell-boundary class is taken 2.5e-4 px wide instead of 1e-4
     _check_grads(fl, ref, n_src, what=what, ref64=ref64, cell_thr=2.5e-4)
     count_in_view_mismatches(ops, dev, d, ref, "hwc", what)
+
+
+MOTIONS = {
+    # name: (rot_sigma, trans_sigma, forced tz range or None).  synth's default (0.01, 0.02) is the scale of an untrained PoseNet
+    # (pose_net.py:52); these are what a trained one, or a diverging one, can put out.
+    "medium": (0.05, 0.10, None),          # gather footprints several times wider, a quarter of the frame out of view
+    "large": (0.15, 0.25, None),           # rotations of tenths of a radian: most of the frame out of view
+    "behind": (0.01, 0.02, (-0.6, -0.3)),  # the camera moved BEHIND part of the scene: z = q2 + 1e-10 < 0 there (transform.py:122-125);
+                                           # the reference still divides, and samples every mirrored point that lands in view
+}
+
+
+def make_motion_inputs(synth, motion, **kw):
+    rot, trans, tz = MOTIONS[motion]
+    d = synth.make_inputs(rot_sigma=rot, trans_sigma=trans, **kw)
+    if tz is not None:
+        rng = np.random.RandomState(1000 + kw.get("seed", 0))
+        for p in d["poses"]:
+            p[:, 5] = rng.uniform(tz[0], tz[1], size=p.shape[0]).astype(np.float32)
+    return d
+
+
+def motion_stats(d, ref, what):
+    """Prints (parity_note) what the inputs exercise: the share of warped pixels not in view and of samples with z < 0."""
+    oov = np.mean([float((w == 0).all(axis=2).mean()) for w in ref["warped"]])
+    neg = []
+    for s, disp in enumerate(d["disps"]):
+        K = d["intrinsics"][:, s]
+        B, _, h, w = disp.shape
+        for pose in d["poses"]:
+            Pm = O.proj_tgt_to_src(pose, K)
+            cam, _ = O.pixel2cam(np.broadcast_to((1.0 / disp).reshape(B, 1, h * w), (B, 3, h * w)), O.generate_2dmeshgrid(h, w, B), K)
+            neg.append(float(((Pm @ cam)[:, 2] < 0).mean()))
+    parity_note("motion %s: %.1f%% of the warped pixels not in view, %.1f%% of the samples behind the source camera (z < 0)" % (
+        what, 100 * oov, 100 * float(np.mean(neg))))
+    return oov, float(np.mean(neg))
+
+
+@pytest.mark.parametrize("motion", sorted(MOTIONS))
+@pytest.mark.parametrize("cfg_name,B,H,W,n_src,n_scales,layout", [
+    ("ssim_smooth", 1, 37, 70, 2, 1, "planar"),
+    ("explain", 2, 37, 70, 2, 2, "hwc"),
+    ("edge_aware", 4, 128, 416, 2, 4, "hwc"),       # BASELINE cfg3 as written, oracle-sized batch
+    ("l1_smooth", 4, 128, 416, 2, 4, "planar"),     # cfg2's loss
+])
+def test_large_motion_vs_oracle(ops, synth, dev, motion, cfg_name, B, H, W, n_src, n_scales, layout):
+    """Inputs away from synth's small-motion default: wide gather footprints, most of a frame out of view, and samples BEHIND the
+    source camera (z < 0: the reference divides anyway, transform.py:122-125, and samples the mirrored points that land in view).
+    Loss, warped pixels and every gradient against the oracle by the criteria of the small-motion tests; where the projection is
+    ill-conditioned (|z| small) both fp32 evaluations sit away from the fp64 one, which then decides (printed)."""
+    cfg = CONFIGS[cfg_name]
+    d = make_motion_inputs(synth, motion, B=B, H=H, W=W, n_src=n_src, n_scales=n_scales, seed=21, with_masks=True)
+    ref = _oracle(d, cfg)
+    what = "MOTION %s %s B=%d %dx%d %s" % (motion, cfg_name, B, H, W, layout)
+    oov, neg = motion_stats(d, ref, what)
+    if motion == "behind":
+        assert neg > 0.05, "the case is meant to put a counted share of the samples behind the camera"
+    else:
+        assert oov > (0.15 if motion == "medium" else 0.5)
+    ref64 = lambda: O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], d["masks"], backward=True,
+                               keep_warped=True, dtype=np.float64, **cfg)
+    fl = _bind(ops, dev, d, cfg, layout=layout, want_warped=True)
+    _check_losses(fl.forward_backward(), ref)
+    _check_warped(fl, ref, what, ref64=ref64)
+    _check_grads(fl, ref, n_src, what=what, ref64=ref64, check_mask=bool(cfg.get("exp_reg")))
+    count_in_view_mismatches(ops, dev, d, ref, layout, what)
+
+
+@pytest.mark.parametrize("motion", ["medium", "behind"])
+def test_large_motion_full_batch_vs_oracle(ops, synth, dev, motion):
+    """The same at BASELINE cfg3's FULL batch (B=32, as written: edge-aware smoothness), pixel-interleaved: the launch bench.py's
+    `cfg3_large_motion` key times."""
+    cfg = CONFIGS["edge_aware"]
+    d = make_motion_inputs(synth, motion, B=32, H=128, W=416, n_src=2, n_scales=4, seed=1)
+    ref = _oracle(d, cfg)
+    what = "MOTION %s FULL BATCH edge_aware B=32 128x416 hwc" % motion
+    motion_stats(d, ref, what)
+    ref64 = lambda: O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], None, backward=True,
+                               keep_warped=True, dtype=np.float64, **cfg)
+    fl = _bind(ops, dev, d, cfg, layout="hwc", want_warped=True)
+    _check_losses(fl.forward_backward(), ref)
+    _check_warped(fl, ref, what, ref64=ref64)
+    _check_grads(fl, ref, 2, what=what, ref64=ref64, cell_thr=2.5e-4)
 
 
 @pytest.mark.parametrize("cfg_name,B,H,W,n_src", [

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import sfm_oracle as O
+from oracle.parity import rel_l2
 from util import assert_close_masked, parity_note, to_dev, to_np
 
 pytestmark = pytest.mark.gpu
@@ -89,22 +90,34 @@ def test_projective_inverse_warp_fwd_bwd(ops, synth, dev, shape, texture, depth_
                                            int((aux["margin"] < 2e-5).sum())))
     assert_close_masked(got, want, WARP_TOL, None, what="warped")
     assert not (zero_g != zero_w).any(), "the exactly-zero pixels differ from the oracle's"
-    g = rng.normal(size=(N, C, H, W)).astype(np.float32)
+    # Backward.  The gradient of the bilinear sample jumps where the sample crosses a cell boundary of the lattice; the two evaluations
+    # take the same side (the coordinates are the reference's) except within rounding of the boundary itself.  Those pixels (named by
+    # the ORACLE's margins; share printed and bounded) get a ZERO upstream gradient, so that no output depends on them -- and every
+    # output is then judged by the loss suite's criteria: d_depth and d_src element-wise at 2e-3 of the array's maximum EVERYWHERE,
+    # d_pose element-wise at 2e-3 AND 1e-3 in relative L2 (tests/test_loss_gpu.py), no allowance.
+    kcell = ((aux["cell_margin"] < 2e-5) & ~zero_w)[:, None]
+    parity_note("warp_bwd %s %s rows=%d: upstream gradient zeroed on the cell-boundary share %.4f%%" % (shape, texture, depth_rows, 100 * kcell.mean()))
+    assert kcell.mean() < 1e-3
+    g = (rng.normal(size=(N, C, H, W)) * ~kcell).astype(np.float32)
     w_dep, w_pose, w_src = O.projective_inverse_warp_backward(imgs, depthes, pose, K, g, want_gimgs=True)
     d_depth, d_pose, d_src = ops.warp_bwd(*targs, to_dev(g, dev), want_d_src=True)
-    # the gradient jumps where the sample crosses a cell boundary of the bilinear lattice: the same side in both evaluations
-    # now that the coordinates are the reference's, except within rounding of the boundary itself
-    kcell = ((aux["cell_margin"] < 2e-5) & ~zero_w)[:, None]
-    parity_note("warp_bwd %s %s rows=%d: excluded cell-boundary share %.4f%%" % (shape, texture, depth_rows, 100 * kcell.mean()))
-    assert kcell.mean() < 1e-3
     got_dep = to_np(d_depth).reshape(N, depth_rows, H, W)
     want_dep = (w_dep.sum(1, keepdims=True) if depth_rows == 1 else w_dep).reshape(N, depth_rows, H, W)
-    assert_close_masked(got_dep, want_dep, 1e-3, kcell, what="d_depth")
-    # d_pose sums H*W signed terms driven by a white-noise upstream gradient: it cancels to ~sqrt(HW)
-    # of one term, so a single cell-boundary pixel moves it by ~1/sqrt(HW) of its magnitude
-    assert_close_masked(to_np(d_pose), w_pose, 2e-2, what="d_pose")
-    e = np.abs(to_np(d_src) - w_src)
-    assert (e > 1e-3 * np.abs(w_src).max()).mean() < 1e-3
+    assert_close_masked(got_dep, want_dep, 2e-3, None, what="d_depth")
+    assert rel_l2(got_dep, want_dep) <= 1e-4, rel_l2(got_dep, want_dep)
+    # (d_pose sums H*W signed terms driven by a white-noise upstream gradient: it cancels to ~sqrt(HW) of one term, and the fp32
+    #  oracle's own summation order shows at that level: the fp64 oracle is the yardstick when the fp32 one misses)
+    pose_err, pose_l2 = np.abs(to_np(d_pose) - w_pose).max() / np.abs(w_pose).max(), rel_l2(to_np(d_pose), w_pose)
+    if pose_err > 2e-3 or pose_l2 > 1e-3:
+        w64 = O.projective_inverse_warp_backward(imgs.astype(np.float64), np.asarray(depthes, np.float64), pose.astype(np.float64),
+                                                 K.astype(np.float64), g.astype(np.float64), dtype=np.float64)[1]
+        own_err, own_l2 = np.abs(w_pose - w64).max() / np.abs(w64).max(), rel_l2(w_pose, w64)
+        pose_err, pose_l2 = np.abs(to_np(d_pose) - w64).max() / np.abs(w64).max(), rel_l2(to_np(d_pose), w64)
+        parity_note("warp_bwd %s %s rows=%d: d_pose judged against the fp64 oracle (the fp32 oracle's own error: %.2e element-wise, %.2e L2)" % (
+            shape, texture, depth_rows, own_err, own_l2))
+        assert pose_err <= max(2e-3, 3 * own_err) and pose_l2 <= max(1e-3, 3 * own_l2), (pose_err, pose_l2, own_err, own_l2)
+    parity_note("warp_bwd %s %s rows=%d: d_pose max element-wise %.2e (tol 2e-3), relative L2 %.2e (tol 1e-3)" % (shape, texture, depth_rows, pose_err, pose_l2))
+    assert_close_masked(to_np(d_src), w_src, 2e-3, None, what="d_src")
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 8, 13, 8, 13), (1, 2, 5, 7, 11, 3), (2, 3, 16, 52, 16, 52), (1, 6, 9, 70, 35, 67), (1, 4, 40, 9, 33, 130)])
@@ -226,19 +239,16 @@ def test_pyramid_pair_is_the_two_pyramids_in_one_launch(ops, dev, N, n_src, H, W
 
 def test_band_and_per_pixel_pyramid_kernels_agree_bitwise(ops, dev):
     """The band kernel (every input pixel read once, through LDS) and the per-pixel kernel it replaces for aligned shapes
-    (SFM_PYRAMID_PER_PIXEL=1 selects it; read at every launch) compute every output pixel with the same statements."""
-    import os
+    (selected for ONE call by sfm_pyramid_variant(1)) compute every output pixel with the same statements."""
     rng = np.random.RandomState(8)
     tgt = to_dev(rng.uniform(-1, 1, size=(3, 3, 128, 416)).astype(np.float32), dev)
     src = to_dev(rng.uniform(-1, 1, size=(3, 6, 128, 416)).astype(np.float32), dev)
     band = [to_np(a).copy() for pyr in ops.pyramid_pair_hwc(tgt, src, 4) for a in pyr]
-    os.environ["SFM_PYRAMID_PER_PIXEL"] = "1"
-    try:
-        per_pixel = [to_np(a).copy() for pyr in ops.pyramid_pair_hwc(tgt, src, 4) for a in pyr]
-    finally:
-        del os.environ["SFM_PYRAMID_PER_PIXEL"]
-    for a, b in zip(band, per_pixel):
+    per_pixel = [to_np(a).copy() for pyr in ops.pyramid_pair_hwc(tgt, src, 4, per_pixel=True) for a in pyr]
+    again = [to_np(a).copy() for pyr in ops.pyramid_pair_hwc(tgt, src, 4) for a in pyr]     # the switch holds for one call only
+    for a, b, c in zip(band, per_pixel, again):
         np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(a, c)
 
 
 def test_type_checks(ops, dev):

@@ -21,7 +21,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHECK = "--check" in sys.argv          # recompute from the sources and compare with the committed JSON instead of writing it
 _args = [a for a in sys.argv[1:] if not a.startswith("--")]
-tag = _args[0] if _args else "r03"
+tag = _args[0] if _args else "r04"
 CSRC = os.path.join(ROOT, "sfm-learner-chainer_amd", "csrc")
 
 # instruction -> row of the op-cost table whose measured cost it takes
@@ -84,13 +84,16 @@ def main():
     out = {"tag": tag, "kernels": {}}
     for n, st in enumerate(starts):
         name = lines[st].split(":")[0]
-        m = re.match(r"_ZN3sfm11loss_kernelILb(\d)ELb(\d)ELb(\d)ELb(\d)ELi(\d)ELb(\d)EEE", name)
+        # (the last template argument, WARPED, selects the variants that also write SfmLossDesc.warped: parity tests only, not priced)
+        m = re.match(r"_ZN3sfm11loss_kernelILb(\d)ELb(\d)ELb(\d)ELb(\d)ELi(\d)ELb(\d)ELb(\d)EEE", name)
         wide = m is None
-        if wide:      # loss_kernel_wide<LOSS, SMODE, HWC>: the L1 gradient kernels built for three waves per SIMD
-            mw = re.match(r"_ZN3sfm16loss_kernel_wideILb(\d)ELi(\d)ELb(\d)EEE", name)
-            ssim, grad, loss, expl, smode, hwc = 0, 1, int(mw.group(1)), 0, int(mw.group(2)), int(mw.group(3))
+        if wide:      # loss_kernel_wide<LOSS, SMODE, HWC, WARPED>: the L1 gradient kernels built for three waves per SIMD
+            mw = re.match(r"_ZN3sfm16loss_kernel_wideILb(\d)ELi(\d)ELb(\d)ELb(\d)EEE", name)
+            ssim, grad, loss, expl, smode, hwc, warped = 0, 1, int(mw.group(1)), 0, int(mw.group(2)), int(mw.group(3)), int(mw.group(4))
         else:
-            ssim, grad, loss, expl, smode, hwc = [int(v) for v in m.groups()]
+            ssim, grad, loss, expl, smode, hwc, warped = [int(v) for v in m.groups()]
+        if warped:
+            continue
         body = lines[st:(starts[n + 1] if n + 1 < len(starts) else len(lines))]
         waves = 3 if ((ssim and grad) or wide) else 4
         costs, src = op_costs(waves)
@@ -133,9 +136,9 @@ def main():
                     n_valu += 1
         steps = 3.0 if ssim else 1.0                       # the SSIM pass instantiates the row step three times (ring rotation)
         full = "void sfm::loss_kernel<%s>(sfm::LossArgs)" % ", ".join(
-            [("true" if v else "false") for v in (ssim, grad, loss, expl)] + [str(smode), "true" if hwc else "false"])
+            [("true" if v else "false") for v in (ssim, grad, loss, expl)] + [str(smode), "true" if hwc else "false", "false"])
         if wide:
-            full = "void sfm::loss_kernel_wide<%s, %d, %s>(sfm::LossArgs)" % ("true" if loss else "false", smode, "true" if hwc else "false")
+            full = "void sfm::loss_kernel_wide<%s, %d, %s, false>(sfm::LossArgs)" % ("true" if loss else "false", smode, "true" if hwc else "false")
         out["kernels"][full] = {
             "waves_per_simd": waves, "valu_per_row_step": round(n_valu / steps, 1), "issue_cycles_per_row_step": round(cyc / steps, 1),
             "mean_issue_cycles_per_valu": round(cyc / max(n_valu, 1), 4),
@@ -158,7 +161,7 @@ def main():
         for k, v in sorted(out["kernels"].items()):
             f.write("| `%s` | %d | %.0f | %.0f | %.3f |\n" % (k.replace("void sfm::", "").replace("(sfm::LossArgs)", ""), v["waves_per_simd"], v["valu_per_row_step"],
                                                          v["issue_cycles_per_row_step"], v["mean_issue_cycles_per_valu"]))
-    k = "void sfm::loss_kernel<true, true, true, false, 2, true>(sfm::LossArgs)"
+    k = "void sfm::loss_kernel<true, true, true, false, 2, true, false>(sfm::LossArgs)"
     print(k, json.dumps(out["kernels"].get(k), indent=1))
 
 
