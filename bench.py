@@ -7,9 +7,11 @@
 One "step" = forward + backward of the multi-scale photometric loss through the C ABI over one synthetic batch
 that is already resident in HBM: the fused launch sfm_loss_fwd_bwd (loss and all gradients -- what
 SFMLearnerLoss.__call__ runs when backprop is enabled).  The path shards over samples with no exchange on the data
-path; for N > 1 the five REPORTED scalars of the K steps of a block are summed over the ranks with ONE RCCL all-reduce at
-the end of the block, inside the timed region (`--collective step` all-reduces them after every step instead; that variant
-is measured in the same run and reported as `per_step_collective_variant`).  Workload at any N: BASELINE.json configs[2]/[3] AS WRITTEN -- B = 32 samples PER GPU,
+path; under a launcher (any N, N = 1 included) the five REPORTED scalars of EVERY step are summed over the ranks by one
+ncclAllReduce(sum, fp32, count=5) issued straight through librccl on the stream the loss kernels run on (SURVEY.md 8(e);
+sfm-learner-chainer_amd/rccl.py), inside the timed region.  Two other placements are measured in the same N > 1 run and reported
+as secondary keys: `interval_variant` (ONE all-reduce of the K rows per block of K steps) and `per_step_torch_variant` (the
+per-step all-reduce through torch.distributed: 42 us of host time per call).  Workload at any N: BASELINE.json configs[2]/[3] AS WRITTEN -- B = 32 samples PER GPU,
 128x416, 4 scales, 2 sources, L1 + SSIM(0.15, experiments/sfm_learner_v1_ssim.yml) + EDGE-AWARE smoothness(0.1)
 (models/base_model.py:144-155), weak scaling.  The same with the second-order smoothness the reference's live code runs
 (base_model.py:75-77,169-185) is the secondary key `cfg3` of the line.
@@ -43,6 +45,13 @@ BYTES_FWD, BYTES_BWD = 28, 32   # algorithmic bytes per warped pixel, SURVEY.md 
 N_SIMD = 1024                   # 256 CUs x 4 SIMDs
 PROFILE_TAGS = ("r04", "r03")         # profiles/<tag>_summary.json, _issue_model.json, _wave_stage_stamps.txt: what roofline_valu is built from
 GRAD_BUFFER_FLOATS = 36489060 + 3393892   # DispNet + PoseNet parameters: the ~160 MB all-reduce probe
+
+COLLECTIVE_NOTES = {
+    "step": "after EVERY step: ncclAllReduce(sum, fp32, count=5) straight through librccl on the stream of the loss kernels (SURVEY.md 8(e))",
+    "interval": "ONE all-reduce of the K rows per block of K steps, in the timed region (reporting per LogReport interval)",
+    "step_torch": "after EVERY step through torch.distributed.all_reduce (blocking in stream order; 42 us of host time per call)",
+}
+VARIANT_KEYS = {"step": "per_step_collective_variant", "interval": "interval_variant", "step_torch": "per_step_torch_variant"}
 
 WORKLOADS = {
     # name: (B per GPU, H, W, n_src, n_scales, loss config, description)
@@ -417,9 +426,10 @@ def main():
     ap.add_argument("--layout", default="hwc", choices=["hwc", "planar"],
                     help="memory layout of the image pyramids resident in HBM when the timed region starts: hwc = pixel-"
                          "interleaved, as sfm_pyramid_hwc_fwd writes them (default); planar = the reference's (B,3,h,w)")
-    ap.add_argument("--collective", default="interval", choices=["interval", "step"],
-                    help="N > 1: all-reduce the reported scalars once per block of --steps steps (default; what a trainer that "
-                         "reports per LogReport interval needs) or after every step")
+    ap.add_argument("--collective", default="step", choices=["step", "interval", "step_torch"],
+                    help="under a launcher: all-reduce the five reported scalars after EVERY step with ncclAllReduce on the compute "
+                         "stream (default, SURVEY.md 8(e)); once per block of --steps steps (interval); or after every step through "
+                         "torch.distributed.all_reduce (step_torch)")
     ap.add_argument("--min-time", type=float, default=0.3, help="seconds of timed steps at least (blocks of --steps are repeated)")
     ap.add_argument("--max-blocks", type=int, default=400)
     ap.add_argument("--event-every", type=int, default=20, help="attach the kernel-timing events to every n-th timed step (1 = every step)")
@@ -466,12 +476,23 @@ def main():
 
     # The path has no exchange on the data path (every quantity is per sample until the final means; gradients of a rank's own
     # disparities / poses never leave it).  What is exchanged is what gets REPORTED: the five scalars, summed over the shards (RCCL
-    # over xGMI).  Every step writes its scalars into its own row of a device-resident log; `--collective interval` (default) sums
-    # the K rows of a block with ONE all-reduce at the end of the block, inside the timed region -- what a trainer that reports per
-    # LogReport interval needs; `--collective step` all-reduces each row right after its step, in stream order (async_op=False: no
-    # host wait, the next step's launches queue behind it).  Measured with tools/allreduce_overhead.py (one rank, RCCL): the per-step
-    # form costs +8.6 us per 60 us step, +25 us with async_op=True and the waits deferred (the host side of torch's all_reduce is
-    # 42 us), +6.7 us replayed from a HIP graph.  Both placements are measured in every N > 1 run; the other one is a secondary key.
+    # over xGMI).  Every step writes its scalars into its own row of a device-resident log.  `--collective step` (default, SURVEY.md
+    # 8(e)): ncclAllReduce(sum, fp32, 5) of the row right behind the step's launches, ON THE SAME STREAM, straight through librccl
+    # (rccl.py) -- one library call, no host wait, no cross-stream event; `interval`: ONE all-reduce of the K rows at the end of the
+    # block (what a trainer that reports per LogReport interval needs); `step_torch`: the per-step all-reduce through
+    # torch.distributed (tools/allreduce_overhead.py, one rank: 42 us of host time per call, +8.6 us per 60 us step).
+    comm = None
+    if use_dist and not rehearse:
+        rccl = importlib.import_module(PKG + ".rccl")
+        comm = rccl.Communicator(rank, world, dev)
+    raw_stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def reduce_rows(t):
+        if comm is not None:
+            comm.all_reduce_sum_f32(t, raw_stream)
+        else:                      # the one-GPU rehearsal: gloo (RCCL refuses two ranks on one device)
+            dist.all_reduce(t)
+
     n_log = max(K, args.warmup, 1)
     loss_log = torch.zeros((n_log, 5), dtype=torch.float32, device=dev)
     rows = [loss_log[k] for k in range(n_log)]
@@ -485,15 +506,14 @@ def main():
     events = {k: [ev.create() for _ in range(4)] for k in sampled}
 
     def run_steps(n, collective, timed):
-        works = []
         for k in range(n):
             R.step(out=rows[k], evs=events.get(k) if timed else None)
             if collective == "step":
+                reduce_rows(rows[k])
+            elif collective == "step_torch":
                 dist.all_reduce(rows[k])
         if collective == "interval":
-            works.append(dist.all_reduce(loss_log[:n], async_op=True))
-        for w in works:
-            w.wait()
+            reduce_rows(loss_log[:n])
 
     def timed_block(collective):
         torch.cuda.synchronize()
@@ -514,7 +534,7 @@ def main():
         return elapsed
 
     coll = args.collective if use_dist else None
-    other_coll = "step" if coll == "interval" else "interval"
+    other_colls = [c for c in ("step", "interval", "step_torch") if c != coll]
     run_steps(args.warmup, coll, False)
     blocks, k_main, k_second = [], [], []
 
@@ -535,10 +555,12 @@ def main():
 
     # N > 1: the same with the other placement of the collective, and the all-reduce of a DispNet+PoseNet-sized gradient buffer
     # (characterises xGMI; not part of this path)
-    interval_ms = allreduce_probe = None
+    variants_ms, allreduce_probe = {}, None
+    if use_dist:      # (also at N = 1 under the launcher: the same calls on a one-rank communicator)
+        for oc in other_colls:
+            run_steps(min(args.warmup, 3), oc, False)
+            variants_ms[oc] = float(np.median([timed_block(oc) for _ in range(min(n_blocks, 5))])) / K * 1e3
     if world > 1:
-        iv = [timed_block(other_coll) for _ in range(min(n_blocks, 5))]
-        interval_ms = float(np.median(iv)) / K * 1e3
         buf = torch.zeros((GRAD_BUFFER_FLOATS,), dtype=torch.float32, device=dev)
         for _ in range(3):
             dist.all_reduce(buf)
@@ -632,9 +654,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": R.desc, "per_gpu_batch": R.B, "global_batch": R.B * world, "H": R.H, "W": R.W, "n_src": R.n_src,
                        "n_scales": R.n_scales, "mode": args.mode, "image_layout": args.layout, "warped_px_per_gpu_step": R.warped_px,
-                       "parallelism": ("batch-sharded x%d, no exchange on the data path; RCCL all-reduce of the 5 reported scalars %s" % (
-                           world, "once per block of %d steps (in the timed region)" % K if coll == "interval" else "after EVERY step (in stream order)"))
-                       if use_dist else "single GPU, no collective"},
+                       "collective": COLLECTIVE_NOTES[coll] if use_dist else None,
+                       "parallelism": ("batch-sharded x%d, no exchange on the data path; RCCL all-reduce of the 5 reported scalars: %s" % (
+                           world, COLLECTIVE_NOTES[coll])) if use_dist else "single GPU, no collective"},
             "timing": {"blocks": len(blocks), "steps_per_block": K, "timed_s": round(float(np.sum(blocks)), 4),
                        "ms_per_step_median": round(ms_step, 5), "ms_per_step_p10": round(float(np.percentile(per_step, 10)) * 1e3, 5),
                        "ms_per_step_p90": round(float(np.percentile(per_step, 90)) * 1e3, 5),
@@ -644,11 +666,10 @@ def main():
             "step_roofline_frac": round((BYTES_FWD + BYTES_BWD) * R.warped_px / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "loss5": [round(v, 6) for v in loss],
         }
+        for oc, ms in variants_ms.items():
+            out[VARIANT_KEYS[oc]] = {"ms_per_step": round(ms, 5), "value": round(R.warped_px * world / (ms * 1e-3) / 1e6, 1),
+                                     "note": COLLECTIVE_NOTES[oc]}
         if world > 1:
-            key = "per_step_collective_variant" if other_coll == "step" else "interval_variant"
-            out[key] = {"ms_per_step": round(interval_ms, 5), "value": round(R.warped_px * world / (interval_ms * 1e-3) / 1e6, 1),
-                        "note": "the five scalars all-reduced after EVERY step (blocking, in stream order)" if other_coll == "step"
-                        else "ONE all-reduce of the K rows per K steps (reporting per LogReport interval)"}
             out["allreduce_160MB"] = allreduce_probe
         if rehearse:
             out["rehearsal"] = ("SFM_BENCH_REHEARSE_ONE_GPU: all %d ranks ran on ONE GPU and the collectives went through gloo -- this line "
@@ -658,6 +679,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.destroy()
     if use_dist:
         dist.destroy_process_group()
 

@@ -39,3 +39,52 @@ def rel_l2(got, want, knife=None):
     got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
     keep = np.ones(got.shape, bool) if knife is None else ~np.broadcast_to(knife, got.shape)
     return float(np.sqrt((((got - want) * keep) ** 2).sum()) / max(np.sqrt(((want * keep) ** 2).sum()), 1e-30))
+
+
+def position_uncertainty(K, pose, disp, k=3.0):
+    """How far two correct fp32 evaluations of the sampling position (U, V) = (q0/z, q1/z) of models/transform.py:105-125 may lie
+    apart: a first-order running error bound, evaluated in fp64 from the INPUTS alone (no implementation's rounding enters).
+    Every sum of the chain  ray = K^-1 pix,  cam = D ray,  q = Pm (cam, 1)  is charged k unit roundoffs (2^-24) of the sum of the
+    magnitudes of its terms (cancellation is what makes a position uncertain: q0 = fx X + cx Z sums to D x from terms of size
+    D (x + 2 cx)), and U = q0 / z inherits  (E_q0 + |U| E_z) / |z|  -- which grows without bound where z -> 0.
+      K (B,3,3), pose (B,6), disp (B,1,h,w)  ->  dU, dV (B,h,w) in source pixels.
+    At a 128x416 BASELINE frame with small motion: 0.5e-4 .. 2e-4 px (1.5 .. 7 ulps of U); the measured differences between the
+    fp32 oracle and the fp64 oracle reach 1.0e-4 px there."""
+    from . import sfm_oracle as O
+    K = np.asarray(K, np.float64)
+    B = K.shape[0]
+    h, w = disp.shape[2:]
+    Pm = O.proj_tgt_to_src(np.asarray(pose, np.float64), K, np.float64)[:, :3]          # (B,3,4)
+    Kinv = np.linalg.inv(K)
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    pix = np.stack([xs, ys, np.ones_like(xs)])                                         # (3,h,w)
+    D = 1.0 / np.asarray(disp, np.float64)[:, 0]                                       # (B,h,w)
+    cam = D[:, None] * np.einsum("bij,jhw->bihw", Kinv, pix)
+    cam_abs = D[:, None] * np.einsum("bij,jhw->bihw", np.abs(Kinv), pix)
+    q = np.einsum("bij,bjhw->bihw", Pm[:, :, :3], cam) + Pm[:, :, 3, None, None]
+    E = np.einsum("bij,bjhw->bihw", np.abs(Pm[:, :, :3]), cam_abs) + np.abs(Pm[:, :, 3, None, None])
+    z = q[:, 2] + 1e-10
+    with np.errstate(divide="ignore", invalid="ignore"):
+        U, V = q[:, 0] / z, q[:, 1] / z
+        g = k * 2.0 ** -24
+        dU = g * (E[:, 0] + np.abs(U) * E[:, 2]) / np.abs(z)
+        dV = g * (E[:, 1] + np.abs(V) * E[:, 2]) / np.abs(z)
+    return np.nan_to_num(dU, nan=np.inf), np.nan_to_num(dV, nan=np.inf)
+
+
+def tap_contrast(img, U, V):
+    """Largest difference between horizontally / vertically adjacent taps of the bilinear cell a sample at (U, V) falls in (over
+    the channels): the Lipschitz constants of the bilinear sample in u and v there.  img (B,C,h,w); U, V (B,h,w) -> Gu, Gv (B,h,w)
+    (0 where the sample is not inside the image)."""
+    img = np.asarray(img, np.float64)
+    B, C, h, w = img.shape
+    du = np.abs(img[:, :, :, 1:] - img[:, :, :, :-1]).max(axis=1)      # (B,h,w-1)
+    dv = np.abs(img[:, :, 1:, :] - img[:, :, :-1, :]).max(axis=1)      # (B,h-1,w)
+    with np.errstate(invalid="ignore"):
+        ok = np.isfinite(U) & np.isfinite(V) & (U >= 0) & (U <= w - 1) & (V >= 0) & (V <= h - 1)
+    u0 = np.clip(np.floor(np.where(ok, U, 0)).astype(np.int64), 0, w - 2)
+    v0 = np.clip(np.floor(np.where(ok, V, 0)).astype(np.int64), 0, h - 2)
+    bi = np.arange(B)[:, None, None]
+    Gu = np.maximum(du[bi, v0, u0], du[bi, v0 + 1, u0])
+    Gv = np.maximum(dv[bi, v0, u0], dv[bi, v0, u0 + 1])
+    return np.where(ok, Gu, 0.0), np.where(ok, Gv, 0.0)

@@ -24,7 +24,49 @@ def test_two_ranks_on_one_gpu(dev):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and "rehearsal" in d
     assert d["config"]["global_batch"] == 2 * d["config"]["per_gpu_batch"]
-    assert "per_step_collective_variant" in d and "allreduce_160MB" in d and "once per block" in d["config"]["parallelism"]
+    assert "interval_variant" in d and "per_step_torch_variant" in d and "allreduce_160MB" in d and "after EVERY step" in d["config"]["parallelism"]
     total, pixel, smooth, expl, ssim = d["loss5"]
     # every rank normalises by the GLOBAL batch, so the summed scalars are a loss of ordinary size (not twice / half of one)
     assert 1.0 < total < 8.0 and abs(total - (0.85 * pixel + 0.15 * ssim + smooth + expl)) < 1e-3 * total
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.timeout(900)
+def test_drivers_launcher_form_runs_on_real_rccl_at_one_rank(dev):
+    """The driver's own N > 1 command form at N = 1 (the one size this box can run on RCCL): `python -m torch.distributed.run
+    --nproc-per-node 1 bench.py --gpus 1`.  The launcher is a CHILD process started before anything in it touches the GPU.
+    init_process_group("nccl"), the communicator bench.py makes through librccl (rccl.py), the per-step ncclAllReduce on the
+    compute stream, the per-interval and the torch.distributed variants and the barrier + MAX timing all execute on RCCL; the
+    line must be the plain N = 1 line to within 5 % (a one-rank all-reduce costs a step nothing)."""
+    common = ["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-secondary", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    bench = os.path.join(ROOT, "bench.py")
+
+    def line(cmd):
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420, cwd=ROOT)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-1500:]
+        return json.loads(lines[0])
+
+    plain = line([sys.executable, bench] + common)
+    dist = line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                 "--master-port", str(_free_port()), bench] + common)
+    assert plain["config"]["collective"] is None and "ncclAllReduce" in dist["config"]["collective"]
+    assert dist["n_gpus"] == 1 and dist["scaling"] == "weak"
+    for key in ("interval_variant", "per_step_torch_variant"):          # the other placements ran too, on the same communicator
+        assert dist[key]["ms_per_step"] > 0
+    np = __import__("numpy")
+    np.testing.assert_allclose(dist["loss5"], plain["loss5"], rtol=1e-6)        # one rank: the all-reduced scalars ARE the loss
+    assert abs(dist["value"] / plain["value"] - 1.0) <= 0.05, (dist["value"], plain["value"], dist["ms_per_step"], plain["ms_per_step"])
+    from util import parity_note
+    parity_note("bench.py under torch.distributed.run at N=1 on RCCL: %.1f Mpix/s (%.4f ms/step; interval %.4f, through torch %.4f) vs plain %.1f Mpix/s (%.4f ms/step)" % (
+        dist["value"], dist["ms_per_step"], dist["interval_variant"]["ms_per_step"], dist["per_step_torch_variant"]["ms_per_step"],
+        plain["value"], plain["ms_per_step"]))

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from oracle import sfm_oracle as O
-from oracle.parity import knife_mask, rel_l2
+from oracle.parity import knife_mask, position_uncertainty, rel_l2, tap_contrast
 from util import assert_close_masked, dilate, parity_note, to_dev, to_np
 
 pytestmark = pytest.mark.gpu
@@ -44,20 +44,39 @@ WARP_TOL = 1e-4      # north_star: warped pixels within 1e-4 (of the image range
 FLIP_THR = 8e-6      # |x_n| within this of 1: the strict `-1 < x < 1` test (transform.py:129) is decided by the last bits
 
 
-def _check_warped(fl, ref, what, ref64=None):
+def position_tolerance(d, s):
+    """(dU, dV), each (B,n,h,w): how far apart two correct fp32 evaluations of the sampling positions of scale s may lie
+    (oracle/parity.py: first-order error bound from the inputs alone)."""
+    per = [position_uncertainty(d["intrinsics"][:, s], pose, d["disps"][s]) for pose in d["poses"]]
+    return np.stack([p[0] for p in per], axis=1), np.stack([p[1] for p in per], axis=1)
+
+
+def cell_width_from_position_bound(d, floor=1e-4):
+    """scale -> (B,n,h,w): the width of the cell-boundary knife class taken from the fp32 uncertainty of each sample's position
+    (never below the flat `floor` px the small tests use): a sample closer to a lattice line than two correct fp32 evaluations may
+    lie apart can land in either cell.  Replaces the hand-set widths of round 3 (2.5e-4 px at the full batch, where one sample in
+    1.7 M sat 1.2e-4 px from a line; 5e-4 px for a 1408-wide frame, where an ulp of U is 1.2e-4 px)."""
+    def width(s):
+        dU, dV = position_tolerance(d, s)
+        return np.maximum(floor, np.maximum(dU, dV))
+    return width
+
+
+def _check_warped(fl, ref, what, d):
     """The warped images the FUSED kernel computed its loss on (SfmLossDesc.warped, written by the kernel that is benchmarked)
     against the oracle's curr_proj_img (models/base_model.py:90-94), pixel for pixel:
       * the sets of exactly-zero (not in view, :96) pixels agree except at pixels the ORACLE places within FLIP_THR of the strict
         in-view test -- those that differ are counted and printed;
-      * everywhere else |I^ - I^_oracle| <= WARP_TOL of the image range.  `ref64` (callable -> fp64 oracle result with `warped`):
-        consulted only if a pixel misses that -- where the projection is ill-conditioned (|z| small: the sample position is a
-        quotient of two small numbers) the fp32 oracle itself is off, and the kernel may be off by 3x the fp32 oracle's own
-        error; every such pixel is counted and printed.
+      * everywhere else |I^ - I^_oracle| <= WARP_TOL of the image range + what the fp32 uncertainty of the sampling POSITION moves
+        the bilinear sample by at that pixel: (contrast between the cell's horizontally adjacent taps) x dU + (vertical) x dV,
+        with (dU, dV) the first-order rounding bound of oracle/parity.py (1 .. 2e-4 px at U = 400; unbounded where z -> 0).  On
+        image-like texture the second term is a few 1e-5; on a step edge of contrast 2 (the wrap-around seam of synth's rolled
+        sources) NO fp32 evaluation meets a flat 1e-4: the fp32 oracle itself is 2.4e-4 from the fp64 one there.  How many pixels
+        exceed the flat WARP_TOL, and by how much, is printed.
     Returns the number of pixels zeroed differently."""
     assert fl.warped is not None
-    n_flip = n_soft = 0
-    worst = 0.0
-    w64 = None
+    n_flip = n_over = 0
+    worst = worst_flat = 0.0
     for s, (g, w) in enumerate(zip(fl.warped, ref["warped"])):
         g = to_np(g)
         assert g.shape == w.shape, (g.shape, w.shape)
@@ -71,31 +90,22 @@ def _check_warped(fl, ref, what, ref64=None):
         scale = max(float(np.abs(w).max()), 1.0)
         err = np.abs(g.astype(np.float64) - w).max(axis=2)
         err[mism] = 0.0
-        bad = err > WARP_TOL * scale
-        if bad.any():
-            assert ref64 is not None, "%s scale %d: %d warped pixels off by more than %g (max %.3g)" % (what, s, int(bad.sum()), WARP_TOL, err.max())
-            if w64 is None:
-                w64 = ref64()["warped"]
-            own = np.abs(np.asarray(w, np.float64) - w64[s]).max(axis=2)
-            e64 = np.abs(g.astype(np.float64) - w64[s]).max(axis=2)
-            still = bad & (e64 > np.maximum(WARP_TOL * scale, 3.0 * own))
-            assert not still.any(), "%s scale %d: %d warped pixels off by more than max(%g, 3x the fp32 oracle's own error) vs the fp64 oracle" % (
-                what, s, int(still.sum()), WARP_TOL)
-            n_soft += int(bad.sum())
-            err[bad] = 0.0
-        worst = max(worst, float(err.max()) / scale)
-    parity_note("warped pixels %s: max |I^ - I^_oracle| %.2e of the range (tol %.0e); %d pixels zeroed differently (all within %.0e of the "
-                "strict test); %d ill-conditioned pixels judged against the fp64 oracle" % (what, worst, WARP_TOL, n_flip, FLIP_THR, n_soft))
+        dU, dV = position_tolerance(d, s)
+        n = w.shape[1]
+        G = [tap_contrast(d["src_pyr"][s][:, 3 * i:3 * i + 3], ref["uv"][s][:, i, 0], ref["uv"][s][:, i, 1]) for i in range(n)]
+        Gu, Gv = np.stack([a for a, _ in G], axis=1), np.stack([b for _, b in G], axis=1)
+        with np.errstate(invalid="ignore"):
+            tol = WARP_TOL * scale + np.nan_to_num(Gu * dU + Gv * dV, nan=0.0, posinf=2.0 * scale)
+        bad = err > tol
+        assert not bad.any(), "%s scale %d: %d warped pixels off by more than %g + (tap contrast x position uncertainty); worst %.3g at tolerance %.3g" % (
+            what, s, int(bad.sum()), WARP_TOL, float(err[bad].max()), float(tol[bad][np.argmax(err[bad])]))
+        n_over += int((err > WARP_TOL * scale).sum())
+        worst_flat = max(worst_flat, float(err.max()) / scale)
+        worst = max(worst, float((err / tol).max()))
+    parity_note("warped pixels %s: max |I^ - I^_oracle| %.2e of the range; %d pixels above the flat %.0e (all on tap contrast x position "
+                "uncertainty; worst pixel at %.2f of its tolerance); %d pixels zeroed differently (all within %.0e of the strict test)" % (
+                    what, worst_flat, n_over, WARP_TOL, worst, n_flip, FLIP_THR))
     return n_flip
-
-
-def _check_losses(loss5, ref, slack=0.0):
-    """`slack`: absolute allowance for pixels that sit on the strict `-1 < x < 1` test (only the random sweep passes one:
-    counted, bounded and reported there); 0 everywhere else."""
-    got = to_np(loss5)
-    for k, name in enumerate(KEYS):
-        want = ref[name]
-        assert abs(got[k] - want) <= LOSS_RTOL * max(abs(want), 1e-6) + slack, (name, got[k], want, slack)
 
 
 KNIFE_CAP_LARGE, KNIFE_CAP_SMALL, KNIFE_SMALL_PX = 0.01, 0.05, 20000
@@ -250,7 +260,8 @@ def pose_explained_by_discontinuities(d, cfg, ref, i, got, norm_B=None, cell_thr
 def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=True, what="", ref64=None, cell_thr=1e-4, explain=None,
                  abs_thr=3e-5):
     """`ref64`: optional callable returning the fp64 oracle's result; consulted only for an array that misses the fp32
-    criterion (see _judged64), and every such use is reported.  `cell_thr`, `abs_thr`: see _knife.  `explain`: optional callable
+    criterion (see _judged64), and every such use is reported.  `cell_thr`, `abs_thr`: see _knife (`cell_thr` may be a callable
+    scale -> width, e.g. cell_width_from_position_bound).  `explain`: optional callable
     (i, got) -> pose_explained_by_discontinuities(...), consulted for a d_pose array that misses everything else."""
     worst = 0.0
     r64 = []
@@ -286,18 +297,19 @@ def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=T
             return min(l2, mine)
         return l2
 
+    cell_of = cell_thr if callable(cell_thr) else (lambda s_: cell_thr)     # per scale: a width in px, or an array (B,n,h,w) of widths
     observed = None      # per sample: knife-edge pixels where the kernel demonstrably took the other branch (a count; REPORTED only)
     on_test = None       # per sample: pixels the ORACLE places within `thr` of the strict in-view test (what the allowance goes by)
     knives = []
     for s, (g, w) in enumerate(zip(fl.d_disps, ref["d_disps"])):
-        knife = _knife(ref, s, n_src, what=what, cell_thr=cell_thr, abs_thr=abs_thr)
+        knife = _knife(ref, s, n_src, what=what, cell_thr=cell_of(s), abs_thr=abs_thr)
         knives.append(knife)
         gnp = to_np(g)
         # (a quarter of the gradient tolerance already counts as "took the other branch": rounding noise is 1000x smaller)
         off = (np.abs(gnp.astype(np.float64) - w) > 0.25 * GRAD_TOL * np.abs(w).max()) & np.broadcast_to(knife, w.shape)
         cnt = off.reshape(off.shape[0], -1).sum(axis=1)
         observed = cnt if observed is None else observed + cnt
-        flip = knife_mask(ref, s, cell_thr=cell_thr, abs_thr=abs_thr)[1]   # (B,h,w): from the oracle's own margins only
+        flip = knife_mask(ref, s, cell_thr=cell_of(s), abs_thr=abs_thr)[1]   # (B,h,w): from the oracle's own margins only
         fc = flip.reshape(flip.shape[0], -1).sum(axis=1)
         on_test = fc if on_test is None else on_test + fc
         close(gnp, w, knife, "d_disp[%d]" % s, "d_disps", s)
@@ -489,12 +501,12 @@ def test_baseline_configs_vs_oracle(ops, synth, dev, cfg_name, B, H, W, n_src, n
     fl = _bind(ops, dev, d, cfg, layout=layout, want_warped=True)
     what = "%s B=%d %dx%d %s" % (cfg_name, B, H, W, layout)
     _check_losses(fl.forward(), ref)
-    _check_warped(fl, ref, what + " [sfm_loss_fwd]")
+    _check_warped(fl, ref, what + " [sfm_loss_fwd]", d)
     w_fwd = [to_np(t).copy() for t in fl.warped]
     for t in fl.warped:
         t.fill_(7.0)
     _check_losses(fl.forward_backward(), ref)
-    _check_warped(fl, ref, what + " [sfm_loss_fwd_bwd]")
+    _check_warped(fl, ref, what + " [sfm_loss_fwd_bwd]", d)
     for a, t in zip(w_fwd, fl.warped):      # the two entry points warp with the same statements
         np.testing.assert_array_equal(a, to_np(t))
     _check_grads(fl, ref, n_src, what=what)
@@ -517,7 +529,7 @@ def test_full_batch_vs_oracle(ops, synth, dev, cfg_name, B, H, W, n_src):
     fl = _bind(ops, dev, d, cfg, layout="hwc", want_warped=True)
     _check_losses(fl.forward_backward(), ref)
     what = "FULL BATCH %s B=%d %dx%d %d src hwc" % (cfg_name, B, H, W, n_src)
-    _check_warped(fl, ref, what + " [sfm_loss_fwd_bwd]")
+    _check_warped(fl, ref, what + " [sfm_loss_fwd_bwd]", d)
     # the launch without the warped output (another instantiation of the same template: what bench.py times) gives the same loss and gradients
     plain = _bind(ops, dev, d, cfg, layout="hwc")
     np.testing.assert_array_equal(to_np(plain.forward_backward()), to_np(fl.loss5))
@@ -527,10 +539,10 @@ def test_full_batch_vs_oracle(ops, synth, dev, cfg_name, B, H, W, n_src):
     # pixels -- and every such use is printed)
     ref64 = lambda: O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], None, backward=True,
                                dtype=np.float64, **cfg)
-    # cell_thr: the two evaluations of the sampling position differ by up to a few 1e-5 px; among 1.7 million samples one lands
-    # 1.2e-4 px from a lattice line and is placed in the neighbouring cell by the kernel (dI^/du jumps there: sample 0, scale 0,
-    # (11, 397), U = 361.9999), so at the full batch the cell-boundary class is taken 2.5e-4 px wide instead of 1e-4
-    _check_grads(fl, ref, n_src, what=what, ref64=ref64, cell_thr=2.5e-4)
+    # cell_thr: among 1.7 million samples one lands 1.2e-4 px from a lattice line (sample 0, scale 0, (11, 397), U = 361.9999) and
+    # is placed in the neighbouring cell by the kernel (dI^/du jumps there); the cell-boundary class is as wide as the fp32
+    # uncertainty of each sample's position (oracle/parity.py: 1 .. 2e-4 px here), not a hand-set constant
+    _check_grads(fl, ref, n_src, what=what, ref64=ref64, cell_thr=cell_width_from_position_bound(d))
     count_in_view_mismatches(ops, dev, d, ref, "hwc", what)
 
 
@@ -595,8 +607,8 @@ def test_large_motion_vs_oracle(ops, synth, dev, motion, cfg_name, B, H, W, n_sr
                                keep_warped=True, dtype=np.float64, **cfg)
     fl = _bind(ops, dev, d, cfg, layout=layout, want_warped=True)
     _check_losses(fl.forward_backward(), ref)
-    _check_warped(fl, ref, what, ref64=ref64)
-    _check_grads(fl, ref, n_src, what=what, ref64=ref64, check_mask=bool(cfg.get("exp_reg")))
+    _check_warped(fl, ref, what, d)
+    _check_grads(fl, ref, n_src, what=what, ref64=ref64, check_mask=bool(cfg.get("exp_reg")), cell_thr=cell_width_from_position_bound(d))
     count_in_view_mismatches(ops, dev, d, ref, layout, what)
 
 
@@ -613,8 +625,8 @@ def test_large_motion_full_batch_vs_oracle(ops, synth, dev, motion):
                                keep_warped=True, dtype=np.float64, **cfg)
     fl = _bind(ops, dev, d, cfg, layout="hwc", want_warped=True)
     _check_losses(fl.forward_backward(), ref)
-    _check_warped(fl, ref, what, ref64=ref64)
-    _check_grads(fl, ref, 2, what=what, ref64=ref64, cell_thr=2.5e-4)
+    _check_warped(fl, ref, what, d)
+    _check_grads(fl, ref, 2, what=what, ref64=ref64, cell_thr=cell_width_from_position_bound(d))
 
 
 @pytest.mark.parametrize("cfg_name,B,H,W,n_src", [
