@@ -41,7 +41,7 @@ def rel_l2(got, want, knife=None):
     return float(np.sqrt((((got - want) * keep) ** 2).sum()) / max(np.sqrt(((want * keep) ** 2).sum()), 1e-30))
 
 
-def position_uncertainty(K, pose, disp, k=3.0):
+def position_uncertainty(K, pose, disp, k=2.0):
     """How far two correct fp32 evaluations of the sampling position (U, V) = (q0/z, q1/z) of models/transform.py:105-125 may lie
     apart: a first-order running error bound, evaluated in fp64 from the INPUTS alone (no implementation's rounding enters).
     Every sum of the chain  ray = K^-1 pix,  cam = D ray,  q = Pm (cam, 1)  is charged k unit roundoffs (2^-24) of the sum of the

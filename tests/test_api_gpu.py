@@ -117,8 +117,8 @@ def test_loss_link_takes_frames_above_the_pixel_interleaved_limit(synth, dev):
     K = to_dev(d["intrinsics"], dev)
     ref = O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], None, backward=True, keep_warped=True,
                      smooth_reg=0.1, ssim_rate=0.15)
-    from test_loss_gpu import _knife, cell_width_from_position_bound
-    width = cell_width_from_position_bound(d)
+    from test_loss_gpu import _knife, knife_widths
+    kw = knife_widths(d, ref)
     for call in range(2):
         disps = [cs.Variable(to_dev(a, dev)) for a in d["disps"]]
         poses = [cs.Variable(to_dev(a, dev)) for a in d["poses"]]
@@ -126,10 +126,10 @@ def test_loss_link_takes_frames_above_the_pixel_interleaved_limit(synth, dev):
         assert abs(float(loss.data) - ref.total_loss) <= 1e-4 * abs(ref.total_loss), call
         loss.backward()
         for s in range(S):
-            # (the cell-boundary class as wide as the fp32 uncertainty of each sample's position: an ulp of U = 1400 is 1.2e-4 px,
-            #  four times that of the 416-wide BASELINE frames)
-            assert_close_masked(to_np(disps[s].grad), ref.d_disps[s], 2e-3, _knife(ref, s, 1, what="1.4 Mpx planar link", cell_thr=width(s)),
-                                what="disp.grad[%d]" % s)
+            # (the cell-boundary and |I^ - I|-kink knife classes as wide as the fp32 uncertainty of each sample's position makes them:
+            #  an ulp of U = 1400 is 1.2e-4 px, four times that of the 416-wide BASELINE frames)
+            knife = _knife(ref, s, 1, what="1.4 Mpx planar link", cell_thr=kw["cell_thr"](s), abs_thr=kw["abs_thr"](s))
+            assert_close_masked(to_np(disps[s].grad), ref.d_disps[s], 2e-3, knife, what="disp.grad[%d]" % s)
     st = next(iter(link._cache.values()))
     assert st.layout == "planar"
     # ... while the C ABI still rejects the pixel-interleaved layout at this size, with a message

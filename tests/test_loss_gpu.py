@@ -51,6 +51,17 @@ def position_tolerance(d, s):
     return np.stack([p[0] for p in per], axis=1), np.stack([p[1] for p in per], axis=1)
 
 
+def value_tolerance(d, ref, s):
+    """(B,n,h,w): what the fp32 uncertainty of the sampling position moves the bilinear sample by at each pixel of scale s:
+    (contrast between the cell's horizontally adjacent taps) x dU + (vertically adjacent) x dV."""
+    dU, dV = position_tolerance(d, s)
+    n = ref["uv"][s].shape[1]
+    G = [tap_contrast(d["src_pyr"][s][:, 3 * i:3 * i + 3], ref["uv"][s][:, i, 0], ref["uv"][s][:, i, 1]) for i in range(n)]
+    Gu, Gv = np.stack([a for a, _ in G], axis=1), np.stack([b for _, b in G], axis=1)
+    with np.errstate(invalid="ignore"):
+        return np.nan_to_num(Gu * dU + Gv * dV, nan=0.0, posinf=np.inf)
+
+
 def cell_width_from_position_bound(d, floor=1e-4):
     """scale -> (B,n,h,w): the width of the cell-boundary knife class taken from the fp32 uncertainty of each sample's position
     (never below the flat `floor` px the small tests use): a sample closer to a lattice line than two correct fp32 evaluations may
@@ -60,6 +71,15 @@ def cell_width_from_position_bound(d, floor=1e-4):
         dU, dV = position_tolerance(d, s)
         return np.maximum(floor, np.maximum(dU, dV))
     return width
+
+
+def knife_widths(d, ref, cell_floor=1e-4, abs_floor=3e-5):
+    """The widths of the two knife classes that follow from WHERE a sample lands, as keyword arguments of _check_grads, both
+    taken from the fp32 uncertainty of each sample's position (oracle/parity.py) and never below the flat widths of the small
+    tests: the cell-boundary class (see cell_width_from_position_bound) and the kink of |I^ - I| (models/base_model.py:95) --
+    sign(I^ - I) is undecided where |I^ - I| is smaller than what that uncertainty moves I^ by."""
+    return dict(cell_thr=cell_width_from_position_bound(d, cell_floor),
+                abs_thr=lambda s: np.maximum(abs_floor, value_tolerance(d, ref, s)))
 
 
 def _check_warped(fl, ref, what, d):
@@ -90,12 +110,7 @@ def _check_warped(fl, ref, what, d):
         scale = max(float(np.abs(w).max()), 1.0)
         err = np.abs(g.astype(np.float64) - w).max(axis=2)
         err[mism] = 0.0
-        dU, dV = position_tolerance(d, s)
-        n = w.shape[1]
-        G = [tap_contrast(d["src_pyr"][s][:, 3 * i:3 * i + 3], ref["uv"][s][:, i, 0], ref["uv"][s][:, i, 1]) for i in range(n)]
-        Gu, Gv = np.stack([a for a, _ in G], axis=1), np.stack([b for _, b in G], axis=1)
-        with np.errstate(invalid="ignore"):
-            tol = WARP_TOL * scale + np.nan_to_num(Gu * dU + Gv * dV, nan=0.0, posinf=2.0 * scale)
+        tol = WARP_TOL * scale + np.minimum(value_tolerance(d, ref, s), 2.0 * scale)
         bad = err > tol
         assert not bad.any(), "%s scale %d: %d warped pixels off by more than %g + (tap contrast x position uncertainty); worst %.3g at tolerance %.3g" % (
             what, s, int(bad.sum()), WARP_TOL, float(err[bad].max()), float(tol[bad][np.argmax(err[bad])]))
@@ -106,6 +121,15 @@ def _check_warped(fl, ref, what, d):
                 "uncertainty; worst pixel at %.2f of its tolerance); %d pixels zeroed differently (all within %.0e of the strict test)" % (
                     what, worst_flat, n_over, WARP_TOL, worst, n_flip, FLIP_THR))
     return n_flip
+
+
+def _check_losses(loss5, ref, slack=0.0):
+    """`slack`: absolute allowance for pixels that sit on the strict `-1 < x < 1` test (only the random sweep passes one:
+    counted, bounded and reported there); 0 everywhere else."""
+    got = to_np(loss5)
+    for k, name in enumerate(KEYS):
+        want = ref[name]
+        assert abs(got[k] - want) <= LOSS_RTOL * max(abs(want), 1e-6) + slack, (name, got[k], want, slack)
 
 
 KNIFE_CAP_LARGE, KNIFE_CAP_SMALL, KNIFE_SMALL_PX = 0.01, 0.05, 20000
@@ -138,13 +162,19 @@ def _knife(ref, s, n_src, thr=8e-6, cell_thr=1e-4, abs_thr=3e-5, clip_thr=5e-5, 
     return m[:, None]                                 # (B,1,h,w)
 
 
-def _judged64(got, w32, w64, knife, what, extra=0.0):
+def _judged64(got, w32, w64, knife, what, extra=0.0, rowwise=False):
     """Second opinion from the fp64 oracle for an array that misses the flat fp32 criterion: where the gradient is
     ill-conditioned in fp32 (far points: d_disp = -gD / disp^2 amplifies the rounding of the sampling coordinates; d_pose sums
     1e4..1e5 signed terms) BOTH fp32 evaluations sit away from the fp64 value, and the kernel may be off by the flat tolerance
-    or three times the fp32 oracle's own error, whichever is larger.  Same knife mask, no other allowance."""
+    or three times the fp32 oracle's own error, whichever is larger.  Same knife mask, no other allowance.
+    `rowwise` (d_pose, (B,6)): the six components of a sample sum over the SAME pixels, so the fp32 oracle's own error of a
+    sample is taken as the largest of its six -- a sample whose sums are dominated by a few near-singular pixels (|z| small: the
+    behind-the-camera cases) is ill-conditioned in all six, whichever of them the fp32 oracle happens to hit."""
     got = np.asarray(got, np.float64)
-    tol = np.maximum((GRAD_TOL + extra) * np.abs(w64).max(), 3.0 * np.abs(np.asarray(w32, np.float64) - w64))
+    own = np.abs(np.asarray(w32, np.float64) - w64)
+    if rowwise:
+        own = np.broadcast_to(own.max(axis=-1, keepdims=True), own.shape)
+    tol = np.maximum((GRAD_TOL + extra) * np.abs(w64).max(), 3.0 * own)
     bad = np.abs(got - w64) > tol
     if knife is not None:
         bad &= ~np.broadcast_to(knife, got.shape)
@@ -180,13 +210,14 @@ def src_footprints(ref, s, knife):
     return np.repeat(out, 3, axis=1)
 
 
-def pose_explained_by_discontinuities(d, cfg, ref, i, got, norm_B=None, cell_thr=1e-4, max_px=48):
+def pose_explained_by_discontinuities(d, cfg, ref, i, got, norm_B=None, cell_thr=1e-4, max_px=48, max_jumps=2):
     """Third opinion for d_pose[i] (B,6): is the kernel's value the ORACLE's with a few named pixels on the other side of a
     discontinuity they sit on?  For every sample whose d_pose row is off by more than a quarter of the gradient tolerance, the
     fp32 oracle is re-run on that sample and source alone (same normalisation: norm_batch) with ONE knife-edge pixel's disparity
     nudged by +-1e-3 / +-1e-2 of its value (or its target texel by +-1e-4: the kink of |I^ - I|); a nudge that makes d_pose JUMP (by more than 1e-4 of its maximum; the smooth response
     to such a nudge is <= 1e-2 of one pixel's share, 1e-5) is that pixel taking its other branch.  Jumps are then picked greedily
-    (each pixel once, only while the distance to the kernel's row shrinks by > 10 %).  Returns the oracle's array with the
+    (each pixel once, only while the distance to the kernel's row shrinks by > 10 %, and AT MOST `max_jumps` per sample: with
+    dozens of free 6-vectors a genuine error could be fitted away -- round-3 advisor finding).  Returns the oracle's array with the
     picked jumps added and the list of pixels; the caller judges the kernel against it with the flat criteria."""
     want = np.asarray(ref["d_poses"][i], np.float64)
     got = np.asarray(got, np.float64)
@@ -243,7 +274,7 @@ def pose_explained_by_discontinuities(d, cfg, ref, i, got, norm_B=None, cell_thr
             for p_, dlt in jumps:
                 print("   jump at %s: %s" % (p_, dlt / scale))
         res, used = got[b] - want[b], set()
-        while True:
+        while len(used) < max_jumps:
             best = None
             for p, dlt in jumps:
                 if p not in used and (best is None or np.linalg.norm(res - dlt) < np.linalg.norm(res - best[1])):
@@ -283,7 +314,7 @@ def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=T
         except AssertionError:
             if ref64 is None:
                 raise
-            _judged64(got, w, second(key, idx), knife, "%s %s" % (what, name), extra=extra)
+            _judged64(got, w, second(key, idx), knife, "%s %s" % (what, name), extra=extra, rowwise=(key == "d_poses"))
 
     def l2_ok(got, w, knife, name, key, idx, tol=L2_TOL):
         l2 = rel_l2(got, w, knife)
@@ -298,18 +329,19 @@ def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=T
         return l2
 
     cell_of = cell_thr if callable(cell_thr) else (lambda s_: cell_thr)     # per scale: a width in px, or an array (B,n,h,w) of widths
+    abs_of = abs_thr if callable(abs_thr) else (lambda s_: abs_thr)
     observed = None      # per sample: knife-edge pixels where the kernel demonstrably took the other branch (a count; REPORTED only)
     on_test = None       # per sample: pixels the ORACLE places within `thr` of the strict in-view test (what the allowance goes by)
     knives = []
     for s, (g, w) in enumerate(zip(fl.d_disps, ref["d_disps"])):
-        knife = _knife(ref, s, n_src, what=what, cell_thr=cell_of(s), abs_thr=abs_thr)
+        knife = _knife(ref, s, n_src, what=what, cell_thr=cell_of(s), abs_thr=abs_of(s))
         knives.append(knife)
         gnp = to_np(g)
         # (a quarter of the gradient tolerance already counts as "took the other branch": rounding noise is 1000x smaller)
         off = (np.abs(gnp.astype(np.float64) - w) > 0.25 * GRAD_TOL * np.abs(w).max()) & np.broadcast_to(knife, w.shape)
         cnt = off.reshape(off.shape[0], -1).sum(axis=1)
         observed = cnt if observed is None else observed + cnt
-        flip = knife_mask(ref, s, cell_thr=cell_of(s), abs_thr=abs_thr)[1]   # (B,h,w): from the oracle's own margins only
+        flip = knife_mask(ref, s, cell_thr=cell_of(s), abs_thr=abs_of(s))[1]   # (B,h,w): from the oracle's own margins only
         fc = flip.reshape(flip.shape[0], -1).sum(axis=1)
         on_test = fc if on_test is None else on_test + fc
         close(gnp, w, knife, "d_disp[%d]" % s, "d_disps", s)
@@ -542,7 +574,7 @@ def test_full_batch_vs_oracle(ops, synth, dev, cfg_name, B, H, W, n_src):
     # cell_thr: among 1.7 million samples one lands 1.2e-4 px from a lattice line (sample 0, scale 0, (11, 397), U = 361.9999) and
     # is placed in the neighbouring cell by the kernel (dI^/du jumps there); the cell-boundary class is as wide as the fp32
     # uncertainty of each sample's position (oracle/parity.py: 1 .. 2e-4 px here), not a hand-set constant
-    _check_grads(fl, ref, n_src, what=what, ref64=ref64, cell_thr=cell_width_from_position_bound(d))
+    _check_grads(fl, ref, n_src, what=what, ref64=ref64, **knife_widths(d, ref))
     count_in_view_mismatches(ops, dev, d, ref, "hwc", what)
 
 
@@ -608,7 +640,7 @@ def test_large_motion_vs_oracle(ops, synth, dev, motion, cfg_name, B, H, W, n_sr
     fl = _bind(ops, dev, d, cfg, layout=layout, want_warped=True)
     _check_losses(fl.forward_backward(), ref)
     _check_warped(fl, ref, what, d)
-    _check_grads(fl, ref, n_src, what=what, ref64=ref64, check_mask=bool(cfg.get("exp_reg")), cell_thr=cell_width_from_position_bound(d))
+    _check_grads(fl, ref, n_src, what=what, ref64=ref64, check_mask=bool(cfg.get("exp_reg")), **knife_widths(d, ref))
     count_in_view_mismatches(ops, dev, d, ref, layout, what)
 
 
@@ -626,7 +658,7 @@ def test_large_motion_full_batch_vs_oracle(ops, synth, dev, motion):
     fl = _bind(ops, dev, d, cfg, layout="hwc", want_warped=True)
     _check_losses(fl.forward_backward(), ref)
     _check_warped(fl, ref, what, d)
-    _check_grads(fl, ref, 2, what=what, ref64=ref64, cell_thr=cell_width_from_position_bound(d))
+    _check_grads(fl, ref, 2, what=what, ref64=ref64, **knife_widths(d, ref))
 
 
 @pytest.mark.parametrize("cfg_name,B,H,W,n_src", [
