@@ -53,6 +53,8 @@ COLLECTIVE_NOTES = {
 }
 VARIANT_KEYS = {"step": "per_step_collective_variant", "interval": "interval_variant", "step_torch": "per_step_torch_variant"}
 
+SYNTH_KW = {"cfg3_large_motion": dict(rot_sigma=0.05, trans_sigma=0.10)}   # everything else: synth.make_inputs' defaults
+
 WORKLOADS = {
     # name: (B per GPU, H, W, n_src, n_scales, loss config, description)
     "cfg3": (32, 128, 416, 2, 4, dict(smooth_reg=0.1, ssim_rate=0.15),
@@ -65,6 +67,9 @@ WORKLOADS = {
                "cfg2's loss (L1 + smoothness) at B=32: the L1 kernels at full occupancy (development: tools/ab_inproc.py)"),
     "cfg3_edge": (32, 128, 416, 2, 4, dict(smooth_reg=0.1, ssim_rate=0.15, smooth_mode="edge_aware"),
                   "BASELINE cfg3 as written: B=32/GPU, 128x416, 4 scales, 2 src, L1+SSIM(0.15)+EDGE-AWARE smoothness(0.1) (base_model.py:144-155)"),
+    "cfg3_large_motion": (32, 128, 416, 2, 4, dict(smooth_reg=0.1, ssim_rate=0.15, smooth_mode="edge_aware"),
+                          "BASELINE cfg3 as written on LARGE-MOTION inputs: poses N(0, 0.05^2) rad / N(0, 0.1^2) instead of synth's (0.01, 0.02) -- gather "
+                          "footprints several times wider, more than half of the warped pixels out of view (tests: MOTION medium)"),
     "cfg5": (8, 256, 832, 4, 4, dict(smooth_reg=0.1, ssim_rate=0.15),
              "BASELINE cfg5: B=8, 256x832, 5-frame (4 src), 4 scales"),
     "cfg5_2src": (8, 256, 832, 2, 4, dict(smooth_reg=0.1, ssim_rate=0.15),
@@ -251,7 +256,7 @@ class Runner:
         self.torch, self.ops, self.dev = torch, ops, dev
         self.B, self.H, self.W, self.n_src, self.n_scales, self.cfg, self.desc = B, H, W, n_src, n_scales, cfg, desc
         self.layout, self.mode = layout, mode
-        d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=n_scales, seed=seed)
+        d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=n_scales, seed=seed, **SYNTH_KW.get(workload, {}))
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         self.full = (t(d["tgt"]), t(d["src"]))                         # full-resolution frames (the link's inputs)
         tgt, src = [t(a) for a in d["tgt_pyr"]], [t(a) for a in d["src_pyr"]]
@@ -597,7 +602,7 @@ def main():
                                                                     "separate" if args.mode == "fused" else "fused", args.batch)))
         guarded("graph_ms_per_step", lambda: graph_path(torch, np, R))
         guarded("link_ms_per_step", lambda: link_path(torch, np, R))
-        for name in ("cfg3", "cfg3_edge", "cfg2", "cfg5", "cfg5_2src", "cfg1"):
+        for name in ("cfg3", "cfg3_edge", "cfg3_large_motion", "cfg2", "cfg5", "cfg5_2src", "cfg1"):
             if name != args.workload:
                 guarded(name, lambda name=name: quick(torch, np, ev, Runner(torch, np, ops, synth, dev, name, args.layout, "fused")))
 

@@ -431,50 +431,41 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
     }
     if (i * 2 >= A.n_src) set_issue_prio((int)((A.prio_tab >> (8 + 2 * prio_rank)) & 3u));
     SsimCtx C;
-    // the geometry table was written by geom_kernel before this launch and is read-only here: reading it
-    // through the constant address space lets the wave fetch the 32 floats with a few scalar loads
-    // (s_load_dwordx8/x16 into SGPRs, one wait) instead of 21 dependent vector loads + v_readfirstlane
-    typedef const __attribute__((address_space(4))) Geom* GeomConstPtr;
-    GeomConstPtr gp = (GeomConstPtr)(uintptr_t)(A.geom + ((size_t)(b * A.n_scales + s) * A.n_src + i));
     const float xf = (float)x;
-    C.gp = gp;
     C.x0 = x - lane;
-#ifdef SFM_GEOM_IN_WAVE   // experiment: every wave builds the geometry of its pass itself, no geom_kernel, no table
+#ifdef SFM_GEOM_TABLE   // A/B build only: the round-3 form (geom_kernel in front of the launch writes a table, read here with scalar loads)
     {
-      typedef const __attribute__((address_space(4))) float* ConstF;
-      ConstF pp = (ConstF)(uintptr_t)(A.pose[i] + b * 6);
-      ConstF kp = (ConstF)(uintptr_t)(A.intrinsics + (size_t)(b * A.n_scales + s) * 9);
-      float pose6[6], K9[9];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) pose6[k] = pp[k];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) K9[k] = kp[k];
-      Geom g;
-      make_geom(pose6, K9, g);
+      typedef const __attribute__((address_space(4))) Geom* GeomConstPtr;
+      GeomConstPtr gp = (GeomConstPtr)(uintptr_t)(A.geom + ((size_t)(b * A.n_scales + s) * A.n_src + i));
+      C.gp = gp;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        C.M1[k] = uniform(g.M[k * 3 + 1]);
-        C.P3[k] = uniform(g.P[k * 4 + 3]);
-        C.mx[k] = fmaf(uniform(g.M[k * 3 + 0]), xf, uniform(g.M[k * 3 + 2]));
-        C.K1[k] = uniform(g.Kinv[k * 3 + 1]);
-        C.kx[k] = fmaf(uniform(g.Kinv[k * 3 + 0]), xf, uniform(g.Kinv[k * 3 + 2]));
+        C.M1[k] = gp->M[k * 3 + 1];
+        C.P3[k] = gp->P[k * 4 + 3];
+        C.mx[k] = fmaf(gp->M[k * 3 + 0], xf, gp->M[k * 3 + 2]);
       }
     }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      C.tp[k] = S.tgt + ((size_t)b * 3 + k) * P;
-      C.sp[k] = S.src + (((size_t)b * A.n_src + i) * 3 + k) * P;
-    }
 #else
+    {
+      // (the pose pointer is SELECTED from the argument block, not loaded through an index: see finalize_kernel)
+      const float* pp = A.pose[0];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      C.M1[k] = gp->M[k * 3 + 1];
-      C.P3[k] = gp->P[k * 4 + 3];
-      C.mx[k] = fmaf(gp->M[k * 3 + 0], xf, gp->M[k * 3 + 2]);
-      C.tp[k] = S.tgt + ((size_t)b * 3 + k) * P;
-      C.sp[k] = S.src + (((size_t)b * A.n_src + i) * 3 + k) * P;
+      for (int k = 1; k < SFM_MAX_SRC; ++k) pp = (i == k) ? A.pose[k] : pp;
+      C.Kp = A.intrinsics + (size_t)(b * A.n_scales + s) * 9;
+      const PassGeom g = build_pass_geom(pp + b * 6, C.Kp, lane);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        C.M1[k] = g.M1[k];
+        C.P3[k] = g.P3[k];
+        C.mx[k] = fmaf(g.M0[k], xf, g.M2[k]);
+      }
     }
 #endif
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      C.tp[k] = S.tgt + ((size_t)b * 3 + k) * P;
+      C.sp[k] = S.src + (((size_t)b * A.n_src + i) * 3 + k) * P;
+    }
     C.k_pix = S.k_pix;
     C.kq = S.kq;
     C.k_exp = S.k_exp;
@@ -1117,7 +1108,7 @@ static int run(const SfmLossDesc* d, bool grad, bool loss, float gy, float* loss
   if (((uintptr_t)ws & 255) != 0) return fail(SFM_ERR_WORKSPACE, "%s: workspace must be 256-byte aligned", who);
   bind_workspace(p, ws);
   const int ng = d->B * d->n_scales * d->n_src;
-#ifndef SFM_GEOM_IN_WAVE
+#ifdef SFM_GEOM_TABLE
   hipLaunchKernelGGL(geom_kernel, dim3((ng + 63) / 64), dim3(64), 0, st, p.args);
 #else
   (void)ng;

@@ -36,7 +36,11 @@ __device__ Stamps g_dummy_stamps;
 struct SsimCtx {
   // uniform (SGPR)
   float M1[3], P3[3];
+#ifdef SFM_GEOM_TABLE
   const __attribute__((address_space(4))) Geom* gp;   // the geometry entry of this (sample, scale, source): read again by pose_sums_expand
+#else
+  const float* Kp;      // intrinsics of this (sample, scale): pose_sums_expand inverts them again (33 instructions, off the row loop)
+#endif
   int x0;               // column of lane 0 (uniform); the lane's column is x0 + lane
   float k_pix;   // dL/d(sum |e|)        = gy (1-alpha) / (norm_B 3 h w)   base_model.py:111,117
   float kq;      // -dL/d(sum ssim)      = -gy alpha / (norm_B 3 h w): 2 kappa of App. A.3   base_model.py:115,117,142
@@ -53,9 +57,6 @@ struct SsimCtx {
   ScaleConst sc;
   // per lane
   float mx[3];          // M[k][0] x + M[k][2]
-#ifdef SFM_GEOM_IN_WAVE
-  float K1[3], kx[3];   // Kinv[j][1] (uniform), Kinv[j][0] x + Kinv[j][2]: for pose_sums_expand
-#endif
   float disp_first, disp_second;   // disparity of the first row a pass fetches (row y0 - halo, clamped into the image) and of the next
   unsigned xc;          // column, clamped into the image (address-safe for halo lanes)
   unsigned xc12;        // 12 xc: byte offset of the lane's texel in a pixel-interleaved row
@@ -175,6 +176,92 @@ __device__ __forceinline__ float vabs_sum(float d) { return fabsf(d); }
 __device__ __forceinline__ float vhadd(f2 v) { return v.x + v.y; }
 __device__ __forceinline__ float vhadd(float v) { return v; }
 
+// ------------------------------------------------------------------------------------------
+// The geometry of a pass -- proj_tgt_to_src (models/transform.py:64-91: euler2mat :11-40, pose_vec2mat :43-59, K4 . T :86-88) and
+// batch_inv(K) (:105) -- built by the wave itself at the start of the pass: no geometry kernel in front of the launch, no table.
+// A launch that waits for another launch costs ~2.5 us of a 60 us step; the same numbers made redundantly by every wave cost
+// ~120 vector instructions of the ~8000 of a pass, because the work is laid out over LANES where it is regular:
+//   * lane k (k = 0,1,2) holds angle k: ONE evaluation of the short-range sincos (angles are clipped to +-pi, :23) gives all three;
+//   * lane k holds ROW k of K: the products K . R, K . t and (K R) . K^-1 are 9 + 3 + 9 multiply-adds for all rows at once;
+//   * R = (X . Y) . Z in closed form -- products with the zeros and ones of X, Y, Z are exact in the general product too, so
+//     these are its values up to the fused roundings (14 instructions instead of 90);
+//   * K^-1 = adj(K) / det with ONE refined reciprocal instead of nine IEEE divisions.
+// The twelve numbers the row loop needs leave the lanes through v_readlane.
+// ------------------------------------------------------------------------------------------
+// three consecutive floats with one 12-byte load; only 4-byte alignment is guaranteed
+struct __attribute__((packed, aligned(4))) Rgb {
+  float c[3];
+};
+__device__ __forceinline__ Rgb load_rgb(const float* p) { return *reinterpret_cast<const Rgb*>(p); }
+struct __attribute__((packed, aligned(4))) K9 {
+  float k[9];
+};
+__device__ __forceinline__ K9 load_k9(const float* Kp) { return *reinterpret_cast<const K9*>(Kp); }
+
+__device__ __forceinline__ float from_lane(const float v, const int k) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
+}
+
+// batch_inv for one general 3x3 (models/transform.py:105), wave-uniform: cofactors as multiply + fused multiply-add, one reciprocal
+__device__ __forceinline__ void inv3_fast(const float* K, float* o) {
+  const float a = K[0], b = K[1], c = K[2], d = K[3], e = K[4], f = K[5], g = K[6], h = K[7], i = K[8];
+  const float A = fmaf(e, i, -(f * h)), B = fmaf(f, g, -(d * i)), Cc = fmaf(d, h, -(e * g));
+  const float det = fmaf(a, A, fmaf(b, B, c * Cc));
+  const float r = rcp_refined(det);
+  o[0] = A * r;
+  o[1] = fmaf(c, h, -(b * i)) * r;
+  o[2] = fmaf(b, f, -(c * e)) * r;
+  o[3] = B * r;
+  o[4] = fmaf(a, i, -(c * g)) * r;
+  o[5] = fmaf(c, d, -(a * f)) * r;
+  o[6] = Cc * r;
+  o[7] = fmaf(b, g, -(a * h)) * r;
+  o[8] = fmaf(a, e, -(b * d)) * r;
+}
+
+struct PassGeom {       // what the row loop needs of the geometry, wave-uniform
+  float M0[3], M1[3], M2[3];   // M = (K R) K^-1 by rows k: q = D (M . (x,y,1)) + P3
+  float P3[3];                 // K . t
+};
+
+__device__ __forceinline__ PassGeom build_pass_geom(const float* pose_b /* pose6 of this sample */, const float* Kp /* K of this (sample, scale) */,
+                                                    const int lane) {
+  const float pi = 3.14159265358979323846f;
+  const unsigned l2 = (unsigned)min(lane, 2), l5 = (unsigned)min(lane, 5);
+  // one batch of loads: the lane's pose component (lanes 0..2 the angles, 3..5 the translation), its row of K, and all of K
+  const float pv = ldf(pose_b, l5);
+  const Rgb Kr = ld_off<Rgb>(Kp, 12u * l2);
+  const K9 Ku = load_k9(Kp);
+  float sn, cs;
+  sincos_pi(fminf(fmaxf(pv, -pi), pi), &sn, &cs);                     // transform.py:23-25
+  const float sx = from_lane(sn, 0), sy = from_lane(sn, 1), sz = from_lane(sn, 2);
+  const float cx = from_lane(cs, 0), cy = from_lane(cs, 1), cz = from_lane(cs, 2);
+  const float tx = from_lane(pv, 3), ty = from_lane(pv, 4), tz = from_lane(pv, 5);
+  // X . Y = [[cy, 0, sy], [sx sy, cx, -sx cy], [-cx sy, sx, cx cy]] ;  R = (X . Y) . Z   (transform.py:27-39)
+  const float xy10 = sx * sy, xy20 = -(cx * sy);
+  const float R[9] = {cy * cz, -(cy * sz), sy,
+                      fmaf(xy10, cz, cx * sz), fmaf(-xy10, sz, cx * cz), -(sx * cy),
+                      fmaf(xy20, cz, sx * sz), fmaf(-xy20, sz, sx * cz), cx * cy};
+  float Kinv[9];
+  inv3_fast(Ku.k, Kinv);
+  // lane k: row k of P = K . [R | t] (transform.py:56-58,86-88) and of M = P[:, :3] . K^-1
+  float P[3], M[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) P[j] = fmaf(Kr.c[2], R[6 + j], fmaf(Kr.c[1], R[3 + j], Kr.c[0] * R[j]));
+  const float p3 = fmaf(Kr.c[2], tz, fmaf(Kr.c[1], ty, Kr.c[0] * tx));
+#pragma unroll
+  for (int j = 0; j < 3; ++j) M[j] = fmaf(P[2], Kinv[6 + j], fmaf(P[1], Kinv[3 + j], P[0] * Kinv[j]));
+  PassGeom g;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    g.M0[k] = from_lane(M[0], k);
+    g.M1[k] = from_lane(M[1], k);
+    g.M2[k] = from_lane(M[2], k);
+    g.P3[k] = from_lane(p3, k);
+  }
+  return g;
+}
+
 struct RowS {            // a warped row as the later stages need it (per lane = per pixel)
   Ch3 ih, it;            // I^ (0 where not in view / outside the image), I (0 outside the image)
   f2 duv0, duv1, duv_s;  // (dI^/du, dI^/dv) of channels 0, 1, 2 (of whatever the tap registers held where the sample is not in view: rzi
@@ -224,11 +311,6 @@ __device__ __forceinline__ void zero_rare(RowS& s) {
 }
 
 // stage A, first half: project row r and issue its loads (row r is inside the image)
-// three consecutive floats with one 12-byte load; only 4-byte alignment is guaranteed
-struct __attribute__((packed, aligned(4))) Rgb {
-  float c[3];
-};
-__device__ __forceinline__ Rgb load_rgb(const float* p) { return *reinterpret_cast<const Rgb*>(p); }
 struct __attribute__((packed, aligned(4))) Rgb2 {   // two horizontally adjacent pixel-interleaved texels: one 24-byte access
   float c[6];
 };
@@ -444,13 +526,19 @@ __device__ __forceinline__ void pose_sums_expand(const SsimCtx& C, const PoseAcc
   float K1[3], kx[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-#ifdef SFM_GEOM_IN_WAVE
-    K1[j] = C.K1[j]; kx[j] = C.kx[j]; (void)xf;
-#else
+#ifdef SFM_GEOM_TABLE
     K1[j] = C.gp->Kinv[j * 3 + 1];
     kx[j] = fmaf(C.gp->Kinv[j * 3 + 0], xf, C.gp->Kinv[j * 3 + 2]);
 #endif
   }
+#ifndef SFM_GEOM_TABLE
+  {
+    float Kinv[9];
+    inv3_fast(load_k9(C.Kp).k, Kinv);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { K1[j] = Kinv[j * 3 + 1]; kx[j] = fmaf(Kinv[j * 3 + 0], xf, Kinv[j * 3 + 2]); }
+  }
+#endif
   float v[12];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {

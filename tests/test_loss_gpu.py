@@ -214,11 +214,13 @@ def pose_explained_by_discontinuities(d, cfg, ref, i, got, norm_B=None, cell_thr
     """Third opinion for d_pose[i] (B,6): is the kernel's value the ORACLE's with a few named pixels on the other side of a
     discontinuity they sit on?  For every sample whose d_pose row is off by more than a quarter of the gradient tolerance, the
     fp32 oracle is re-run on that sample and source alone (same normalisation: norm_batch) with ONE knife-edge pixel's disparity
-    nudged by +-1e-3 / +-1e-2 of its value (or its target texel by +-1e-4: the kink of |I^ - I|); a nudge that makes d_pose JUMP (by more than 1e-4 of its maximum; the smooth response
-    to such a nudge is <= 1e-2 of one pixel's share, 1e-5) is that pixel taking its other branch.  Jumps are then picked greedily
-    (each pixel once, only while the distance to the kernel's row shrinks by > 10 %, and AT MOST `max_jumps` per sample: with
-    dozens of free 6-vectors a genuine error could be fitted away -- round-3 advisor finding).  Returns the oracle's array with the
-    picked jumps added and the list of pixels; the caller judges the kernel against it with the flat criteria."""
+    nudged by +-1e-3 / +-1e-2 of its value (or its target texel by +-1e-4: the kink of |I^ - I|); a nudge that makes d_pose JUMP
+    (by more than 1e-4 of its maximum; the smooth response to such a nudge is <= 1e-2 of one pixel's share, 1e-5) is that pixel
+    taking its other branch.  The knife-edge pixels of the sample are probed one at a time, the most decisive first (see below),
+    at most `max_px` of them; a pixel's jump is taken only when it removes at least 30 % of what is left of the difference, AT
+    MOST `max_jumps` per sample (with dozens of free 6-vectors a genuine error could be fitted away: round-3 advisor finding),
+    and the search stops as soon as the rest is below the trigger.  Returns the oracle's array with the taken jumps added and the
+    list of pixels; the caller judges the kernel against it with the flat criteria."""
     want = np.asarray(ref["d_poses"][i], np.float64)
     got = np.asarray(got, np.float64)
     scale = float(np.abs(want).max())
@@ -245,46 +247,58 @@ def pose_explained_by_discontinuities(d, cfg, ref, i, got, norm_B=None, cell_thr
             m = ((ref["margin"][s][b, i] < 8e-6) | (ref["cell_margin"][s][b, i] < cell_thr) | (ref["abs_margin"][s][b, i] < 3e-5)
                  | (ref["clip_margin"][s][b, i] < 5e-5))
             cands += [(s, int(y), int(x)) for y, x in np.argwhere(m)]
-        if len(cands) > max_px:
-            return None, "sample %d has %d knife-edge pixels (> %d): too many to probe" % (b, len(cands), max_px)
-        jumps = []
+        # Probed ONE BY ONE, the most decisive first: pixels on the strict in-view test (the whole term appears / disappears), then
+        # by how uncertain the sampling position is (near-singular samples, |z| small, carry the largest terms of the sums and the
+        # least decided branch); at most `max_px` probes, and the search stops as soon as the residual is explained.
+        unc = {}
+        for s in range(S):
+            dU, dV = position_tolerance(d, s)
+            unc[s] = np.maximum(dU[b, i], dV[b, i])
+        cands.sort(key=lambda c: (not ref["margin"][c[0]][b, i, c[1], c[2]] < 8e-6, -float(unc[c[0]][c[1], c[2]])))
+        n_cands, cands = len(cands), cands[:max_px]
 
-        def note(p_, dlt):
-            if np.abs(dlt).max() > 1e-4 * scale and not any(p == p_ and np.abs(dlt - q).max() < 1e-5 * scale for p, q in jumps):
-                jumps.append((p_, dlt))
+        def probe(s, y, x):
+            jumps = []
 
-        for (s, y, x) in cands:
+            def note(dlt):
+                if np.abs(dlt).max() > 1e-4 * scale and not any(np.abs(dlt - q).max() < 1e-5 * scale for q in jumps):
+                    jumps.append(dlt)
+
             for rel in (1e-3, -1e-3, 1e-2, -1e-2):
                 disps = [a.copy() for a in disps0]
                 disps[s][0, 0, y, x] *= np.float32(1 + rel)
-                note((s, y, x), pose_grad(disps) - base)
+                note(pose_grad(disps) - base)
             # the kink of |I^ - I| is crossed most directly from the target's side: the pixel's three channels moved by +-1e-4
             # (more than the 3e-5 within which the knife mask puts a pixel on the kink, 1e-4 of the image range)
             for dt in (1e-4, -1e-4):
                 tgt = [a.copy() for a in base_in["tgt_pyr"]]
                 tgt[s][0, :, y, x] += np.float32(dt)
                 dlt = pose_grad(disps0, tgt) - base
-                note((s, y, x), dlt)
+                note(dlt)
                 # ... and the kink has a value of its own: F.absolute's backward is sign(0) = 0 where one evaluation finds
                 # I^ - I == 0 exactly -- half way between the two signs
                 if ref["abs_margin"][s][b, i, y, x] < 3e-5:
-                    note((s, y, x), 0.5 * dlt)
-        if os.environ.get("SFM_EXPLAIN_DEBUG"):
-            print("explain sample %d: residual/scale %s" % (b, (got[b] - want[b]) / scale))
-            for p_, dlt in jumps:
-                print("   jump at %s: %s" % (p_, dlt / scale))
-        res, used = got[b] - want[b], set()
-        while len(used) < max_jumps:
-            best = None
-            for p, dlt in jumps:
-                if p not in used and (best is None or np.linalg.norm(res - dlt) < np.linalg.norm(res - best[1])):
-                    best = (p, dlt)
-            if best is None or np.linalg.norm(res - best[1]) > 0.9 * np.linalg.norm(res):
+                    note(0.5 * dlt)
+            return jumps
+
+        res, used = got[b] - want[b], 0
+        for (s, y, x) in cands:
+            if used >= max_jumps or np.abs(res).max() <= 0.25 * GRAD_TOL * scale:
                 break
-            used.add(best[0])
-            res = res - best[1]
-            out[b] += best[1]
-            named.append("sample %d scale %d pixel (%d,%d)" % ((b,) + best[0]))
+            jumps = probe(s, y, x)
+            if os.environ.get("SFM_EXPLAIN_DEBUG"):
+                print("explain sample %d: residual/scale %s; probe %s: %d jumps" % (b, res / scale, (s, y, x), len(jumps)))
+            if not jumps:
+                continue
+            best = min(jumps, key=lambda dlt: np.linalg.norm(res - dlt))
+            if np.linalg.norm(res - best) > 0.7 * np.linalg.norm(res):      # a named pixel must carry a real share of the difference
+                continue
+            used += 1
+            res = res - best
+            out[b] += best
+            named.append("sample %d scale %d pixel (%d,%d)" % (b, s, y, x))
+        if os.environ.get("SFM_EXPLAIN_DEBUG"):
+            print("explain sample %d: %d candidates, %d probed at most, named %s" % (b, n_cands, len(cands), named))
     return out, named
 
 
@@ -574,7 +588,10 @@ def test_full_batch_vs_oracle(ops, synth, dev, cfg_name, B, H, W, n_src):
     # cell_thr: among 1.7 million samples one lands 1.2e-4 px from a lattice line (sample 0, scale 0, (11, 397), U = 361.9999) and
     # is placed in the neighbouring cell by the kernel (dI^/du jumps there); the cell-boundary class is as wide as the fp32
     # uncertainty of each sample's position (oracle/parity.py: 1 .. 2e-4 px here), not a hand-set constant
-    _check_grads(fl, ref, n_src, what=what, ref64=ref64, **knife_widths(d, ref))
+    # (last rung, printed when used: a d_pose array that misses everything else is re-judged against the oracle with single NAMED
+    #  knife-edge pixels on their other branch -- at most two per sample, at most 16 probed)
+    explain = lambda i, got: pose_explained_by_discontinuities(d, cfg, ref, i, got, max_px=16)
+    _check_grads(fl, ref, n_src, what=what, ref64=ref64, explain=explain, **knife_widths(d, ref))
     count_in_view_mismatches(ops, dev, d, ref, "hwc", what)
 
 
@@ -637,10 +654,11 @@ def test_large_motion_vs_oracle(ops, synth, dev, motion, cfg_name, B, H, W, n_sr
         assert oov > (0.15 if motion == "medium" else 0.5)
     ref64 = lambda: O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], d["masks"], backward=True,
                                keep_warped=True, dtype=np.float64, **cfg)
+    explain = lambda i, got: pose_explained_by_discontinuities(d, cfg, ref, i, got)
     fl = _bind(ops, dev, d, cfg, layout=layout, want_warped=True)
     _check_losses(fl.forward_backward(), ref)
     _check_warped(fl, ref, what, d)
-    _check_grads(fl, ref, n_src, what=what, ref64=ref64, check_mask=bool(cfg.get("exp_reg")), **knife_widths(d, ref))
+    _check_grads(fl, ref, n_src, what=what, ref64=ref64, explain=explain, check_mask=bool(cfg.get("exp_reg")), **knife_widths(d, ref))
     count_in_view_mismatches(ops, dev, d, ref, layout, what)
 
 
@@ -655,10 +673,13 @@ def test_large_motion_full_batch_vs_oracle(ops, synth, dev, motion):
     motion_stats(d, ref, what)
     ref64 = lambda: O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], None, backward=True,
                                keep_warped=True, dtype=np.float64, **cfg)
+    # (a d_pose array that misses everything else: the few least certain knife-edge pixels of the sample are probed, see
+    #  pose_explained_by_discontinuities -- behind the camera single near-singular samples carry whole percents of a sum)
+    explain = lambda i, got: pose_explained_by_discontinuities(d, cfg, ref, i, got, max_px=24)
     fl = _bind(ops, dev, d, cfg, layout="hwc", want_warped=True)
     _check_losses(fl.forward_backward(), ref)
     _check_warped(fl, ref, what, d)
-    _check_grads(fl, ref, 2, what=what, ref64=ref64, **knife_widths(d, ref))
+    _check_grads(fl, ref, 2, what=what, ref64=ref64, explain=explain, **knife_widths(d, ref))
 
 
 @pytest.mark.parametrize("cfg_name,B,H,W,n_src", [
