@@ -15,9 +15,9 @@
 //   * the 3x3 SSIM pools and their transposes are separable sums over those two,
 //   * depth gradients of all sources are summed in a wave-private LDS tile and d_disp is
 //     written exactly once, coalesced; the 12 sums of dL/dPm are reduced in-wavefront.
-// All scales, sources and samples of a step are covered by ONE launch of loss_kernel, between two tiny ones:
-// geom_kernel builds the geometry table of every (sample, scale, source) first, finalize_kernel reduces the
-// per-wave partials in a fixed order (bitwise reproducible) and finishes d_pose.
+// All scales, sources and samples of a step are covered by ONE launch of loss_kernel (every wave builds the geometry of its
+// passes itself: sfm_ssim_pass.h, build_pass_geom), followed by a tiny one: finalize_kernel reduces the per-wave partials in a
+// fixed order (bitwise reproducible) and finishes d_pose.
 #include <stdlib.h>
 #include <string.h>
 
@@ -65,7 +65,6 @@ struct LossArgs {
   int tiles_of[SFM_MAX_SCALES];        // sc[s].tiles, 0 beyond n_scales
   int item_begin_of[SFM_MAX_SCALES];   // sc[s].item_begin
   const float* intrinsics;
-  Geom* geom;        // [B][n_scales][n_src]
   float* part_loss;  // [items][4]   pixel, ssim, smooth, exp
   float* part_gpm;   // [items][n_src][12]
   float gy;          // upstream gradient on total_loss
@@ -90,30 +89,6 @@ static int strip_width(bool ssim, bool grad, int smode) {
   const int hr = hs > hm ? hs : hm;
   const int hl = grad ? hr : hs;
   return 64 - hl - hr;
-}
-
-// ------------------------------------------------------------------------------------------
-// geometry table
-// ------------------------------------------------------------------------------------------
-__global__ void geom_kernel(const LossArgs A) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int total = A.B * A.n_scales * A.n_src;
-  if (t >= total) return;
-  const int i = t % A.n_src;
-  const int bs = t / A.n_src;  // b * n_scales + s
-  const int b = bs / A.n_scales;
-  // (the pose pointer is SELECTED from the argument block, not loaded through a lane-dependent index: that load would be one more
-  //  round trip to memory in front of the pose itself -- this kernel is nothing but a chain of such round trips)
-  const float* pp = nullptr;
-#pragma unroll
-  for (int k = 0; k < SFM_MAX_SRC; ++k) {
-    const float* pk = A.pose[k];
-    asm volatile("" : "+s"(pk));     // (keeps the selection from being folded back into an indexed load)
-    pp = (i == k) ? pk : pp;
-  }
-  Geom g;
-  make_geom(pp + b * 6, A.intrinsics + (size_t)bs * 9, g);
-  A.geom[t] = g;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -306,7 +281,7 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
   // start of every wave, with the whole chip waiting.
   asm volatile("" ::"s"(A.B), "s"(A.n_src), "s"(A.n_scales), "s"(A.items), "s"(A.simds_per_xcd), "s"(A.prio_top), "s"(A.prio_tab),
                "s"(A.tiles_of[0]), "s"(A.tiles_of[1]), "s"(A.tiles_of[2]), "s"(A.tiles_of[3]), "s"(A.tiles_of[4]), "s"(A.tiles_of[5]),
-               "s"(A.tiles_of[6]), "s"(A.tiles_of[7]), "s"(A.geom), "s"(A.trace));
+               "s"(A.tiles_of[6]), "s"(A.tiles_of[7]), "s"(A.trace));
   const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
   int s = 0, b, t;
   if (A.B >= 8) {
@@ -433,19 +408,6 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
     SsimCtx C;
     const float xf = (float)x;
     C.x0 = x - lane;
-#ifdef SFM_GEOM_TABLE   // A/B build only: the round-3 form (geom_kernel in front of the launch writes a table, read here with scalar loads)
-    {
-      typedef const __attribute__((address_space(4))) Geom* GeomConstPtr;
-      GeomConstPtr gp = (GeomConstPtr)(uintptr_t)(A.geom + ((size_t)(b * A.n_scales + s) * A.n_src + i));
-      C.gp = gp;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        C.M1[k] = gp->M[k * 3 + 1];
-        C.P3[k] = gp->P[k * 4 + 3];
-        C.mx[k] = fmaf(gp->M[k * 3 + 0], xf, gp->M[k * 3 + 2]);
-      }
-    }
-#else
     {
       // (the pose pointer is SELECTED from the argument block, not loaded through an index: see finalize_kernel)
       const float* pp = A.pose[0];
@@ -460,7 +422,6 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
         C.mx[k] = fmaf(g.M0[k], xf, g.M2[k]);
       }
     }
-#endif
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       C.tp[k] = S.tgt + ((size_t)b * 3 + k) * P;
@@ -753,7 +714,7 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const Los
 // ------------------------------------------------------------------------------------------
 struct Plan {
   LossArgs args;
-  size_t off_geom, off_loss, off_gpm, total;
+  size_t off_loss, off_gpm, total;
   bool ssim, expl, hwc;
   bool wide;     // the three-waves-per-SIMD build of an L1 gradient kernel (see loss_kernel)
   bool warped;   // the instantiation that also writes SfmLossDesc.warped
@@ -987,8 +948,7 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
   // and sized for the largest item count any chunking can produce.
   const size_t cap = (size_t)max_items(d, sw);
   if ((size_t)items > cap) return fail(SFM_ERR_CONFIG, "sfm_loss: internal error: %d items exceed the bound %zu", items, cap);
-  p.off_geom = 0;
-  p.off_loss = align_up(p.off_geom + (size_t)d->B * d->n_scales * d->n_src * sizeof(Geom), 256);
+  p.off_loss = 0;
   p.off_gpm = align_up(p.off_loss + cap * 4 * sizeof(float), 256);
   p.total = align_up(p.off_gpm + cap * d->n_src * 12 * sizeof(float), 256);
   return SFM_OK;
@@ -1007,7 +967,6 @@ static void set_gy(Plan& p, const float gy) {
 
 static void bind_workspace(Plan& p, void* ws) {
   char* base = (char*)ws;
-  p.args.geom = (Geom*)(base + p.off_geom);
   p.args.part_loss = (float*)(base + p.off_loss);
   p.args.part_gpm = (float*)(base + p.off_gpm);
 }
@@ -1107,12 +1066,6 @@ static int run(const SfmLossDesc* d, bool grad, bool loss, float gy, float* loss
   if (!ws || ws_bytes < p.total) return fail(SFM_ERR_WORKSPACE, "%s: workspace of %zu bytes needed, got %zu", who, p.total, ws_bytes);
   if (((uintptr_t)ws & 255) != 0) return fail(SFM_ERR_WORKSPACE, "%s: workspace must be 256-byte aligned", who);
   bind_workspace(p, ws);
-  const int ng = d->B * d->n_scales * d->n_src;
-#ifdef SFM_GEOM_TABLE
-  hipLaunchKernelGGL(geom_kernel, dim3((ng + 63) / 64), dim3(64), 0, st, p.args);
-#else
-  (void)ng;
-#endif
   p.args.trace = g_trace;
   g_trace = nullptr;
   hipEvent_t ev_start = g_ev_start, ev_stop = g_ev_stop;

@@ -36,11 +36,7 @@ __device__ Stamps g_dummy_stamps;
 struct SsimCtx {
   // uniform (SGPR)
   float M1[3], P3[3];
-#ifdef SFM_GEOM_TABLE
-  const __attribute__((address_space(4))) Geom* gp;   // the geometry entry of this (sample, scale, source): read again by pose_sums_expand
-#else
   const float* Kp;      // intrinsics of this (sample, scale): pose_sums_expand inverts them again (33 instructions, off the row loop)
-#endif
   int x0;               // column of lane 0 (uniform); the lane's column is x0 + lane
   float k_pix;   // dL/d(sum |e|)        = gy (1-alpha) / (norm_B 3 h w)   base_model.py:111,117
   float kq;      // -dL/d(sum ssim)      = -gy alpha / (norm_B 3 h w): 2 kappa of App. A.3   base_model.py:115,117,142
@@ -526,19 +522,13 @@ __device__ __forceinline__ void pose_sums_expand(const SsimCtx& C, const PoseAcc
   float K1[3], kx[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-#ifdef SFM_GEOM_TABLE
-    K1[j] = C.gp->Kinv[j * 3 + 1];
-    kx[j] = fmaf(C.gp->Kinv[j * 3 + 0], xf, C.gp->Kinv[j * 3 + 2]);
-#endif
   }
-#ifndef SFM_GEOM_TABLE
   {
     float Kinv[9];
     inv3_fast(load_k9(C.Kp).k, Kinv);
 #pragma unroll
     for (int j = 0; j < 3; ++j) { K1[j] = Kinv[j * 3 + 1]; kx[j] = fmaf(Kinv[j * 3 + 0], xf, Kinv[j * 3 + 2]); }
   }
-#endif
   float v[12];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
