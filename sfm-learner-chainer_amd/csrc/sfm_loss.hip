@@ -376,6 +376,9 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
     disp_first = ldf(dpl, (unsigned)min(max(rfirst, 0), h - 1) * (unsigned)w + xcl);
     disp_second = ldf(dpl, (unsigned)min(max(rfirst + 1, 0), h - 1) * (unsigned)w + xcl);
   }
+  // the geometry of every source pass of this wave (sfm_ssim_pass.h, build_wave_geom), its loads in the same batch as the disparities
+  static_assert(SFM_MAX_SRC * 8 <= 64, "one group of eight lanes per source");
+  const WaveGeom WG = build_wave_geom([&](const int g) { return A.pose[g]; }, A.n_src, b, A.intrinsics + (size_t)(b * A.n_scales + s) * 9, lane);
 #ifdef SFM_STAMPS
   Stamps st = {0, 0, 0, 0, 0};
   unsigned long long ts0 = 0, cyc_smooth = 0, cyc_src = 0;
@@ -409,17 +412,12 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
     const float xf = (float)x;
     C.x0 = x - lane;
     {
-      // (the pose pointer is SELECTED from the argument block, not loaded through an index: see finalize_kernel)
-      const float* pp = A.pose[0];
-#pragma unroll
-      for (int k = 1; k < SFM_MAX_SRC; ++k) pp = (i == k) ? A.pose[k] : pp;
-      C.Kp = A.intrinsics + (size_t)(b * A.n_scales + s) * 9;
-      const PassGeom g = build_pass_geom(pp + b * 6, C.Kp, lane);
+      // the twelve numbers of this pass out of the wave's geometry rows (lane 8 i + k: row k of source i)
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        C.M1[k] = g.M1[k];
-        C.P3[k] = g.P3[k];
-        C.mx[k] = fmaf(g.M0[k], xf, g.M2[k]);
+        C.M1[k] = from_lane(WG.M1, 8 * i + k);
+        C.P3[k] = from_lane(WG.P3, 8 * i + k);
+        C.mx[k] = fmaf(from_lane(WG.M0, 8 * i + k), xf, from_lane(WG.M2, 8 * i + k));
       }
     }
 #pragma unroll
@@ -589,10 +587,18 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const Los
     const float* Kp_ = A.intrinsics + ((size_t)b * A.n_scales + s_) * 9;                                                          \
     _Pragma("unroll") for (int k = 0; k < 9; ++k) K_[k] = Kp_[k];                                                                 \
   }
-    // gT3 += K^T . gPm   (K4^T . gPm of the rows that reach R and t)
+    // the tile's raw pose sums S_k = (sum x A_k, B_k, A_k, C_k) (pose_sums_raw) -> dL/dPm[k][j] = Kinv[j] . S_k[0:3], [k][3] = S_k[3];
+    // then gT3 += K^T . gPm   (K4^T . gPm of the rows that reach R and t)
 #define SFM_FIN_FOLD(v0_, v1_, v2_, K_)                                                                                           \
   {                                                                                                                               \
-    const float g_[12] = {v0_.x, v0_.y, v0_.z, v0_.w, v1_.x, v1_.y, v1_.z, v1_.w, v2_.x, v2_.y, v2_.z, v2_.w};                    \
+    const float s_[12] = {v0_.x, v0_.y, v0_.z, v0_.w, v1_.x, v1_.y, v1_.z, v1_.w, v2_.x, v2_.y, v2_.z, v2_.w};                    \
+    float Ki_[9], g_[12];                                                                                                         \
+    inv3_fast(K_, Ki_);                                                                                                           \
+    _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                                                               \
+      _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                                               \
+          g_[k * 4 + j] = fmaf(Ki_[j * 3 + 2], s_[k * 4 + 2], fmaf(Ki_[j * 3 + 1], s_[k * 4 + 1], Ki_[j * 3 + 0] * s_[k * 4 + 0])); \
+      g_[k * 4 + 3] = s_[k * 4 + 3];                                                                                              \
+    }                                                                                                                             \
     _Pragma("unroll") for (int r = 0; r < 3; ++r)                                                                                 \
         _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                             \
             gT3[r * 4 + c] += K_[0 * 3 + r] * g_[0 * 4 + c] + K_[1 * 3 + r] * g_[1 * 4 + c] + K_[2 * 3 + r] * g_[2 * 4 + c];      \

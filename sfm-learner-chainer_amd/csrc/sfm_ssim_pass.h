@@ -36,7 +36,6 @@ __device__ Stamps g_dummy_stamps;
 struct SsimCtx {
   // uniform (SGPR)
   float M1[3], P3[3];
-  const float* Kp;      // intrinsics of this (sample, scale): pose_sums_expand inverts them again (33 instructions, off the row loop)
   int x0;               // column of lane 0 (uniform); the lane's column is x0 + lane
   float k_pix;   // dL/d(sum |e|)        = gy (1-alpha) / (norm_B 3 h w)   base_model.py:111,117
   float kq;      // -dL/d(sum ssim)      = -gy alpha / (norm_B 3 h w): 2 kappa of App. A.3   base_model.py:115,117,142
@@ -173,16 +172,19 @@ __device__ __forceinline__ float vhadd(f2 v) { return v.x + v.y; }
 __device__ __forceinline__ float vhadd(float v) { return v; }
 
 // ------------------------------------------------------------------------------------------
-// The geometry of a pass -- proj_tgt_to_src (models/transform.py:64-91: euler2mat :11-40, pose_vec2mat :43-59, K4 . T :86-88) and
-// batch_inv(K) (:105) -- built by the wave itself at the start of the pass: no geometry kernel in front of the launch, no table.
-// A launch that waits for another launch costs ~2.5 us of a 60 us step; the same numbers made redundantly by every wave cost
-// ~120 vector instructions of the ~8000 of a pass, because the work is laid out over LANES where it is regular:
-//   * lane k (k = 0,1,2) holds angle k: ONE evaluation of the short-range sincos (angles are clipped to +-pi, :23) gives all three;
-//   * lane k holds ROW k of K: the products K . R, K . t and (K R) . K^-1 are 9 + 3 + 9 multiply-adds for all rows at once;
+// The geometry of a wave's passes -- proj_tgt_to_src (models/transform.py:64-91: euler2mat :11-40, pose_vec2mat :43-59, K4 . T
+// :86-88) and batch_inv(K) (:105) for every source of its (sample, scale) -- built by the wave itself, ONCE, at its start: no
+// geometry kernel in front of the launch, no table.  A launch that waits for another launch costs ~2.5 us of a 60 us step
+// (profiles/r04_ab_geom_in_wave.txt); the same numbers made redundantly by every wave cost ~100 vector instructions of the
+// ~17000 of a wave, because the work is laid out over LANES where it is regular:
+//   * lanes 8g .. 8g+7 belong to source g; lane 8g+k (k = 0,1,2) holds angle k of its pose and ROW k of K, lanes 8g+3..5 the
+//     translation: ONE evaluation of the short-range sincos (angles are clipped to +-pi, :23) gives all angles of all sources, and
+//     the products K . R, K . t and (K R) . K^-1 are 9 + 3 + 9 multiply-adds for all rows of all sources at once;
 //   * R = (X . Y) . Z in closed form -- products with the zeros and ones of X, Y, Z are exact in the general product too, so
 //     these are its values up to the fused roundings (14 instructions instead of 90);
 //   * K^-1 = adj(K) / det with ONE refined reciprocal instead of nine IEEE divisions.
-// The twelve numbers the row loop needs leave the lanes through v_readlane.
+// The rows stay in their lanes (four registers for the life of the wave); a pass takes the twelve numbers its row loop needs
+// out of them with v_readlane.  (K^-1 is NOT needed again: the pose sums leave the wave un-multiplied, see pose_sums_raw.)
 // ------------------------------------------------------------------------------------------
 // three consecutive floats with one 12-byte load; only 4-byte alignment is guaranteed
 struct __attribute__((packed, aligned(4))) Rgb {
@@ -196,6 +198,10 @@ __device__ __forceinline__ K9 load_k9(const float* Kp) { return *reinterpret_cas
 
 __device__ __forceinline__ float from_lane(const float v, const int k) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
+}
+// the value of lane `src` (a per-lane index; ds_bpermute: the LDS crossbar, no LDS memory, no vector-ALU slot)
+__device__ __forceinline__ float from_lane_v(const float v, const int src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, v)));
 }
 
 // batch_inv for one general 3x3 (models/transform.py:105), wave-uniform: cofactors as multiply + fused multiply-add, one reciprocal
@@ -215,24 +221,30 @@ __device__ __forceinline__ void inv3_fast(const float* K, float* o) {
   o[8] = fmaf(a, e, -(b * d)) * r;
 }
 
-struct PassGeom {       // what the row loop needs of the geometry, wave-uniform
-  float M0[3], M1[3], M2[3];   // M = (K R) K^-1 by rows k: q = D (M . (x,y,1)) + P3
-  float P3[3];                 // K . t
+struct WaveGeom {       // lane 8g+k: row k of source g (per-lane registers, alive for the whole wave)
+  float M0, M1, M2;     // M = (K R) K^-1:  q = D (M . (x,y,1)) + P3
+  float P3;             // K . t
 };
 
-__device__ __forceinline__ PassGeom build_pass_geom(const float* pose_b /* pose6 of this sample */, const float* Kp /* K of this (sample, scale) */,
+// pose_of(g): pointer to the (B,6) pose array of source g (wave-uniform)
+template <typename PoseOf>
+__device__ __forceinline__ WaveGeom build_wave_geom(const PoseOf pose_of, const int n_src, const int b, const float* Kp /* K of this (sample, scale) */,
                                                     const int lane) {
   const float pi = 3.14159265358979323846f;
-  const unsigned l2 = (unsigned)min(lane, 2), l5 = (unsigned)min(lane, 5);
-  // one batch of loads: the lane's pose component (lanes 0..2 the angles, 3..5 the translation), its row of K, and all of K
-  const float pv = ldf(pose_b, l5);
-  const Rgb Kr = ld_off<Rgb>(Kp, 12u * l2);
+  const int grp = lane >> 3, sub = lane & 7, base = lane & ~7;
+  // one batch of loads: the lane's pose component (sub 0..2 the angles, 3..5 the translation) of ITS source, its row of K, all of K
+  float pv = 0.f;
+  for (int g = 0; g < n_src; ++g) {               // (wave-uniform trip count; one load per source, under the lanes of its group)
+    const float* pg = pose_of(g) + b * 6;
+    if (grp == g) pv = ldf(pg, (unsigned)min(sub, 5));
+  }
+  const Rgb Kr = ld_off<Rgb>(Kp, 12u * (unsigned)min(sub, 2));
   const K9 Ku = load_k9(Kp);
   float sn, cs;
   sincos_pi(fminf(fmaxf(pv, -pi), pi), &sn, &cs);                     // transform.py:23-25
-  const float sx = from_lane(sn, 0), sy = from_lane(sn, 1), sz = from_lane(sn, 2);
-  const float cx = from_lane(cs, 0), cy = from_lane(cs, 1), cz = from_lane(cs, 2);
-  const float tx = from_lane(pv, 3), ty = from_lane(pv, 4), tz = from_lane(pv, 5);
+  const float sx = from_lane_v(sn, base), sy = from_lane_v(sn, base + 1), sz = from_lane_v(sn, base + 2);
+  const float cx = from_lane_v(cs, base), cy = from_lane_v(cs, base + 1), cz = from_lane_v(cs, base + 2);
+  const float tx = from_lane_v(pv, base + 3), ty = from_lane_v(pv, base + 4), tz = from_lane_v(pv, base + 5);
   // X . Y = [[cy, 0, sy], [sx sy, cx, -sx cy], [-cx sy, sx, cx cy]] ;  R = (X . Y) . Z   (transform.py:27-39)
   const float xy10 = sx * sy, xy20 = -(cx * sy);
   const float R[9] = {cy * cz, -(cy * sz), sy,
@@ -240,21 +252,15 @@ __device__ __forceinline__ PassGeom build_pass_geom(const float* pose_b /* pose6
                       fmaf(xy20, cz, sx * sz), fmaf(-xy20, sz, sx * cz), cx * cy};
   float Kinv[9];
   inv3_fast(Ku.k, Kinv);
-  // lane k: row k of P = K . [R | t] (transform.py:56-58,86-88) and of M = P[:, :3] . K^-1
-  float P[3], M[3];
+  // lane 8g+k: row k of P = K . [R | t] (transform.py:56-58,86-88) and of M = P[:, :3] . K^-1
+  float P[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) P[j] = fmaf(Kr.c[2], R[6 + j], fmaf(Kr.c[1], R[3 + j], Kr.c[0] * R[j]));
-  const float p3 = fmaf(Kr.c[2], tz, fmaf(Kr.c[1], ty, Kr.c[0] * tx));
-#pragma unroll
-  for (int j = 0; j < 3; ++j) M[j] = fmaf(P[2], Kinv[6 + j], fmaf(P[1], Kinv[3 + j], P[0] * Kinv[j]));
-  PassGeom g;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    g.M0[k] = from_lane(M[0], k);
-    g.M1[k] = from_lane(M[1], k);
-    g.M2[k] = from_lane(M[2], k);
-    g.P3[k] = from_lane(p3, k);
-  }
+  WaveGeom g;
+  g.P3 = fmaf(Kr.c[2], tz, fmaf(Kr.c[1], ty, Kr.c[0] * tx));
+  g.M0 = fmaf(P[2], Kinv[6], fmaf(P[1], Kinv[3], P[0] * Kinv[0]));
+  g.M1 = fmaf(P[2], Kinv[7], fmaf(P[1], Kinv[4], P[0] * Kinv[1]));
+  g.M2 = fmaf(P[2], Kinv[8], fmaf(P[1], Kinv[5], P[0] * Kinv[2]));
   return g;
 }
 
@@ -490,7 +496,7 @@ __device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& 
   else *ga = *ga + gdisp;
   // dL/dPm[k][j] = sum over pixels of gq_k * c_j with c = D * (K1 y + kx) (the back-projected point), c_3 = 1.  The ray
   // is linear in the row, so a lane only accumulates  A_k = sum gq_k D,  B_k = sum y gq_k D,  C_k = sum gq_k  (9 values
-  // instead of 12) and expands them once per pass: gpm[k][j] = K1[j] B_k + kx[j] A_k, K1 = Kinv[:,1], kx = Kinv[:,0] x + Kinv[:,2]   (pose_sums_expand)
+  // instead of 12); pose_sums_raw reduces them over the wave once per pass and finalize_kernel multiplies K^-1 in
   gpm.A += t; gpm.A2 += t2;
   gpm.B = vfma(T_of<f2>(yf), t, gpm.B); gpm.B2 = fmaf(yf, t2, gpm.B2);
   gpm.Cq += gq; gpm.C2 += gq2;
@@ -511,29 +517,23 @@ __device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& 
   }
 }
 
-// the 12 sums of dL/dPm of this (wave, source) from the 9 per-lane accumulators of geometry_backward.
+// The pose sums of this (wave, source) from the 9 per-lane accumulators of geometry_backward.  dL/dPm[k][j] = sum over pixels of
+// gq_k c_j with c = D K^-1 (x,y,1) the back-projected point (c_3 = 1), i.e. with A_k = sum gq_k D, B_k = sum y gq_k D, C_k = sum gq_k:
+//   dL/dPm[k][j] = Kinv[j][0] (sum x A_k) + Kinv[j][1] B_k + Kinv[j][2] A_k ,   dL/dPm[k][3] = C_k .
+// The wave writes the RAW sums (sum x A_k, B_k, A_k, C_k), k = 0..2; finalize_kernel, which holds K of the scale anyway for
+// K^T . gPm, multiplies K^-1 in once per tile: K^-1 never enters the main kernel's passes.
 // The twelve wave reductions run in LOCKSTEP (stage by stage over all twelve values): twelve independent DPP adds per stage
 // instead of twelve dependent chains of six (each link of a chain waits for the previous one; 2.7-3.9k cycles per pass in
 // profiles/r02_wave_stage_stamps.txt).  Same adds in the same order per value: the sums are bit-identical to wave_sum's.
-__device__ __forceinline__ void pose_sums_expand(const SsimCtx& C, const PoseAcc& pa, float* gpm_out) {
+__device__ __forceinline__ void pose_sums_raw(const SsimCtx& C, const PoseAcc& pa, float* gpm_out) {
   const float acc[9] = {pa.A.x, pa.A.y, pa.A2, pa.B.x, pa.B.y, pa.B2, pa.Cq.x, pa.Cq.y, pa.C2};
-  // K1[j] = Kinv[j][1], kx[j] = Kinv[j][0] x + Kinv[j][2]: only needed here, so neither lives through the row loop
   const float xf = (float)(C.x0 + C.lane);
-  float K1[3], kx[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-  }
-  {
-    float Kinv[9];
-    inv3_fast(load_k9(C.Kp).k, Kinv);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { K1[j] = Kinv[j * 3 + 1]; kx[j] = fmaf(Kinv[j * 3 + 0], xf, Kinv[j * 3 + 2]); }
-  }
   float v[12];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) v[k * 4 + j] = fmaf(K1[j], acc[3 + k], kx[j] * acc[k]);
+    v[k * 4 + 0] = xf * acc[k];
+    v[k * 4 + 1] = acc[3 + k];
+    v[k * 4 + 2] = acc[k];
     v[k * 4 + 3] = acc[6 + k];
   }
   wave_sums_lockstep(v);
@@ -768,7 +768,7 @@ __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, 
     if (k + 2 < n)
       ssim_row_step<GRAD, LOSS, HWC, WARPED>(C, M, k + 2, r + 2, ps, disp_next, S2, S1, S0, G2, G1, G0, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
   }
-  if (GRAD) pose_sums_expand(C, gpm, gpm_out);
+  if (GRAD) pose_sums_raw(C, gpm, gpm_out);
 }
 
 // Photometric pass WITHOUT SSIM for one (wave, source): L1 (+ explainability weighting, base_model.py:103-109).
@@ -810,7 +810,7 @@ __device__ __forceinline__ void l1_source_pass(const SsimCtx& C, float* gacc, co
       geometry_backward(C, s0, r, contract_uv(s0, gp, gs), gI, gacc, first, gpm);
     }
   }
-  if (GRAD) pose_sums_expand(C, gpm, gpm_out);
+  if (GRAD) pose_sums_raw(C, gpm, gpm_out);
 }
 
 }  // namespace sfm
