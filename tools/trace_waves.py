@@ -8,7 +8,12 @@ ops = importlib.import_module(PKG + ".ops"); synth = importlib.import_module(PKG
 mode = sys.argv[1] if len(sys.argv) > 1 else "fused"
 dev = torch.device("cuda:0")
 TB, TH, TW, TS = [int(v) for v in os.environ.get("SFM_TRACE_SHAPE", "32,128,416,2").split(",")]
-d = synth.make_inputs(B=TB, H=TH, W=TW, n_src=TS, n_scales=4, seed=1)
+d = synth.make_inputs(B=TB, H=TH, W=TW, n_src=TS, n_scales=4, seed=int(os.environ.get("SFM_TRACE_SEED", "1")))
+if os.environ.get("SFM_TRACE_ROLL"):   # the same samples, rotated by k: which XCD gets which sample changes, nothing else
+    _k = int(os.environ["SFM_TRACE_ROLL"])
+    for _key in ("tgt_pyr", "src_pyr", "disps", "poses"):
+        d[_key] = [np.roll(a, _k, axis=0) for a in d[_key]]
+    d["intrinsics"] = np.roll(d["intrinsics"], _k, axis=0)
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 if os.environ.get("SFM_TRACE_ZERO"):   # DVFS probe (MI355X_MICROARCH.md, DVFS give-back): the same launch on all-zero images
     for k in ("tgt_pyr", "src_pyr"):
