@@ -292,12 +292,14 @@ def quick(torch, np, ev, runner, min_time=0.12, k=25):
     while time.perf_counter() - t_all < min_time or len(blocks) < 3:
         t0 = time.perf_counter()
         for i in range(k):
-            runner.step(evs=pairs[i] if i % 5 == 0 else None)      # kernel events on every fifth step (see main)
+            # kernel events on ONE step per block, the one in its middle (see main: an event-carrying dispatch costs its step ~5 us,
+            # which on every fifth step of a 19 us cfg2 step was +1 us on the block's mean)
+            runner.step(evs=pairs[i] if i == k // 2 else None)
         torch.cuda.synchronize()
         blocks.append((time.perf_counter() - t0) / k)
-        kt += [ev.elapsed_ms(p[0], p[1]) for i, p in enumerate(pairs) if i % 5 == 0]
+        kt.append(ev.elapsed_ms(pairs[k // 2][0], pairs[k // 2][1]))
         if runner.mode != "fused":
-            kt2 += [ev.elapsed_ms(p[2], p[3]) for i, p in enumerate(pairs) if i % 5 == 0]
+            kt2.append(ev.elapsed_ms(pairs[k // 2][2], pairs[k // 2][3]))
     for p in pairs:
         for e in p:
             ev.destroy(e)

@@ -767,8 +767,10 @@ struct Tuning {
   bool has_prio = false;
   unsigned prio_tab = 0;                    // SFM_PRIO_TABLE: "0123,3210" = levels of ranks 0.. in phase 1, phase 2
   bool no_wide = false;                     // SFM_NO_WIDE: small L1 launches on the four-wave build too
+  bool no_fill = false;                     // SFM_NO_FILL: no slot-filling refinement of the chunk heights (plan_chunks)
   Tuning() {
     no_wide = getenv("SFM_NO_WIDE") != nullptr;
+    no_fill = getenv("SFM_NO_FILL") != nullptr;
     if (const char* e = getenv("SFM_CHUNK_ROWS")) chunk_rows = atoi(e);
     if (const char* rl = getenv("SFM_CHUNK_ROWS_LIST")) {
       for (int k = 0; *rl && k < SFM_MAX_SCALES; ++k) {
@@ -825,6 +827,33 @@ static void plan_chunks(const SfmLossDesc* d, int sw, int halo2, int slots, int*
   long long items, work;
   int maxcost;
   chunk_layout(d, sw, halo2, bestT, rows, &items, &work, &maxcost);
+  // Refinement for launches that fit ONE resident round: the equal-height search above leaves slots empty (cfg3: 2912 items on
+  // 3072 slots, i.e. 160 SIMDs with two waves instead of three, which finish at 31-48 us of a 55 us launch).  The empty slots are
+  // filled by splitting the chunks of the scale with the tallest chunks that still fits, one more chunk at a time: every extra
+  // chunk costs its halo rows again (+1 % of the row steps at cfg3).  Measured (profiles/r04_ab_chunk_fill.txt): the main kernel gets
+  // 1.5 - 2.2 % shorter where a wave is SHORT -- B = 16 / 24 / 32 at 128x416 with two sources, cfg5 with two sources -- and 3 - 5 %
+  // LONGER where it is long (cfg5 with four sources: 17 steps x 4; B = 48: 26 steps x 2), so the refinement is applied while a
+  // wave's row steps, tallest chunk x sources, stay within 40.
+  if (!tuning().no_fill && items <= slots && !(forced >= MIN_CHUNK_ROWS && forced <= MAX_CHUNK_ROWS) && (long long)maxcost * d->n_src <= 40) {
+    for (;;) {
+      int pick = -1, pick_rows = 0;
+      long long pick_add = 0;
+      for (int s = 0; s < d->n_scales; ++s) {
+        const int h = d->H[s], strips = (d->W[s] + sw - 1) / sw;
+        const int chunks = (h + rows[s] - 1) / rows[s];
+        if (rows[s] <= MIN_CHUNK_ROWS) continue;
+        const int nr = (h + chunks) / (chunks + 1);                 // ceil(h / (chunks + 1))
+        if (nr < MIN_CHUNK_ROWS || nr >= rows[s]) continue;
+        const long long add = (long long)d->B * strips * ((h + nr - 1) / nr - chunks);
+        if (add <= 0 || items + add > slots) continue;
+        if (rows[s] > pick_rows) { pick = s; pick_rows = rows[s]; pick_add = add; }
+      }
+      if (pick < 0) break;
+      const int h = d->H[pick], chunks = (h + rows[pick] - 1) / rows[pick];
+      rows[pick] = (h + chunks) / (chunks + 1);
+      items += pick_add;
+    }
+  }
   for (int k = 0; k < d->n_scales; ++k) {
     const int v = tuning().rows_list[k];
     if (v >= MIN_CHUNK_ROWS && v <= MAX_CHUNK_ROWS) rows[k] = v;
