@@ -52,5 +52,9 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
         os.makedirs(out, exist_ok=True)
         with open(os.path.join(out, "parity_stats.txt"), "w") as f:
             f.write("\n".join(notes) + "\n")
+        import json
+        with open(os.path.join(out, "parity_rows.jsonl"), "w") as f:
+            for row in util.PARITY_ROWS:
+                f.write(json.dumps(row) + "\n")
     except OSError:
         pass

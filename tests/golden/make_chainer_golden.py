@@ -19,6 +19,10 @@ What it records, with the reference call site each one stands for:
   chainer_warp_*.npz      projective_inverse_warp forward + backward (needs --reference)                   models/transform.py:156-193
   chainer_loss_*.npz      SFMLearner.__call__ itself, forward + backward, with DispNet / PoseNet replaced by callables that return
                           fixed disparities / poses (needs --reference)                                     models/base_model.py:48-124
+  chainer_cfg1_l1.npz     BASELINE.json configs[0] as a whole: the reference's __call__ on ONE 128x416 3-frame snippet, 1 scale,
+                          L1 only (experiments/sfm_learner_v1.yml) -> total_loss and the reported pixel_loss, the gradients, and the
+                          warped image of source 0 (curr_proj_img, :90-94).  This ONE file turns "parity" green for the fused loss:
+                          the oracle, sfm_loss_fwd_bwd and its warped-image output (SfmLossDesc.warped) are all compared with it.
 
 Inputs come from sfm-learner-chainer_amd/synth.py with fixed seeds, so the consuming tests can rebuild them bit for bit and only
 the OUTPUTS need to travel; they are stored anyway, to make the fixtures self-contained.
@@ -139,6 +143,24 @@ def main():
         total.backward()
         save("chainer_loss_" + cfg_name, total=np.float32(total.data),
              **{"d_disp%d" % s: disps[s].grad for s in range(4)}, **{"d_pose%d" % i: poses[i].grad for i in range(2)})
+
+    # ---- BASELINE.json configs[0]: the Chainer CPU reference's own case, as a whole (1 x (128x416) 3-frame snippet, 1 scale, L1 only)
+    d = synth.make_inputs(B=1, H=128, W=416, n_src=2, n_scales=1, seed=1)
+    disps = [chainer.Variable(d["disps"][0].copy())]
+    poses = [chainer.Variable(a.copy()) for a in d["poses"]]
+    net.smooth_reg, net.exp_reg, net.ssim_rate, net.n_sources = 0.0, 0.0, 0.0, 2
+    net.disp_net = lambda tgt, disps=disps: disps
+    net.pose_net = lambda tgt, src, do_exp=False, poses=poses: (poses, None)
+    reporter, seen = chainer.Reporter(), {}
+    reporter.add_observer("sfm", net)                                # the five chainer.report keys of :119-123 land in `seen`
+    with reporter.scope(seen):
+        total = net(d["tgt"], d["src"], d["intrinsics"], None)
+    total.backward()
+    depth = (1.0 / d["disps"][0]).reshape(1, 1, 128 * 416).astype(np.float32)
+    warped0 = transform.projective_inverse_warp(d["src"][:, 0].copy(), chainer.Variable(np.broadcast_to(depth, (1, 3, 128 * 416)).copy()),
+                                                chainer.Variable(d["poses"][0].copy()), d["intrinsics"][:, 0].copy())     # :90-94 for source 0
+    save("chainer_cfg1_l1", total=np.float32(total.data), pixel=np.float32(chainer.cuda.to_cpu(getattr(seen.get("sfm/pixel_loss"), "data", seen.get("sfm/pixel_loss")))),
+         warped0=warped0.data, d_disp0=disps[0].grad, d_pose0=poses[0].grad, d_pose1=poses[1].grad)
 
 
 if __name__ == "__main__":

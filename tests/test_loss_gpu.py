@@ -14,7 +14,7 @@ import pytest
 
 from oracle import sfm_oracle as O
 from oracle.parity import knife_mask, position_uncertainty, rel_l2, tap_contrast
-from util import assert_close_masked, dilate, parity_note, to_dev, to_np
+from util import assert_close_masked, dilate, parity_note, parity_row, to_dev, to_np
 
 pytestmark = pytest.mark.gpu
 
@@ -322,21 +322,32 @@ def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=T
             r64.append(ref64())
         return r64[0][key][idx]
 
+    def measured(got, w, knife):
+        """(largest element-wise error outside the knife mask, of the array's largest magnitude; relative L2 outside the mask)"""
+        g64, w64_ = np.asarray(got, np.float64), np.asarray(w, np.float64)
+        keep = np.ones(g64.shape, bool) if knife is None else ~np.broadcast_to(knife, g64.shape)
+        return float((np.abs(g64 - w64_) * keep).max() / max(np.abs(w64_).max(), 1e-30)), rel_l2(got, w, knife)
+
     def close(got, w, knife, name, key, idx, extra=0.0):
+        """-> the rung that decided the element-wise comparison"""
         try:
             try:
                 assert_close_masked(got, w, GRAD_TOL, knife, what=name)
+                return "flat"
             except AssertionError:
                 if not extra:
                     raise
                 assert_close_masked(got, w, GRAD_TOL + extra, knife, what=name)
                 parity_note("in-view allowance USED for %s %s: misses the flat %.0e, passes at %.2e" % (what, name, GRAD_TOL, GRAD_TOL + extra))
+                return "in-view allowance"
         except AssertionError:
             if ref64 is None:
                 raise
             _judged64(got, w, second(key, idx), knife, "%s %s" % (what, name), extra=extra, arraywise=(key == "d_poses"))
+            return "fp64 second opinion"
 
     def l2_ok(got, w, knife, name, key, idx, tol=L2_TOL):
+        """-> (relative L2 that was judged, the rung that decided)"""
         l2 = rel_l2(got, w, knife)
         if l2 > tol:
             # one ill-conditioned element can carry the whole norm: the fp64 oracle decides, with the fp32 oracle's own error as the yardstick
@@ -345,8 +356,13 @@ def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=T
             mine, theirs = rel_l2(got, w64, knife), rel_l2(w, w64, knife)
             assert mine <= max(tol, 3.0 * theirs), "%s: relative L2 error %.2e vs the fp64 oracle (the fp32 oracle's own: %.2e)" % (name, mine, theirs)
             parity_note("second opinion (fp64 oracle) used for the L2 norm of %s %s: %.2e vs the fp32 oracle's own %.2e" % (what, name, mine, theirs))
-            return min(l2, mine)
-        return l2
+            return min(l2, mine), "fp64 second opinion"
+        return l2, "flat"
+
+    def record(name, got, w, knife, rung_e, rung_l2, tol_e, tol_l2, knife_share=None):
+        e, l2 = measured(got, w, knife)
+        parity_row(case=what, array=name, elementwise_rung=rung_e, elementwise_err=e, elementwise_tol=tol_e, l2_rung=rung_l2, l2_err=l2, l2_tol=tol_l2,
+                   knife_share=knife_share)
 
     cell_of = cell_thr if callable(cell_thr) else (lambda s_: cell_thr)     # per scale: a width in px, or an array (B,n,h,w) of widths
     abs_of = abs_thr if callable(abs_thr) else (lambda s_: abs_thr)
@@ -364,11 +380,14 @@ def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=T
         flip = knife_mask(ref, s, cell_thr=cell_of(s), abs_thr=abs_of(s))[1]   # (B,h,w): from the oracle's own margins only
         fc = flip.reshape(flip.shape[0], -1).sum(axis=1)
         on_test = fc if on_test is None else on_test + fc
-        close(gnp, w, knife, "d_disp[%d]" % s, "d_disps", s)
-        worst = max(worst, l2_ok(gnp, w, knife, "d_disp[%d]" % s, "d_disps", s))
+        rung_e = close(gnp, w, knife, "d_disp[%d]" % s, "d_disps", s)
+        l2, rung_l2 = l2_ok(gnp, w, knife, "d_disp[%d]" % s, "d_disps", s)
+        worst = max(worst, l2)
+        record("d_disp[%d]" % s, gnp, w, knife, rung_e, rung_l2, GRAD_TOL, L2_TOL, float(knife.mean()))
         if check_mask:
-            close(to_np(fl.d_masks[s]), ref["d_masks"][s], None, "d_mask[%d]" % s, "d_masks", s)
-            l2_ok(to_np(fl.d_masks[s]), ref["d_masks"][s], None, "d_mask[%d]" % s, "d_masks", s)
+            rung_e = close(to_np(fl.d_masks[s]), ref["d_masks"][s], None, "d_mask[%d]" % s, "d_masks", s)
+            _, rung_l2 = l2_ok(to_np(fl.d_masks[s]), ref["d_masks"][s], None, "d_mask[%d]" % s, "d_masks", s)
+            record("d_mask[%d]" % s, to_np(fl.d_masks[s]), ref["d_masks"][s], None, rung_e, rung_l2, GRAD_TOL, L2_TOL)
     # d_pose of a sample sums SIGNED terms of all its pixels and scales: a pixel on the strict in-view test that the two fp32
     # evaluations place on different sides changes one term by its full size, which can be many times the net sum's share of a
     # pixel (measured: one such pixel of a 92x108 image moved d_pose by 0.26 % of its maximum).  The allowance goes by how many
@@ -385,8 +404,10 @@ def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=T
     pose_l2_tol = POSE_L2_TOL if px0 <= 1.0e5 else 2.0 * POSE_L2_TOL
     for i, (g, w) in enumerate(zip(fl.d_poses, ref["d_poses"]) if check_pose else ()):
         try:
-            close(to_np(g), w, None, "d_pose[%d]" % i, "d_poses", i, extra=extra)
-            worst_pose = max(worst_pose, l2_ok(to_np(g), w, None, "d_pose[%d]" % i, "d_poses", i, tol=pose_l2_tol))
+            rung_e = close(to_np(g), w, None, "d_pose[%d]" % i, "d_poses", i, extra=extra)
+            l2, rung_l2 = l2_ok(to_np(g), w, None, "d_pose[%d]" % i, "d_poses", i, tol=pose_l2_tol)
+            worst_pose = max(worst_pose, l2)
+            record("d_pose[%d]" % i, to_np(g), w, None, rung_e, rung_l2, GRAD_TOL + (extra if rung_e != "flat" else 0.0), pose_l2_tol)
         except AssertionError as first:
             if explain is None:
                 raise
@@ -398,6 +419,7 @@ def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=T
             l2 = rel_l2(to_np(g), w2)
             assert l2 <= pose_l2_tol, "d_pose[%d]: relative L2 %.2e vs the oracle with %s on the other branch" % (i, l2, named)
             worst_pose = max(worst_pose, l2)
+            record("d_pose[%d]" % i, to_np(g), w, None, "explained by named pixels", "explained by named pixels", GRAD_TOL, pose_l2_tol)
             parity_note("d_pose EXPLAINED for %s d_pose[%d]: misses the criteria against the oracle as is (%s); equals the oracle with %s "
                         "pushed across the discontinuity it sits on (relative L2 %.2e, flat %.0e met)" % (
                             what, i, str(first).split("\n")[0][:120], ", ".join(named), l2, GRAD_TOL))

@@ -248,6 +248,15 @@ def test_oracle_matches_chainer_fixtures():
             gd, gp, _ = O.projective_inverse_warp_backward(z["imgs"], z["depthes"], z["poses"], z["K"], z["g"])
             np.testing.assert_allclose(gd, z["d_depthes"], rtol=0, atol=1e-3 * np.abs(z["d_depthes"]).max(), err_msg=name)
             np.testing.assert_allclose(gp, z["d_poses"], rtol=0, atol=2e-2 * np.abs(z["d_poses"]).max(), err_msg=name)
+        elif name.startswith("chainer_cfg1_"):       # BASELINE.json configs[0] as a whole, from the reference's own __call__
+            d = synth.make_inputs(B=1, H=128, W=416, n_src=2, n_scales=1, seed=1)
+            ref = O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], backward=True, keep_warped=True)
+            assert abs(ref["total_loss"] - float(z["total"])) <= 1e-4 * abs(float(z["total"])), name
+            assert abs(ref["pixel_loss"] - float(z["pixel"])) <= 1e-4 * abs(float(z["pixel"])), name
+            np.testing.assert_allclose(ref["warped"][0][:, 0], z["warped0"], rtol=0, atol=1e-4, err_msg=name)
+            np.testing.assert_allclose(ref["d_disps"][0], z["d_disp0"], rtol=0, atol=2e-3 * np.abs(z["d_disp0"]).max(), err_msg=name)
+            for i in range(2):
+                np.testing.assert_allclose(ref["d_poses"][i], z["d_pose%d" % i], rtol=0, atol=2e-3 * np.abs(z["d_pose%d" % i]).max(), err_msg=name)
         elif name.startswith("chainer_loss_"):
             cfg = dict(smooth_reg=0.1, ssim_rate=0.15 if "ssim" in name else 0.0)
             d = synth.make_inputs(B=2, H=32, W=104, n_src=2, n_scales=4, seed=8)

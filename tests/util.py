@@ -9,6 +9,15 @@ def parity_note(line):
     PARITY_NOTES.append(str(line))
 
 
+# one record per compared gradient array: which criterion decided it, measured error next to the tolerance
+# (conftest writes them to gpurun_out/parity_rows.jsonl; tools/parity_table.py turns them into the table of DESIGN.md 3)
+PARITY_ROWS = []
+
+
+def parity_row(**row):
+    PARITY_ROWS.append(row)
+
+
 def to_dev(a, dev):
     import torch
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)

@@ -4,9 +4,9 @@
 # fit one pass on gfx950; counters are never combined with tracing).  Raw CSVs land in gpurun_out/profiles_raw/<tag>/<variant>/ ;
 # tools/summarize_profiles.py <tag> condenses every variant found there into profiles/<tag>_*.
 #   usage: tools/collect_profiles.sh <tag> [workload=cfg3_edge] [layout=hwc] [mode=fused]
-#   e.g.   for w in cfg3_edge cfg3 cfg2 cfg5 cfg5_2src; do tools/collect_profiles.sh r03 $w; done; tools/collect_profiles.sh r03 cfg3_edge planar
+#   e.g.   for w in cfg3_edge cfg3 cfg2 cfg5 cfg5_2src; do tools/collect_profiles.sh r04 $w; done; tools/collect_profiles.sh r04 cfg3_edge planar
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 WL=${2:-cfg3_edge}
 LAYOUT=${3:-hwc}
 MODE=${4:-fused}

@@ -11,7 +11,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 raw_root = os.path.join(ROOT, "gpurun_out", "profiles_raw", tag)
 out = os.path.join(ROOT, "profiles")
 os.makedirs(out, exist_ok=True)
@@ -89,6 +89,9 @@ with open(os.path.join(out, "%s_summary.md" % tag), "w") as f:
         for name, k in s["kernels"].items():
             if "counters_per_launch" in k:
                 f.write("\nPMC per launch of `%s`: " % name[:80] + ", ".join("%s %.4g" % (c, val) for c, val in sorted(k["counters_per_launch"].items())) + "\n")
+                c = k["counters_per_launch"]
+                if c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum") is not None and c["TCC_HIT_sum"] + c["TCC_MISS_sum"] > 0:
+                    f.write("L2 (TCC) hit rate: %.1f %% of %.3g requests\n" % (100 * c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), c["TCC_HIT_sum"] + c["TCC_MISS_sum"]))
                 if "hbm_bytes_raw" in k:
                     f.write("HBM-side traffic: raw (FETCH_SIZE + WRITE_SIZE) x 1024 = %.1f MB; with the guide's x2 FETCH correction %.1f MB; algorithmic %.1f MB\n" % (
                         k["hbm_bytes_raw"] / 1e6, k["hbm_bytes_fetch_x2"] / 1e6, k["algorithmic_bytes"] / 1e6))
