@@ -13,6 +13,12 @@
  *     deliberately not reproduced).  Per THREAD the library remembers the launch plans of the last
  *     four distinct (descriptor bytes, device, entry point) combinations of sfm_loss_*: host-side
  *     integers only, no device memory, never a pointer that is used without being passed in again;
+ *   - image values: the reference's input contract is uint8 / 127.5 - 1, i.e. [-1, 1]
+ *     (datasets/kitti/kitti_raw_dataset.py:12-14).  Warp, zero mask (models/base_model.py:96), L1 and smoothness hold for finite
+ *     images of any range.  The SSIM terms (models/base_model.py:126-142) form variances as E[x^2] - mu^2 in fp32, as the
+ *     reference does: beyond a range of about +-16 those cancel, SSIM's denominator can reach 0, and where the reference's
+ *     F.clip backward then yields a zero gradient this library may yield a non-finite one (the loss scalars stay right).
+ *     A NaN anywhere in an image makes the loss NaN, as in the reference;
  *   - return value: 0 on success; SFM_ERR_* (<0) for a rejected argument; a positive value is
  *     a hipError_t from the launch.  sfm_last_error() returns a thread-local message.
  *     No exception or abort crosses the ABI.

@@ -421,7 +421,6 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
 //  ps.rz is already masked: the pixel-interleaved path's range-checked loads, see issue_row)
 template <bool PREMASKED>
 __device__ __forceinline__ void finish_row(const SsimCtx& C, const Pipe& ps, RowS& s) {
-  unsigned nz = 0;
   float ih[3], it[3], du[3], dv[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -434,7 +433,6 @@ __device__ __forceinline__ void finish_row(const SsimCtx& C, const Pipe& ps, Row
     dv[c] = dvv;
     du[c] = fmaf(ps.f.y, dxb - dxt, dxt);
     it[c] = PREMASKED ? ps.it[c] : ps.it[c] * C.xinf;       // 0 outside the image (planar: the load came from the clamped column)
-    nz |= __float_as_uint(val);
   }
   s.ih = ch3(ih[0], ih[1], ih[2]);
   s.it = ch3(it[0], it[1], it[2]);
@@ -442,12 +440,13 @@ __device__ __forceinline__ void finish_row(const SsimCtx& C, const Pipe& ps, Row
   s.duv_s.x = du[2]; s.duv_s.y = dv[2];
   s.UV = ps.UV; s.D = ps.D;
   s.rzi = (PREMASKED || ps.inview_o) ? ps.rz : 0.f;   // halo lanes get no gradient of their own
-  // base_model.py:96: mask = all three channels exactly 0 (+-0 both count).  nz without its sign bit, read as a float, is 0 or
-  // at least the smallest magnitude among the channels: the clamped product with 2^127 is the 0 / 1 indicator (one full-rate
-  // instruction; shift + compare + select are three of the slow class)
+  // base_model.py:96: mask = all three channels exactly 0 (+-0 both count).  The largest magnitude among the channels (ONE
+  // v_max3_f32 with |.| operand modifiers) is 0 or a normal number, for images of ANY range: the clamped product with 2^127 is the
+  // 0 / 1 indicator.  (Rounds 1-3 OR-ed the channels' bit patterns instead: exact for the reference's [-1, 1] images, where no
+  // exponent field can fill up, but a 200.0 next to a 1.5 made the pattern of a NaN and the pixel counted as masked.)
   {
     const float big = 0x1p127f;
-    const float mag = __uint_as_float(nz & 0x7fffffffu);
+    const float mag = __builtin_fmaxf(__builtin_fabsf(ih[0]), __builtin_fmaxf(__builtin_fabsf(ih[1]), __builtin_fabsf(ih[2])));
     asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(s.nm) : "v"(mag), "s"(big));
   }
 }

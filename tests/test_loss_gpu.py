@@ -775,6 +775,41 @@ def test_identity_pose_identical_images_give_zero_photometric_loss(ops, synth, d
     assert abs(loss[4] - ref["ssim_loss"]) <= 1e-4 * max(ref["ssim_loss"], 1e-6)
 
 
+@pytest.mark.parametrize("layout", ["planar", "hwc"])
+def test_images_outside_the_unit_range(ops, synth, dev, layout):
+    """The input contract is the reference's: images uint8 / 127.5 - 1 in [-1, 1] (datasets/kitti/kitti_raw_dataset.py:12-14).
+    What happens outside it, pinned (round-3 advisor finding):
+      * the zero mask of models/base_model.py:96 and the L1 path hold for images of ANY finite range -- checked here on 0..255
+        images: loss and every gradient against the oracle (rounds 1-3 OR-ed the channels' bit patterns for the mask, which
+        silently mis-masked pixels once values of 128+ met values in [1, 2): pixel_loss was 3.6 % low);
+      * with SSIM the five scalars still match the oracle at 0..255; the gradients do not have to be finite there: the variance
+        terms E[x^2] - mu^2 cancel in fp32 at that range (in the reference too), the denominator of SSIM can reach 0, and the
+        packed clip mask then multiplies an infinite reciprocal by 0 where the reference's F.clip backward gives 0
+        (include/sfmwarp.h states the range the SSIM gradient is defined for);
+      * a NaN pixel makes the loss NaN, as in the reference."""
+    d = synth.make_inputs(B=2, H=32, W=104, n_src=2, n_scales=2, seed=3)
+    big = dict(d, tgt_pyr=[(a * 127.5 + 127.5).astype(np.float32) for a in d["tgt_pyr"]],
+               src_pyr=[(a * 127.5 + 127.5).astype(np.float32) for a in d["src_pyr"]])
+    cfg = CONFIGS["l1_smooth"]
+    ref = _oracle(big, cfg)
+    fl = _bind(ops, dev, big, cfg, layout=layout, want_warped=True)
+    _check_losses(fl.forward_backward(), ref)
+    _check_warped(fl, ref, "0..255 images l1_smooth %s" % layout, big)
+    kw = knife_widths(big, ref, abs_floor=3e-5 * 127.5)           # the kink of |I^ - I| in units of the image range
+    _check_grads(fl, ref, 2, what="0..255 images l1_smooth %s" % layout, **kw)
+    cfg = CONFIGS["ssim_smooth"]
+    _check_losses(_bind(ops, dev, big, cfg, layout=layout).forward(), _oracle(big, cfg))
+    # in contract every output is finite, SSIM included
+    fl = _bind(ops, dev, d, cfg, layout=layout)
+    assert np.isfinite(to_np(fl.forward_backward())).all()
+    assert all(np.isfinite(to_np(t)).all() for t in fl.d_disps + fl.d_poses)
+    # a NaN pixel: the reference's loss is NaN (F.absolute / F.mean propagate it) and so is this one
+    bad = dict(d, src_pyr=[a.copy() for a in d["src_pyr"]])
+    bad["src_pyr"][0][0, 1, 10, 40] = np.nan
+    loss5 = to_np(_bind(ops, dev, bad, cfg, layout=layout).forward())
+    assert np.isnan(loss5[0]) and np.isnan(loss5[1]) and np.isfinite(loss5[2])      # total, pixel; the smoothness term does not see the images
+
+
 def test_argument_errors(ops, synth, dev):
     d = synth.make_inputs(B=1, H=16, W=24, n_src=2, n_scales=1, seed=3)
     with pytest.raises(ValueError):
