@@ -44,6 +44,12 @@ def _worker(rank, world, port, out_dir):
     log = torch.stack([loss5 * (k + 1) for k in range(3)])      # three "steps" of an interval
     dmod.allreduce_losses(loss5)
     dmod.allreduce_losses(log)
+    # the hand-over of RCCL's unique id (rccl.Communicator: made on rank 0, broadcast over the process group that is already up):
+    # 128 bytes that include zeros and values above 127 must arrive unchanged on every rank
+    rccl = importlib.import_module("sfm-learner-chainer_amd.rccl")
+    uid = bytes((37 * k + 11) % 256 for k in range(rccl.NCCL_UNIQUE_ID_BYTES))
+    got = rccl._broadcast_bytes(uid if rank == 0 else bytes(rccl.NCCL_UNIQUE_ID_BYTES), device)
+    assert got == uid and len(got) == rccl.NCCL_UNIQUE_ID_BYTES
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), loss5=loss5.numpy(), log=log.numpy(), d_disp0=res.d_disps[0],
              d_pose0=res.d_poses[0])
     dist.barrier()

@@ -185,3 +185,19 @@ def test_augmentation_parameters_follow_the_reference_rng_order():
     assert K2.shape == (3, 3, 3) and (K2[:, 2, 2] == 1).all() and (K2[:, 0, 0] >= K[:, 0, 0]).all()
     Kms = aug.get_multi_scale_intrinsics(K2, 4)
     np.testing.assert_allclose(Kms[:, 2, 0, 0], K2[:, 0, 0] / 4)
+
+
+def test_rccl_binding_finds_the_library_torch_loaded():
+    """rccl.py binds the librccl.so instance that torch has mapped (the one sharing torch's HIP runtime), declares the four entry
+    points bench.py uses and can ask it for a unique id without a GPU; communicators and collectives need devices (GPU test:
+    tests/test_bench_rehearsal_gpu.py::test_drivers_launcher_form_runs_on_real_rccl_at_one_rank)."""
+    import ctypes as C
+    import importlib
+    rccl = importlib.import_module("sfm-learner-chainer_amd.rccl")
+    path = rccl._loaded_librccl()
+    assert path and "torch" in path, path
+    L = rccl.lib()
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclAllReduce", "ncclCommDestroy", "ncclGetErrorString"):
+        assert hasattr(L, name), name
+    uid = rccl._UniqueId()
+    assert L.ncclGetUniqueId(C.byref(uid)) == 0 and any(bytes(uid.internal)) and C.sizeof(uid) == 128

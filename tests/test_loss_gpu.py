@@ -359,10 +359,16 @@ def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=T
             return min(l2, mine), "fp64 second opinion"
         return l2, "flat"
 
-    def record(name, got, w, knife, rung_e, rung_l2, tol_e, tol_l2, knife_share=None):
+    def record(name, got, w, knife, rung_e, rung_l2, tol_e, tol_l2, knife_share=None, key=None, idx=None):
         e, l2 = measured(got, w, knife)
-        parity_row(case=what, array=name, elementwise_rung=rung_e, elementwise_err=e, elementwise_tol=tol_e, l2_rung=rung_l2, l2_err=l2, l2_tol=tol_l2,
+        row = dict(case=what, array=name, elementwise_rung=rung_e, elementwise_err=e, elementwise_tol=tol_e, l2_rung=rung_l2, l2_err=l2, l2_tol=tol_l2,
                    knife_share=knife_share)
+        if "fp64" in rung_e or "fp64" in rung_l2:      # what the fp64 oracle says: the kernel's distance to it and the fp32 oracle's own
+            w64 = second(key, idx)
+            e64, l64 = measured(got, w64, knife)
+            own_e, own_l = measured(w, w64, knife)
+            row.update(err_vs_fp64=e64, l2_vs_fp64=l64, oracle32_own_err=own_e, oracle32_own_l2=own_l)
+        parity_row(**row)
 
     cell_of = cell_thr if callable(cell_thr) else (lambda s_: cell_thr)     # per scale: a width in px, or an array (B,n,h,w) of widths
     abs_of = abs_thr if callable(abs_thr) else (lambda s_: abs_thr)
@@ -383,11 +389,11 @@ def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=T
         rung_e = close(gnp, w, knife, "d_disp[%d]" % s, "d_disps", s)
         l2, rung_l2 = l2_ok(gnp, w, knife, "d_disp[%d]" % s, "d_disps", s)
         worst = max(worst, l2)
-        record("d_disp[%d]" % s, gnp, w, knife, rung_e, rung_l2, GRAD_TOL, L2_TOL, float(knife.mean()))
+        record("d_disp[%d]" % s, gnp, w, knife, rung_e, rung_l2, GRAD_TOL, L2_TOL, float(knife.mean()), key="d_disps", idx=s)
         if check_mask:
             rung_e = close(to_np(fl.d_masks[s]), ref["d_masks"][s], None, "d_mask[%d]" % s, "d_masks", s)
             _, rung_l2 = l2_ok(to_np(fl.d_masks[s]), ref["d_masks"][s], None, "d_mask[%d]" % s, "d_masks", s)
-            record("d_mask[%d]" % s, to_np(fl.d_masks[s]), ref["d_masks"][s], None, rung_e, rung_l2, GRAD_TOL, L2_TOL)
+            record("d_mask[%d]" % s, to_np(fl.d_masks[s]), ref["d_masks"][s], None, rung_e, rung_l2, GRAD_TOL, L2_TOL, key="d_masks", idx=s)
     # d_pose of a sample sums SIGNED terms of all its pixels and scales: a pixel on the strict in-view test that the two fp32
     # evaluations place on different sides changes one term by its full size, which can be many times the net sum's share of a
     # pixel (measured: one such pixel of a 92x108 image moved d_pose by 0.26 % of its maximum).  The allowance goes by how many
@@ -407,7 +413,7 @@ def _check_grads(fl, ref, n_src, check_src=False, check_mask=False, check_pose=T
             rung_e = close(to_np(g), w, None, "d_pose[%d]" % i, "d_poses", i, extra=extra)
             l2, rung_l2 = l2_ok(to_np(g), w, None, "d_pose[%d]" % i, "d_poses", i, tol=pose_l2_tol)
             worst_pose = max(worst_pose, l2)
-            record("d_pose[%d]" % i, to_np(g), w, None, rung_e, rung_l2, GRAD_TOL + (extra if rung_e != "flat" else 0.0), pose_l2_tol)
+            record("d_pose[%d]" % i, to_np(g), w, None, rung_e, rung_l2, GRAD_TOL + (extra if rung_e != "flat" else 0.0), pose_l2_tol, key="d_poses", idx=i)
         except AssertionError as first:
             if explain is None:
                 raise
