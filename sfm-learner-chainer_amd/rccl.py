@@ -22,7 +22,12 @@ NCCL_FLOAT32, NCCL_SUM = 7, 0       # ncclDataType_t, ncclRedOp_t (rccl.h)
 
 
 class _UniqueId(C.Structure):
-    _fields_ = [("internal", C.c_char * NCCL_UNIQUE_ID_BYTES)]
+    # (bytes, not c_char: ctypes hands a c_char array back truncated at its first NUL, and an id is full of them)
+    _fields_ = [("internal", C.c_ubyte * NCCL_UNIQUE_ID_BYTES)]
+
+
+def _id_bytes(uid):
+    return C.string_at(C.byref(uid), NCCL_UNIQUE_ID_BYTES)
 
 
 class RcclError(RuntimeError):
@@ -85,7 +90,9 @@ class Communicator:
         if rank == 0:
             _check(L.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
         if world > 1:
-            raw = (broadcast or (lambda b: _broadcast_bytes(b, device)))(bytes(uid.internal) if rank == 0 else bytes(NCCL_UNIQUE_ID_BYTES))
+            raw = (broadcast or (lambda b: _broadcast_bytes(b, device)))(_id_bytes(uid) if rank == 0 else bytes(NCCL_UNIQUE_ID_BYTES))
+            if len(raw) != NCCL_UNIQUE_ID_BYTES:
+                raise RcclError("the unique id arrived with %d bytes instead of %d" % (len(raw), NCCL_UNIQUE_ID_BYTES))
             C.memmove(C.byref(uid), raw, NCCL_UNIQUE_ID_BYTES)
         self._comm = C.c_void_p()
         with torch.cuda.device(device):

@@ -200,4 +200,9 @@ def test_rccl_binding_finds_the_library_torch_loaded():
     for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclAllReduce", "ncclCommDestroy", "ncclGetErrorString"):
         assert hasattr(L, name), name
     uid = rccl._UniqueId()
-    assert L.ncclGetUniqueId(C.byref(uid)) == 0 and any(bytes(uid.internal)) and C.sizeof(uid) == 128
+    assert L.ncclGetUniqueId(C.byref(uid)) == 0 and C.sizeof(uid) == 128
+    raw = rccl._id_bytes(uid)
+    assert len(raw) == 128 and any(raw) and 0 in raw          # (an id holds NUL bytes: it must travel as 128 raw bytes, not as a C string)
+    back = rccl._UniqueId()
+    C.memmove(C.byref(back), raw, 128)
+    assert rccl._id_bytes(back) == raw
