@@ -488,10 +488,23 @@ def main():
     # (rccl.py) -- one library call, no host wait, no cross-stream event; `interval`: ONE all-reduce of the K rows at the end of the
     # block (what a trainer that reports per LogReport interval needs); `step_torch`: the per-step all-reduce through
     # torch.distributed (tools/allreduce_overhead.py, one rank: 42 us of host time per call, +8.6 us per 60 us step).
-    comm = None
+    comm, comm_note = None, None
     if use_dist and not rehearse:
-        rccl = importlib.import_module(PKG + ".rccl")
-        comm = rccl.Communicator(rank, world, dev)
+        # (No multi-GPU node was available to the builder: if the direct communicator cannot be made on the node this runs on, EVERY
+        #  rank falls back to torch.distributed for the collective -- agreed through the process group that is already up -- and the
+        #  line says so, rather than losing the scaling run.)
+        try:
+            rccl = importlib.import_module(PKG + ".rccl")
+            comm = rccl.Communicator(rank, world, dev)
+        except Exception as e:       # noqa: BLE001
+            comm_note = "%s: %s" % (type(e).__name__, e)
+            sys.stderr.write("rank %d: direct RCCL communicator failed (%s)\n" % (rank, comm_note))
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if comm is not None:
+                comm.destroy()
+            comm, comm_note = None, comm_note or "another rank could not make the communicator"
     raw_stream = torch.cuda.current_stream(dev).cuda_stream
 
     def reduce_rows(t):
@@ -661,7 +674,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": R.desc, "per_gpu_batch": R.B, "global_batch": R.B * world, "H": R.H, "W": R.W, "n_src": R.n_src,
                        "n_scales": R.n_scales, "mode": args.mode, "image_layout": args.layout, "warped_px_per_gpu_step": R.warped_px,
-                       "collective": COLLECTIVE_NOTES[coll] if use_dist else None,
+                       "collective": (COLLECTIVE_NOTES[coll] + ("" if (comm is not None or rehearse or coll == "step_torch") else
+                                      " -- FALLBACK: issued through torch.distributed.all_reduce, the direct communicator failed: %s" % comm_note))
+                       if use_dist else None,
                        "parallelism": ("batch-sharded x%d, no exchange on the data path; RCCL all-reduce of the 5 reported scalars: %s" % (
                            world, COLLECTIVE_NOTES[coll])) if use_dist else "single GPU, no collective"},
             "timing": {"blocks": len(blocks), "steps_per_block": K, "timed_s": round(float(np.sum(blocks)), 4),
