@@ -645,9 +645,10 @@ def main():
                                             facts["tag"], args.workload, args.layout, args.mode)}
         valu = float(facts["counters"]["SQ_INSTS_VALU"]) if facts["counters"] and "SQ_INSTS_VALU" in facts["counters"] else None
         roofline = {
-            # what binds: vector-instruction issue at the kernel's occupancy, not HBM.  `achieved` / `frac` keep
-            # SURVEY 8(d)'s convention (ALGORITHMIC bytes / kernel time vs the 8 TB/s line) so that rounds stay comparable.
-            "bound": "valu_issue", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # the roofline the fraction is taken against: HBM (ALGORITHMIC bytes / kernel time vs the 8 TB/s line; a gather /
+            # reduce path, no MFMA).  What actually limits the kernel is vector-instruction issue at its occupancy:
+            # `binding_resource`, priced in `roofline_valu`.
+            "bound": "hbm", "binding_resource": "valu_issue", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_detail": traffic_detail,
             "measured_hbm_frac": round(traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
             "kernel": kname, "kernel_ms": round(kms, 5), "kernel_ms_median": round(float(np.median(kt)), 5),
