@@ -197,6 +197,23 @@ def test_forced_chunk_heights(rows):
     assert r.returncode == 0 and ("OK rows=%d" % rows) in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
+@pytest.mark.parametrize("n_src,cfg_name,layout", [(5, "ssim_smooth", "hwc"), (7, "l1_smooth", "planar"), (8, "edge_aware", "hwc"), (8, "explain", "planar")])
+def test_up_to_eight_sources(ops, synth, dev, n_src, cfg_name, layout):
+    """SFM_MAX_SRC = 8 sources: since round 4 every wave builds the geometry of ALL its sources at once, eight lanes per source
+    (build_wave_geom: lanes 8g .. 8g+7 belong to source g) -- at eight sources the sixty-four lanes are exactly used up, and no
+    BASELINE config or sweep case goes beyond four.  Loss, warped pixels of every source and every gradient against the oracle."""
+    from test_loss_gpu import _check_warped, knife_widths
+    cfg = CONFIGS[cfg_name]
+    d = synth.make_inputs(B=3, H=24, W=70, n_src=n_src, n_scales=2, seed=40 + n_src, with_masks=True)
+    ref = _oracle(d, cfg)
+    fl = _bind(ops, dev, d, cfg, layout=layout, want_warped=True)
+    _check_losses(fl.forward_backward(), ref)
+    what = "%d sources %s %s" % (n_src, cfg_name, layout)
+    _check_warped(fl, ref, what, d)
+    _check_grads(fl, ref, n_src, check_mask=bool(cfg.get("exp_reg")), what=what, **knife_widths(d, ref))
+    assert len(fl.d_poses) == n_src and all(np.abs(to_np(g)).max() > 0 for g in fl.d_poses)      # every source got its own pose gradient
+
+
 def test_sweep_rarely_needs_the_last_rungs():
     """Runs after the sweep (definition order): the explanation by named knife-edge pixels is a last resort, not a way of life --
     if more than 2 % of the sweep's cases (at least one) needed it for a d_pose array, or more than 10 % the fp64 second opinion,
