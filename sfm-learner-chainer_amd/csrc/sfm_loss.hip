@@ -378,7 +378,7 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
   }
   // the geometry of every source pass of this wave (sfm_ssim_pass.h, build_wave_geom), its loads in the same batch as the disparities
   static_assert(SFM_MAX_SRC * 8 <= 64, "one group of eight lanes per source");
-  const WaveGeom WG = build_wave_geom([&](const int g) { return A.pose[g]; }, A.n_src, b, A.intrinsics + (size_t)(b * A.n_scales + s) * 9, lane);
+  const WaveGeom WG = build_wave_geom(A.pose, A.n_src, b, A.intrinsics + (size_t)(b * A.n_scales + s) * 9, lane);
 #ifdef SFM_STAMPS
   Stamps st = {0, 0, 0, 0, 0};
   unsigned long long ts0 = 0, cyc_smooth = 0, cyc_src = 0;

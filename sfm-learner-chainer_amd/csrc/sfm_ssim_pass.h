@@ -226,20 +226,31 @@ struct WaveGeom {       // lane 8g+k: row k of source g (per-lane registers, ali
   float P3;             // K . t
 };
 
-// pose_of(g): pointer to the (B,6) pose array of source g (wave-uniform)
-template <typename PoseOf>
-__device__ __forceinline__ WaveGeom build_wave_geom(const PoseOf pose_of, const int n_src, const int b, const float* Kp /* K of this (sample, scale) */,
-                                                    const int lane) {
+// pose[g]: pointer to the (B,6) pose array of source g (kernel arguments: wave-uniform, NULL beyond n_src)
+__device__ __forceinline__ WaveGeom build_wave_geom(const float* const (&pose)[SFM_MAX_SRC], const int n_src, const int b,
+                                                    const float* Kp /* K of this (sample, scale) */, const int lane) {
   const float pi = 3.14159265358979323846f;
   const int grp = lane >> 3, sub = lane & 7, base = lane & ~7;
-  // one batch of loads: the lane's pose component (sub 0..2 the angles, 3..5 the translation) of ITS source, its row of K, all of K
-  float pv = 0.f;
-  for (int g = 0; g < n_src; ++g) {               // (wave-uniform trip count; one load per source, under the lanes of its group)
-    const float* pg = pose_of(g) + b * 6;
-    if (grp == g) pv = ldf(pg, (unsigned)min(sub, 5));
-  }
+  // One batch of loads: the lane's pose component (sub 0..2 the angles, 3..5 the translation) of ITS source, its row of K, all of K.
+  // The lane's pose pointer is SELECTED from the eight kernel arguments (constant indices: scalar registers), never fetched through
+  // a run-time index and never under a branch: indexed, the compiler fetched the pointer itself with a vector load from the argument
+  // block and waited for it before it could issue the pose load -- two dependent round trips PER SOURCE at the start of every wave,
+  // each draining the disparity loads issued before (found in the ISA of the first version of this function).  Lanes of groups
+  // beyond n_src take the last source's pointer (the arguments beyond it are NULL); nothing reads their results.
+  // (K first: its addresses need nothing but the lane; the fence below keeps all the loads of this function in front of the
+  //  arithmetic -- left to itself the scheduler sank the K loads behind the wait for the pose: a second round trip)
   const Rgb Kr = ld_off<Rgb>(Kp, 12u * (unsigned)min(sub, 2));
   const K9 Ku = load_k9(Kp);
+  const int gsel = min(grp, n_src - 1);
+  const float* pp = nullptr;
+#pragma unroll
+  for (int k = 0; k < SFM_MAX_SRC; ++k) {
+    const float* pk = pose[k];
+    asm volatile("" : "+s"(pk));     // (keeps the selection from being folded back into an indexed load of the pointer: it was)
+    pp = (gsel == k) ? pk : pp;
+  }
+  const float pv = ldf(pp + b * 6, (unsigned)min(sub, 5));
+  __builtin_amdgcn_sched_barrier(0);
   float sn, cs;
   sincos_pi(fminf(fmaxf(pv, -pi), pi), &sn, &cs);                     // transform.py:23-25
   const float sx = from_lane_v(sn, base), sy = from_lane_v(sn, base + 1), sz = from_lane_v(sn, base + 2);
