@@ -27,10 +27,11 @@ synth = importlib.import_module(PKG + ".synth")
 
 def load(path):
     lib = C.CDLL(os.path.abspath(path), mode=os.RTLD_LOCAL)
-    for name in ("sfm_loss_workspace_bytes", "sfm_loss_fwd", "sfm_loss_bwd", "sfm_loss_fwd_bwd", "sfm_loss_profile_events"):
+    for name in ("sfm_loss_workspace_bytes", "sfm_loss_workspace_init", "sfm_loss_fwd", "sfm_loss_bwd", "sfm_loss_fwd_bwd", "sfm_loss_profile_events"):
         res, args = _lib.SYMBOLS[name]
-        fn = getattr(lib, name)
-        fn.restype, fn.argtypes = res, args
+        fn = getattr(lib, name, None)      # (a build of ABI v4 has no sfm_loss_workspace_init: its workspace needs no preparation)
+        if fn is not None:
+            fn.restype, fn.argtypes = res, args
     return lib
 
 
@@ -54,13 +55,19 @@ def main():
     fl = ops.FusedLoss(**cfg).bind([cv(a) for a in d["tgt_pyr"]], [cv(a) for a in d["src_pyr"]], t(d["intrinsics"]),
                                    [t(a) for a in d["disps"]], [t(a) for a in d["poses"]], layout=args.layout)
     libs = [(os.path.basename(p), load(p)) for p in args.libs]
-    need = max(l.sfm_loss_workspace_bytes(C.byref(fl.desc)) for _, l in libs)
-    ws = torch.empty((need // 4 + 64,), dtype=torch.float32, device=dev)
-    wsp = C.c_void_p(ws.data_ptr() + (-ws.data_ptr()) % 256)
     loss5 = torch.zeros(5, dtype=torch.float32, device=dev)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    wss = {}
+    for n, l in libs:      # a workspace per build, prepared by that build
+        nb = l.sfm_loss_workspace_bytes(C.byref(fl.desc))
+        t_ws = torch.empty((nb // 4 + 64,), dtype=torch.float32, device=dev)
+        ptr = C.c_void_p(t_ws.data_ptr() + (-t_ws.data_ptr()) % 256)
+        if hasattr(l, "sfm_loss_workspace_init"):
+            assert l.sfm_loss_workspace_init(C.byref(fl.desc), ptr, nb, st) == 0
+        wss[id(l)] = (t_ws, ptr, nb)
 
     def step(lib):
+        _, wsp, need = wss[id(lib)]
         if args.mode == "fused":
             rc = lib.sfm_loss_fwd_bwd(C.byref(fl.desc), C.c_void_p(loss5.data_ptr()), wsp, need, st)
         elif args.mode == "fwd":
