@@ -6,9 +6,7 @@
  * file:line into that repository).  Conventions:
  *
  *   - all tensors are float32, C-contiguous, NCHW, resident in device (HBM) memory and owned
- *     by the caller; the library never allocates, frees or keeps a pointer after return.  The one piece of device memory
- *     with a life across calls is the caller's sfm_loss_* workspace: prepared once (sfm_loss_workspace_init), left prepared
- *     by every call;
+ *     by the caller; the library never allocates, frees or keeps a pointer after return;
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every call is
  *     asynchronous with respect to the host, re-entrant, and keeps no global mutable state
  *     (the reference's module globals `filler` / `meshgrid`, models/transform.py:62,135, are
@@ -35,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SFM_ABI_VERSION 5
+#define SFM_ABI_VERSION 4
 
 #define SFM_OK 0
 #define SFM_ERR_NULL (-1)      /* a required pointer is NULL                       */
@@ -157,14 +155,6 @@ typedef struct SfmLossDesc {
 
 /* scratch needed by the three calls below for this descriptor (0 on a bad descriptor) */
 size_t sfm_loss_workspace_bytes(const SfmLossDesc *desc);
-/* Prepares a workspace (256-byte aligned, >= sfm_loss_workspace_bytes(desc)) for descriptors of this batch size B, on `stream`:
- * ONCE after allocating it, again only if something else wrote into it or B changes.  Every sfm_loss_* call leaves it prepared
- * for the next one.  (ABI v5: one launch covers a whole step -- the tail of SFMLearner.__call__, models/base_model.py:117-124, and
- * the backward of the pose chain, models/transform.py:43-91, run in the wave that arrives last at a per-sample counter kept in the
- * workspace; the counters start at zero and are put back by the wave that consumed them.  One workspace serves one call at a
- * time: launches that may run concurrently need a workspace each.)  A call on a workspace that was not prepared for its B does
- * not hang: it writes NaN into loss5 and d_pose. */
-int sfm_loss_workspace_init(const SfmLossDesc *desc, void *ws, size_t ws_bytes, void *stream);
 
 /* loss5 (device, 5 floats): total, pixel, smooth, exp, ssim -- the chainer.report keys
  * (:119-123) in that order.  With norm_B > B the values are this shard's additive share. */

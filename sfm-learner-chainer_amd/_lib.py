@@ -16,7 +16,7 @@ import torch  # noqa: F401
 
 SFM_MAX_SCALES = 8
 SFM_MAX_SRC = 8
-SFM_ABI_VERSION = 5
+SFM_ABI_VERSION = 4
 SFM_LAYOUT_PLANAR, SFM_LAYOUT_HWC = 0, 1
 
 SMOOTH_NONE, SMOOTH_SECOND_ORDER, SMOOTH_EDGE_AWARE = 0, 1, 2
@@ -61,7 +61,6 @@ SYMBOLS = {
     "sfm_sampler_interp_fwd": (_I, [_FP, _FP, _FP, _I, _I, _I, _I, _I, _I, _V]),
     "sfm_sampler_interp_bwd": (_I, [_FP, _FP, _FP, _FP, _FP, _I, _I, _I, _I, _I, _I, _V]),
     "sfm_loss_workspace_bytes": (_Z, [C.POINTER(SfmLossDesc)]),
-    "sfm_loss_workspace_init": (_I, [C.POINTER(SfmLossDesc), _V, _Z, _V]),
     "sfm_loss_fwd": (_I, [C.POINTER(SfmLossDesc), _FP, _V, _Z, _V]),
     "sfm_loss_bwd": (_I, [C.POINTER(SfmLossDesc), C.c_float, _V, _Z, _V]),
     "sfm_loss_fwd_bwd": (_I, [C.POINTER(SfmLossDesc), _FP, _V, _Z, _V]),

@@ -15,10 +15,9 @@
 //   * the 3x3 SSIM pools and their transposes are separable sums over those two,
 //   * depth gradients of all sources are summed in a wave-private LDS tile and d_disp is
 //     written exactly once, coalesced; the 12 sums of dL/dPm are reduced in-wavefront.
-// All scales, sources and samples of a step are covered by ONE launch of loss_kernel, and nothing else: every wave builds the
-// geometry of its passes itself (sfm_ssim_pass.h, build_wave_geom), and the wave that arrives last at its sample reduces the
-// sample's per-wave partials in a fixed order (bitwise reproducible), finishes d_pose and -- the last of those -- the five
-// scalars (finish_sample below).
+// All scales, sources and samples of a step are covered by ONE launch of loss_kernel (every wave builds the geometry of its
+// passes itself: sfm_ssim_pass.h, build_pass_geom), followed by a tiny one: finalize_kernel reduces the per-wave partials in a
+// fixed order (bitwise reproducible) and finishes d_pose.
 #include <stdlib.h>
 #include <string.h>
 
@@ -66,15 +65,9 @@ struct LossArgs {
   int tiles_of[SFM_MAX_SCALES];        // sc[s].tiles, 0 beyond n_scales
   int item_begin_of[SFM_MAX_SCALES];   // sc[s].item_begin
   const float* intrinsics;
-  char* ws;               // the workspace: control block (magic, launch counter, one arrival counter per sample), then the arrays below
-  unsigned off_loss;      // byte offset of the per-wave loss partials  [items][4]   pixel, ssim, smooth, exp
-  unsigned off_gpm;       // byte offset of the per-wave RAW pose sums  [items][n_src][12]
-  float gy;               // upstream gradient on total_loss
-  int cnt_stride;         // distance between the samples' arrival counters, in 32-bit words
-  // --- end of the header; the rest is read by a wave when it needs it ---
-  unsigned off_sloss;     // byte offset of the per-sample loss sums     [B][4] doubles
-  unsigned gpm_bytes;     // size of the pose-sum array (range of the finishing wave's buffer loads)
-  float* loss5;           // the five reported scalars, or nullptr (sfm_loss_bwd)
+  float* part_loss;  // [items][4]   pixel, ssim, smooth, exp
+  float* part_gpm;   // [items][n_src][12]
+  float gy;          // upstream gradient on total_loss
   unsigned long long* trace;   // diagnostics: per item {t_start, t_end (100 MHz), HW_ID, XCC_ID}; normally nullptr
   const float* pose[SFM_MAX_SRC];
   float* d_pose[SFM_MAX_SRC];
@@ -252,343 +245,6 @@ __device__ __forceinline__ void smooth_edge_pass(const LossArgs& A, const ScaleA
     if (q + 2 < y1) row(q + 2, r2, r3);
     if (q + 3 < y1) row(q + 3, r3, r0);
   }
-}
-
-// ------------------------------------------------------------------------------------------
-// The end of a step, inside the main launch (no second kernel): the tail of SFMLearner.__call__, models/base_model.py:117-124
-// (the five scalars), and the backward of the pose chain, models/transform.py:43-91 (pose_vec2mat, euler2mat, K4 . T).
-//
-// Two levels of "who arrives last", nobody ever waits:
-//   * every wave stores its partial sums THROUGH the L2 (sc1, 16-byte stores), waits for its own stores (s_waitcnt vmcnt(0)) and
-//     adds 1 to the arrival counter of its SAMPLE with a returning agent-scope atomic;
-//   * the wave whose add returns (items of the sample - 1) finishes the sample: it reads the sample's partials with sc1 loads IN ITEM
-//     ORDER (the order is the index, never the arrival: results are bitwise reproducible), folds K_s^T . (S . K_s^-T) over the
-//     sample's tiles, runs the Euler / translation backward and writes d_pose; it sums the sample's loss partials in fp64, stores
-//     them and adds 1 to the launch counter;
-//   * the sample-finishing wave whose add returns B - 1 sums the B x 4 per-sample sums (sample order) and writes loss5.
-// The counters live in the caller's workspace, start at zero (sfm_loss_workspace_init) and are put back to zero by the wave that
-// consumed them: no memset launch.  A wave that finds the control block unprepared poisons the outputs with NaN instead.
-// Memory-model form: MI355X_MICROARCH.md, 'Valid forms', the last-arriver row -- every handed-off byte stored sc1 and drained before
-// the add, every load of it a buffer_/global_ sc1 load issued after the add has returned.
-// (Round 1 tried a last-arriver with a device-scope release per wave: 3x slower; round 2 ONE workgroup reducing all 344 KB: +20 us.)
-// ------------------------------------------------------------------------------------------
-constexpr unsigned WS_MAGIC = 0x53464d35u;   // word 0 of a prepared workspace; word 1 = the batch size B it was prepared for
-constexpr int WS_LAUNCH_CNT = 32;            // word index of the launch counter (a 128-byte line of its own)
-constexpr int WS_SAMPLE_CNT = 64;            // word index of sample 0's arrival counter (sample b: + b * cnt_stride)
-constexpr int WS_CTL_BYTES = 256;            // header + launch counter
-constexpr int FIN_BATCH = 4;                 // (item, source) pairs a lane of the finishing wave keeps in flight
-
-typedef unsigned u4v __attribute__((ext_vector_type(4)));
-constexpr int AUX_SC1 = 16;                  // cache-policy operand of the raw buffer intrinsics on gfx950: sc1
-
-#ifdef SFM_FIN_STAMPS   // diagnostic build only: 100 MHz time stamps of the finishing waves into the debug trace buffer (tools/trace_finalize.py)
-#define SFM_FSTAMP(slot) do { if (A.trace && lane == 0) A.trace[200000 + 16 * b + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define SFM_FSTAMP(slot) do { } while (0)
-#endif
-
-// four fp64 sums -> (hi, lo) float pairs -> fixed-order in-register wave reduction (DPP) -> recombined in fp64, wave-uniform
-__device__ __forceinline__ void wave_sums_f64x4(double (&acc)[4]) {
-  float hl[8];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    hl[2 * k] = (float)acc[k];
-    hl[2 * k + 1] = (float)(acc[k] - (double)hl[2 * k]);
-  }
-  wave_sums_lockstep(hl);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) acc[k] = (double)lane63(hl[2 * k]) + (double)lane63(hl[2 * k + 1]);
-}
-__device__ __forceinline__ double f64_of(const unsigned lo, const unsigned hi) {
-  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-
-// index of a tile among the tiles of sample b (scale by scale) -> its scale and its item id
-// (macros, not lambdas: arrays captured by reference are not split into registers -- the compiler parks them in LDS)
-#define SFM_ITEM_OF(idx_, s_, item_)                                                                                              \
-  {                                                                                                                               \
-    int off_ = 0;                                                                                                                 \
-    s_ = 0;                                                                                                                       \
-    _Pragma("unroll") for (int k = 0; k < SFM_MAX_SCALES - 1; ++k)                                                                \
-        if ((idx_) >= off_ + tl[k] && s_ == k) { off_ += tl[k]; s_ = k + 1; }                                                     \
-    int ibs_ = ib[0], tls_ = tl[0];                                                                                               \
-    _Pragma("unroll") for (int k = 1; k < SFM_MAX_SCALES; ++k) { ibs_ = (s_ == k) ? ib[k] : ibs_; tls_ = (s_ == k) ? tl[k] : tls_; } \
-    item_ = ibs_ + b * tls_ + ((idx_) - off_);                                                                                    \
-  }
-
-template <bool GRAD, bool LOSS>
-__device__ __forceinline__ void finish_sample(const LossArgs& A, const int b, const int lane, const int total, float* lds) {
-  SFM_FSTAMP(0);
-  int tl[SFM_MAX_SCALES], ib[SFM_MAX_SCALES];
-#pragma unroll
-  for (int k = 0; k < SFM_MAX_SCALES; ++k) { tl[k] = A.tiles_of[k]; ib[k] = A.item_begin_of[k]; }
-  const int n_src = A.n_src;
-  // ---- every load of this wave's first round goes out now, oldest first what is needed first --------------------------------
-  // (GRAD) lane i < n_src finishes source i: its pose, selected from the kernel arguments (never loaded through an index, see
-  // build_wave_geom); lane s < n_scales: K of (b, s)
-  float pose6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  K9 Ku;
-  if (GRAD) {
-    const int gsel = min(lane, n_src - 1);
-    const float* pp = nullptr;
-#pragma unroll
-    for (int k = 0; k < SFM_MAX_SRC; ++k) {
-      const float* pk = A.pose[k];
-      asm volatile("" : "+s"(pk));
-      pp = (gsel == k) ? pk : pp;
-    }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) pose6[k] = ldf(pp + b * 6, (unsigned)k);
-    Ku = load_k9(A.intrinsics + ((size_t)b * A.n_scales + min(lane, A.n_scales - 1)) * 9);
-  }
-  // (LOSS) the sample's loss partials, item idx = lane + 64 j: out-of-range lanes read zeros (range-checked buffer loads)
-  const __amdgpu_buffer_rsrc_t lr = __builtin_amdgcn_make_buffer_rsrc(A.ws + A.off_loss, 0, LOSS ? A.items * 16 : 0, 0x00027000);
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  u4v l0[FIN_BATCH];
-  if (LOSS) {
-#pragma unroll
-    for (int u = 0; u < FIN_BATCH; ++u) {
-      const int idx = 64 * u + lane;
-      int s_, item;
-      const int idc = min(idx, total - 1);
-      SFM_ITEM_OF(idc, s_, item)
-      (void)s_;
-      l0[u] = __builtin_amdgcn_raw_buffer_load_b128(lr, idx < total ? (unsigned)item * 16u : 0x80000000u, 0, AUX_SC1);
-    }
-  }
-  // (GRAD) the raw pose sums of the sample: pair p = (tile idx, source i) = (p >> lg, p & (2^lg - 1)), 2^lg = n_src rounded up to a
-  // power of two, so that a lane always holds the same source; 48 contiguous bytes per pair
-  const int lg = n_src <= 1 ? 0 : (n_src <= 2 ? 1 : (n_src <= 4 ? 2 : 3));
-  const int my_i = lane & ((1 << lg) - 1);
-  const int n_pairs = total << lg;
-  const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(A.ws + A.off_gpm, 0, GRAD ? (int)A.gpm_bytes : 0, 0x00027000);
-  u4v r0[FIN_BATCH][3];
-  int scl0[FIN_BATCH];
-#define SFM_FIN_LOAD(p0_, r_, sc_)                                                                                                \
-  _Pragma("unroll") for (int u = 0; u < FIN_BATCH; ++u) {                                                                         \
-    const int p_ = (p0_) + 64 * u + lane, idx_ = p_ >> lg;                                                                        \
-    const bool ok_ = idx_ < total && my_i < n_src;                                                                                \
-    const int idc_ = min(idx_, total - 1);                                                                                        \
-    int item_;                                                                                                                    \
-    SFM_ITEM_OF(idc_, sc_[u], item_)                                                                                              \
-    const unsigned o_ = ok_ ? ((unsigned)item_ * (unsigned)n_src + (unsigned)my_i) * 48u : 0x80000000u;                           \
-    r_[u][0] = __builtin_amdgcn_raw_buffer_load_b128(gr, o_, 0, AUX_SC1);                                                         \
-    r_[u][1] = __builtin_amdgcn_raw_buffer_load_b128(gr, o_ + 16u, 0, AUX_SC1);                                                   \
-    r_[u][2] = __builtin_amdgcn_raw_buffer_load_b128(gr, o_ + 32u, 0, AUX_SC1);                                                   \
-  }
-  // the tile's raw pose sums S_k = (sum x A_k, B_k, A_k, C_k) (pose_sums_raw) -> dL/dPm[k][j] = Kinv[j] . S_k[0:3], [k][3] = S_k[3];
-  // then gT += K^T . gPm (K4^T . gPm of the rows that reach R and t).  K and K^-1 of the tile's scale come from the LDS table.
-  // (zeros -- a pair out of range -- fold to zeros: no select)
-#define SFM_FIN_FOLD(r_, sc_)                                                                                                     \
-  _Pragma("unroll") for (int u = 0; u < FIN_BATCH; ++u) {                                                                         \
-    const float* kp_ = lds + sc_[u] * 20;                                                                                         \
-    float K_[9], Ki_[9], s_[12], g_[12];                                                                                          \
-    _Pragma("unroll") for (int k = 0; k < 9; ++k) { K_[k] = kp_[k]; Ki_[k] = kp_[9 + k]; }                                        \
-    _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                                                               \
-      s_[4 * k] = __uint_as_float(r_[u][k].x); s_[4 * k + 1] = __uint_as_float(r_[u][k].y);                                       \
-      s_[4 * k + 2] = __uint_as_float(r_[u][k].z); s_[4 * k + 3] = __uint_as_float(r_[u][k].w);                                   \
-    }                                                                                                                             \
-    _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                                                               \
-      _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                                               \
-          g_[k * 4 + j] = fmaf(Ki_[j * 3 + 2], s_[k * 4 + 2], fmaf(Ki_[j * 3 + 1], s_[k * 4 + 1], Ki_[j * 3 + 0] * s_[k * 4 + 0])); \
-      g_[k * 4 + 3] = s_[k * 4 + 3];                                                                                              \
-    }                                                                                                                             \
-    _Pragma("unroll") for (int rr = 0; rr < 3; ++rr)                                                                              \
-        _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                             \
-            gT[rr * 4 + c] += K_[0 * 3 + rr] * g_[0 * 4 + c] + K_[1 * 3 + rr] * g_[1 * 4 + c] + K_[2 * 3 + rr] * g_[2 * 4 + c];    \
-  }
-  if (GRAD) { SFM_FIN_LOAD(0, r0, scl0) }
-  __builtin_amdgcn_sched_barrier(0);
-  SFM_FSTAMP(1);
-  // ---- under the shadow of the partials: the rotation (euler2mat: ~150 dependent instructions) and the K table -----------------
-  Rot rot;
-  if (GRAD) {
-    euler2mat(pose6, rot);
-    if (lane < A.n_scales) {
-      float Ki[9];
-      inv3_fast(Ku.k, Ki);
-#pragma unroll
-      for (int k = 0; k < 9; ++k) { lds[lane * 20 + k] = Ku.k[k]; lds[lane * 20 + 9 + k] = Ki[k]; }
-    }
-    __syncthreads();   // (one wave per workgroup: orders the LDS writes above before the reads below)
-  }
-  SFM_FSTAMP(2);
-  // ---- the sample's share of the four loss sums, and its arrival at the launch counter ----------------------------------------
-  unsigned* ctl = reinterpret_cast<unsigned*>(A.ws);
-  unsigned prev2 = 0;
-  if (LOSS) {
-#pragma unroll
-    for (int u = 0; u < FIN_BATCH; ++u) {
-      acc[0] += (double)__uint_as_float(l0[u].x); acc[1] += (double)__uint_as_float(l0[u].y);
-      acc[2] += (double)__uint_as_float(l0[u].z); acc[3] += (double)__uint_as_float(l0[u].w);
-    }
-    for (int i0 = 64 * FIN_BATCH; i0 < total; i0 += 64 * FIN_BATCH) {   // (samples of more than 256 tiles)
-      u4v l1[FIN_BATCH];
-#pragma unroll
-      for (int u = 0; u < FIN_BATCH; ++u) {
-        const int idx = i0 + 64 * u + lane;
-        int s_, item;
-        const int idc = min(idx, total - 1);
-        SFM_ITEM_OF(idc, s_, item)
-        (void)s_;
-        l1[u] = __builtin_amdgcn_raw_buffer_load_b128(lr, idx < total ? (unsigned)item * 16u : 0x80000000u, 0, AUX_SC1);
-      }
-#pragma unroll
-      for (int u = 0; u < FIN_BATCH; ++u) {
-        acc[0] += (double)__uint_as_float(l1[u].x); acc[1] += (double)__uint_as_float(l1[u].y);
-        acc[2] += (double)__uint_as_float(l1[u].z); acc[3] += (double)__uint_as_float(l1[u].w);
-      }
-    }
-    wave_sums_f64x4(acc);
-    if (A.B > 1) {
-      if (lane == 0) {
-        float* o = reinterpret_cast<float*>(A.ws + A.off_sloss) + (size_t)b * 8;
-        float w[8];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const unsigned long long bits = __builtin_bit_cast(unsigned long long, acc[k]);
-          w[2 * k] = __uint_as_float((unsigned)bits);
-          w[2 * k + 1] = __uint_as_float((unsigned)(bits >> 32));
-        }
-        st16_wt(o, w[0], w[1], w[2], w[3]);
-        st16_wt(o + 4, w[4], w[5], w[6], w[7]);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) prev2 = __hip_atomic_fetch_add(ctl + WS_LAUNCH_CNT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  SFM_FSTAMP(3);
-  // ---- d_pose of this sample: lanes = (tile, source) pairs, then one in-register wave reduction per source ---------------------
-  if (GRAD) {
-    float gT[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) gT[k] = 0.f;
-    SFM_FIN_FOLD(r0, scl0)
-    for (int p0 = 64 * FIN_BATCH; p0 < n_pairs; p0 += 64 * FIN_BATCH) {
-      u4v r1[FIN_BATCH][3];
-      int scl1[FIN_BATCH];
-      SFM_FIN_LOAD(p0, r1, scl1)
-      SFM_FIN_FOLD(r1, scl1)
-    }
-    SFM_FSTAMP(4);
-    float mine[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) mine[k] = 0.f;
-    for (int i = 0; i < n_src; ++i) {
-      float v[12];
-#pragma unroll
-      for (int k = 0; k < 12; ++k) v[k] = (my_i == i) ? gT[k] : 0.f;
-      wave_sums_lockstep(v);
-#pragma unroll
-      for (int k = 0; k < 12; ++k) {
-        const float t = lane63(v[k]);
-        mine[k] = (lane == i) ? t : mine[k];
-      }
-    }
-    float d[6];
-    pose_backward(pose6, rot, mine, d);
-    float* dp = nullptr;
-#pragma unroll
-    for (int k = 0; k < SFM_MAX_SRC; ++k) {
-      float* dk = A.d_pose[k];
-      asm volatile("" : "+s"(dk));
-      dp = (lane == k) ? dk : dp;
-    }
-    if (lane < n_src) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) dp[b * 6 + k] = d[k];
-    }
-    SFM_FSTAMP(5);
-  }
-#undef SFM_FIN_LOAD
-#undef SFM_FIN_FOLD
-  // ---- the five reported scalars, in the sample-finishing wave that arrived last ----------------------------------------------
-  if (LOSS) {
-    if (A.B > 1) {
-      prev2 = (unsigned)__builtin_amdgcn_readfirstlane((int)prev2);
-      SFM_FSTAMP(6);
-      if ((int)prev2 + 1 != A.B) return;
-      if (lane == 0) __hip_atomic_store(ctl + WS_LAUNCH_CNT, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-      const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(A.ws + A.off_sloss, 0, A.B * 32, 0x00027000);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) acc[k] = 0.0;
-      for (int k0 = 0; k0 < A.B; k0 += 128) {      // sample k0 + lane, k0 + 64 + lane: per-lane sums in sample order
-        const unsigned oa = k0 + lane < A.B ? (unsigned)(k0 + lane) * 32u : 0x80000000u;
-        const unsigned ob = k0 + 64 + lane < A.B ? (unsigned)(k0 + 64 + lane) * 32u : 0x80000000u;
-        const u4v a0 = __builtin_amdgcn_raw_buffer_load_b128(sr, oa, 0, AUX_SC1), a1 = __builtin_amdgcn_raw_buffer_load_b128(sr, oa + 16u, 0, AUX_SC1);
-        const u4v c0 = __builtin_amdgcn_raw_buffer_load_b128(sr, ob, 0, AUX_SC1), c1 = __builtin_amdgcn_raw_buffer_load_b128(sr, ob + 16u, 0, AUX_SC1);
-        acc[0] += f64_of(a0.x, a0.y); acc[1] += f64_of(a0.z, a0.w); acc[2] += f64_of(a1.x, a1.y); acc[3] += f64_of(a1.z, a1.w);
-        acc[0] += f64_of(c0.x, c0.y); acc[1] += f64_of(c0.z, c0.w); acc[2] += f64_of(c1.x, c1.y); acc[3] += f64_of(c1.z, c1.w);
-      }
-      wave_sums_f64x4(acc);
-    }
-    if (lane == 0) {
-      const double pixel = acc[0], ssim = acc[1], smooth = acc[2], expl = acc[3];
-      const double a = (double)A.alpha;
-      float* loss5 = A.loss5;
-      loss5[0] = (float)((1.0 - a) * pixel + a * ssim + smooth + expl);   // base_model.py:117-118
-      loss5[1] = (float)pixel;
-      loss5[2] = (float)smooth;
-      loss5[3] = (float)expl;
-      loss5[4] = (float)ssim;
-    }
-    SFM_FSTAMP(7);
-  }
-}
-#undef SFM_ITEM_OF
-
-// every wave, once its partial sums have been stored
-template <bool GRAD, bool LOSS>
-__device__ __forceinline__ void wave_arrive(const LossArgs& A, const int b, const int lane, float* lds) {
-#if defined(SFM_FIN_VARIANT) && SFM_FIN_VARIANT == 0   // timing experiment: nothing at the end of a wave (outputs not produced)
-  return;
-#endif
-  unsigned* ctl = reinterpret_cast<unsigned*>(A.ws);
-  // {magic, B} of the control block: in flight while the stores drain
-  const unsigned long long hdr = __hip_atomic_load(reinterpret_cast<unsigned long long*>(ctl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  int total = 0;
-#pragma unroll
-  for (int k = 0; k < SFM_MAX_SCALES; ++k) total += A.tiles_of[k];     // (0 beyond n_scales)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every store of this wave has left (the partial sums: written through, sc1)
-  const unsigned h0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)hdr), h1 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(hdr >> 32));
-  if (h0 != WS_MAGIC || h1 != (unsigned)A.B) {
-    // not a workspace sfm_loss_workspace_init prepared for this batch size: its counters cannot be trusted.  Fail loudly.
-    const float qn = __builtin_nanf("");
-    if (LOSS && lane < 5) A.loss5[lane] = qn;
-    if (GRAD && lane < 6) {
-#pragma unroll
-      for (int k = 0; k < SFM_MAX_SRC; ++k)
-        if (k < A.n_src) A.d_pose[k][b * 6 + lane] = qn;
-    }
-    return;
-  }
-  unsigned* cnt = ctl + WS_SAMPLE_CNT + (size_t)b * A.cnt_stride;
-  unsigned prev = 0;
-  if (lane == 0) prev = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  prev = (unsigned)__builtin_amdgcn_readfirstlane((int)prev);
-  if ((int)prev + 1 != total) return;
-  if (lane == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-#if defined(SFM_FIN_VARIANT) && SFM_FIN_VARIANT == 1   // timing experiment: arrival only
-  return;
-#elif defined(SFM_FIN_VARIANT) && SFM_FIN_VARIANT == 2   // timing experiment: arrival + ONE round trip (all partials of the sample summed as they are) + one store
-  {
-    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(A.ws + A.off_gpm, 0, (int)A.gpm_bytes, 0x00027000);
-    float acc = 0.f;
-    const int n16 = total * A.n_src * 3;
-    for (int q0 = 0; q0 < n16; q0 += 64 * 8) {
-      u4v r[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) r[u] = __builtin_amdgcn_raw_buffer_load_b128(gr, q0 + 64 * u + lane < n16 ? (unsigned)(b * n16 + q0 + 64 * u + lane) * 16u : 0x80000000u, 0, AUX_SC1);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc += __uint_as_float(r[u].x) + __uint_as_float(r[u].y) + __uint_as_float(r[u].z) + __uint_as_float(r[u].w);
-    }
-    acc = wave_sum(acc);
-    if (GRAD && lane < 6) A.d_pose[0][b * 6 + lane] = acc;
-    if (LOSS && lane < 5) A.loss5[lane] = acc;
-  }
-  return;
-#endif
-  finish_sample<GRAD, LOSS>(A, b, lane, total, lds);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -797,7 +453,7 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
     C.xinf = xin ? 1.f : 0.f;
     C.outf = outl ? 1.f : 0.f;
     C.lane = lane;
-    float* gpm_out = GRAD ? reinterpret_cast<float*>(A.ws + A.off_gpm) + ((size_t)item * A.n_src + i) * 12 : nullptr;
+    float* gpm_out = GRAD ? A.part_gpm + ((size_t)item * A.n_src + i) * 12 : nullptr;
     if constexpr (SSIM) {
       ssim_source_pass<GRAD, LOSS, HWC, WARPED>(C, gacc, first, acc_pix, acc_ssim, gpm_out SFM_STAMPS_PASS);
     } else {
@@ -838,10 +494,11 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
     const float v1 = wave_sum(acc_ssim) * S.inv_cnt;
     const float v2 = wave_sum(acc_sm);
     const float v3 = wave_sum(acc_exp) * S.c_exp;
-    if (lane == 0) st16_wt(reinterpret_cast<float*>(A.ws + A.off_loss) + (size_t)item * 4, v0, v1, v2, v3);
+    if (lane == 0) {
+      float* o = A.part_loss + (size_t)item * 4;
+      o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3;
+    }
   }
-  // this wave's partial sums are on their way: sign in at the sample; the wave that signs in last finishes the sample
-  wave_arrive<GRAD, LOSS>(A, b, lane, gacc);
 }
 
 template <bool SSIM, bool GRAD, bool LOSS, bool EXPL, int SMODE, bool HWC, bool WARPED = false>
@@ -855,11 +512,215 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 3) loss_kernel_wide(cons
 }
 
 // ------------------------------------------------------------------------------------------
+// finalize: fixed-order reduction of the per-wave partials
+//   blocks [0, B*n_src): d_pose of (b, i)         (only when do_pose)
+//   last block        : the five reported scalars (only when loss5 != nullptr)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+#ifdef SFM_FIN_STAMPS   // diagnostic build only: 100 MHz time stamps of finalize_kernel's stages into the debug trace buffer (tools/trace_finalize.py)
+#define SFM_FSTAMP(slot) do { if (A.trace && threadIdx.x == 0) A.trace[200000 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SFM_FSTAMP(slot) do { } while (0)
+#endif
+
+constexpr int FINALIZE_WAVES = 16;   // waves of the block that sums the loss partials (the pose blocks use one)
+
+__global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const LossArgs A, float* __restrict__ loss5, const int n_pose_blocks) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ((int)blockIdx.x < n_pose_blocks) {
+    // d_pose of (b, i): every lane folds its tiles of every scale into K_s^T . gPm (linear), one in-register wave reduction (DPP).
+    // A sample with many tiles (308 at cfg2, 376 at cfg5) is spread over the sixteen waves of the block, so that its partials are
+    // fetched in ONE round of independent loads instead of up to six dependent rounds (-1 us on those steps); the waves' sums meet
+    // in LDS and are added in wave order: a fixed order, the result does not depend on timing.
+    const int b = blockIdx.x / A.n_src, i = blockIdx.x - b * A.n_src;
+    const bool stamp = blockIdx.x == 0;
+    if (stamp) SFM_FSTAMP(0);
+    __shared__ float pose_red[FINALIZE_WAVES][12];
+    // This block is a chain of round trips to memory with little arithmetic between them, so it is written to need TWO: every field
+    // of the argument block it uses is fetched unconditionally and at once (tile counts of all SFM_MAX_SCALES scales -- zero beyond
+    // n_scales --, all pose pointers: the one of source i is selected, not loaded through an index), then the pose and up to two
+    // rounds of partials go out together.  While they are in flight wave 0 has nothing to do; when the pose arrives it builds the
+    // rotation (euler2mat: ~150 dependent instructions) under the shadow of the partials.
+    int tl[SFM_MAX_SCALES], ib[SFM_MAX_SCALES];
+#pragma unroll
+    for (int k = 0; k < SFM_MAX_SCALES; ++k) { tl[k] = A.tiles_of[k]; ib[k] = A.item_begin_of[k]; }
+    const float* pp = nullptr;
+    float* dp = nullptr;
+#pragma unroll
+    for (int k = 0; k < SFM_MAX_SRC; ++k) {
+      const float* pk = A.pose[k];
+      float* dk = A.d_pose[k];
+      asm volatile("" : "+s"(pk), "+s"(dk));   // (keeps the selection from being folded back into an indexed load)
+      pp = (i == k) ? pk : pp;
+      dp = (i == k) ? dk : dp;
+    }
+    int total = 0;
+#pragma unroll
+    for (int k = 0; k < SFM_MAX_SCALES; ++k) total += tl[k];
+    // up to two rounds of loads one wave does alone (cfg3: the block's other waves leave at once, no LDS, no barrier: 1 us
+    // faster than sharing); more are spread over all the waves of the block
+    const int nw = total > 128 ? FINALIZE_WAVES : 1;    // block-uniform
+    if (wave >= nw) return;
+    if (stamp) SFM_FSTAMP(1);
+    float pose6[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pose6[k] = pp[b * 6 + k];
+    float gT3[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) gT3[k] = 0.f;
+    // (macros, not lambdas: arrays captured by reference are not split into registers, the compiler parks them in LDS and fetches
+    //  the workgroup size for that from the dispatch packet -- in host memory, 10 us away)
+#define SFM_FIN_FETCH(idx_, v0_, v1_, v2_, K_)                                                                                    \
+  {                                                                                                                               \
+    int s_ = 0, off_ = 0;                                                                                                         \
+    _Pragma("unroll") for (int k = 0; k < SFM_MAX_SCALES - 1; ++k)                                                                \
+        if ((idx_) >= off_ + tl[k] && s_ == k) { off_ += tl[k]; s_ = k + 1; }                                                     \
+    int ibs_ = ib[0], tls_ = tl[0];                                                                                               \
+    _Pragma("unroll") for (int k = 1; k < SFM_MAX_SCALES; ++k) { ibs_ = (s_ == k) ? ib[k] : ibs_; tls_ = (s_ == k) ? tl[k] : tls_; } \
+    const float4* p_ = reinterpret_cast<const float4*>(A.part_gpm + ((size_t)(ibs_ + b * tls_ + ((idx_) - off_)) * A.n_src + i) * 12); \
+    v0_ = p_[0]; v1_ = p_[1]; v2_ = p_[2];                                                                                        \
+    const float* Kp_ = A.intrinsics + ((size_t)b * A.n_scales + s_) * 9;                                                          \
+    _Pragma("unroll") for (int k = 0; k < 9; ++k) K_[k] = Kp_[k];                                                                 \
+  }
+    // the tile's raw pose sums S_k = (sum x A_k, B_k, A_k, C_k) (pose_sums_raw) -> dL/dPm[k][j] = Kinv[j] . S_k[0:3], [k][3] = S_k[3];
+    // then gT3 += K^T . gPm   (K4^T . gPm of the rows that reach R and t)
+#define SFM_FIN_FOLD(v0_, v1_, v2_, K_)                                                                                           \
+  {                                                                                                                               \
+    const float s_[12] = {v0_.x, v0_.y, v0_.z, v0_.w, v1_.x, v1_.y, v1_.z, v1_.w, v2_.x, v2_.y, v2_.z, v2_.w};                    \
+    float Ki_[9], g_[12];                                                                                                         \
+    inv3_fast(K_, Ki_);                                                                                                           \
+    _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                                                               \
+      _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                                               \
+          g_[k * 4 + j] = fmaf(Ki_[j * 3 + 2], s_[k * 4 + 2], fmaf(Ki_[j * 3 + 1], s_[k * 4 + 1], Ki_[j * 3 + 0] * s_[k * 4 + 0])); \
+      g_[k * 4 + 3] = s_[k * 4 + 3];                                                                                              \
+    }                                                                                                                             \
+    _Pragma("unroll") for (int r = 0; r < 3; ++r)                                                                                 \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                             \
+            gT3[r * 4 + c] += K_[0 * 3 + r] * g_[0 * 4 + c] + K_[1 * 3 + r] * g_[1 * 4 + c] + K_[2 * 3 + r] * g_[2 * 4 + c];      \
+  }
+    const int stride = 64 * nw;
+    const int idx0 = threadIdx.x, idx1 = idx0 + stride;
+    const bool has0 = idx0 < total, has1 = idx1 < total;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, c0 = a0, c1 = a0, c2 = a0;
+    float Ka[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, Kc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (has0) SFM_FIN_FETCH(idx0, a0, a1, a2, Ka)
+    if (has1) SFM_FIN_FETCH(idx1, c0, c1, c2, Kc)
+    Rot rot;
+    if (wave == 0) euler2mat(pose6, rot);      // (wave-uniform; the result is only read by lane 0 of wave 0)
+#ifdef SFM_FIN_STAMPS
+    if (stamp && rot.R[0] != 77.f) SFM_FSTAMP(2);
+#endif
+    if (has0) SFM_FIN_FOLD(a0, a1, a2, Ka)
+    if (has1) SFM_FIN_FOLD(c0, c1, c2, Kc)
+    for (int idx = idx1 + stride; idx < total; idx += stride) {   // (samples of more than 2048 tiles)
+      SFM_FIN_FETCH(idx, a0, a1, a2, Ka)
+      SFM_FIN_FOLD(a0, a1, a2, Ka)
+    }
+#undef SFM_FIN_FETCH
+#undef SFM_FIN_FOLD
+#ifdef SFM_FIN_STAMPS
+    if (stamp && gT3[0] != 77.f) SFM_FSTAMP(3);
+#endif
+    wave_sums_lockstep(gT3);
+    float gT[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) gT[k] = lane63(gT3[k]);
+    if (nw > 1) {          // (every wave of the block is here: none left above)
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) pose_red[wave][k] = gT[k];
+      }
+      __syncthreads();
+      if (wave != 0) return;
+      // lane k < 12 adds the sixteen partial sums of component k in wave order, then the twelve totals go to every lane
+      float a = 0.f;
+      if (lane < 12)
+        for (int wv = 0; wv < FINALIZE_WAVES; ++wv) a += pose_red[wv][lane];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) gT[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), k));
+    }
+#ifdef SFM_FIN_STAMPS
+    if (stamp && gT[0] != 77.f) SFM_FSTAMP(4);
+#endif
+    if (lane == 0) {
+      float d[6];
+      pose_backward(pose6, rot, gT, d);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) dp[b * 6 + k] = d[k];
+#ifdef SFM_FIN_STAMPS
+      if (stamp && d[0] != 77.f) SFM_FSTAMP(5);
+#endif
+    }
+    return;
+  }
+  if (loss5 == nullptr) return;
+  // the five reported scalars: per-lane fp64 partial sums over the items, then a fixed-order in-register
+  // wave reduction of (hi, lo) float pairs (DPP), recombined in fp64
+  // (16 waves, so that the partials are fetched in one or two rounds of independent loads; the waves' sums
+  // meet in LDS and are added in wave order: the result does not depend on timing)
+  SFM_FSTAMP(8);
+  __shared__ double wave_red[FINALIZE_WAVES][4];
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  const float4* pl = reinterpret_cast<const float4*>(A.part_loss);
+#pragma unroll 4
+  for (int t = threadIdx.x; t < A.items; t += 64 * FINALIZE_WAVES) {
+    const float4 v = pl[t];
+    acc[0] += (double)v.x; acc[1] += (double)v.y; acc[2] += (double)v.z; acc[3] += (double)v.w;
+  }
+#ifdef SFM_FIN_STAMPS
+  if (acc[0] != 77.0) SFM_FSTAMP(9);
+#endif
+  {
+    float hl[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      hl[2 * k] = (float)acc[k];
+      hl[2 * k + 1] = (float)(acc[k] - (double)hl[2 * k]);
+    }
+    wave_sums_lockstep(hl);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double r = (double)lane63(hl[2 * k]) + (double)lane63(hl[2 * k + 1]);
+      if (lane == 0) wave_red[wave][k] = r;
+    }
+  }
+  __syncthreads();
+  SFM_FSTAMP(10);
+  if (wave == 0) {
+    // lane k < 4 adds the sixteen wave sums of scalar k in wave order (four chains side by side instead of 64 additions in a row)
+    double mine = 0.0;
+    if (lane < 4)
+      for (int wv = 0; wv < FINALIZE_WAVES; ++wv) mine += wave_red[wv][lane];
+    double red[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned long long bits = __builtin_bit_cast(unsigned long long, mine);
+      const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, k), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), k);
+      red[k] = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+    }
+    if (lane != 0) return;
+    const double pixel = red[0], ssim = red[1], smooth = red[2], expl = red[3];
+    const double a = (double)A.alpha;
+    loss5[0] = (float)((1.0 - a) * pixel + a * ssim + smooth + expl);   // base_model.py:117-118
+    loss5[1] = (float)pixel;
+    loss5[2] = (float)smooth;
+    loss5[3] = (float)expl;
+    loss5[4] = (float)ssim;
+    SFM_FSTAMP(11);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 struct Plan {
   LossArgs args;
-  size_t off_sloss, off_loss, off_gpm, total;   // workspace layout (bytes): control block + sample counters at 0
+  size_t off_loss, off_gpm, total;
   bool ssim, expl, hwc;
   bool wide;     // the three-waves-per-SIMD build of an L1 gradient kernel (see loss_kernel)
   bool warped;   // the instantiation that also writes SfmLossDesc.warped
@@ -1122,21 +983,9 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
   // and sized for the largest item count any chunking can produce.
   const size_t cap = (size_t)max_items(d, sw);
   if ((size_t)items > cap) return fail(SFM_ERR_CONFIG, "sfm_loss: internal error: %d items exceed the bound %zu", items, cap);
-  // control block (WS_CTL_BYTES) | arrival counter of every sample | per-sample loss sums [B][4] fp64 | loss partials | pose sums.
-  // The counters of up to 4096 samples get a 256-byte line each: they are hit by a burst of returning atomics when the waves of a
-  // launch end together, and atomics on one line are served one after the other (MI355X_MICROARCH.md, 'dequeue').
-  A.cnt_stride = d->B <= 4096 ? 64 : 1;
-  p.off_sloss = align_up((size_t)WS_CTL_BYTES + (size_t)d->B * A.cnt_stride * 4, 256);
-  p.off_loss = align_up(p.off_sloss + (size_t)d->B * 32, 256);
+  p.off_loss = 0;
   p.off_gpm = align_up(p.off_loss + cap * 4 * sizeof(float), 256);
-  const size_t gpm_bytes = cap * d->n_src * 12 * sizeof(float);
-  p.total = align_up(p.off_gpm + gpm_bytes, 256);
-  // (the finishing wave addresses the partial-sum arrays with 32-bit byte offsets)
-  if (p.total >= (1ull << 31)) return fail(SFM_ERR_SHAPE, "sfm_loss: the launch needs a workspace of %zu bytes (limit 2 GiB)", p.total);
-  A.off_sloss = (unsigned)p.off_sloss;
-  A.off_loss = (unsigned)p.off_loss;
-  A.off_gpm = (unsigned)p.off_gpm;
-  A.gpm_bytes = (unsigned)gpm_bytes;
+  p.total = align_up(p.off_gpm + cap * d->n_src * 12 * sizeof(float), 256);
   return SFM_OK;
 }
 
@@ -1151,7 +1000,11 @@ static void set_gy(Plan& p, const float gy) {
   }
 }
 
-static void bind_workspace(Plan& p, void* ws) { p.args.ws = (char*)ws; }
+static void bind_workspace(Plan& p, void* ws) {
+  char* base = (char*)ws;
+  p.args.part_loss = (float*)(base + p.off_loss);
+  p.args.part_gpm = (float*)(base + p.off_gpm);
+}
 
 template <bool GRAD, bool LOSS>
 static const void* kernel_ptr(bool ssim, bool expl, int smode, bool hwc, bool wide, bool warped) {
@@ -1248,7 +1101,6 @@ static int run(const SfmLossDesc* d, bool grad, bool loss, float gy, float* loss
   if (!ws || ws_bytes < p.total) return fail(SFM_ERR_WORKSPACE, "%s: workspace of %zu bytes needed, got %zu", who, p.total, ws_bytes);
   if (((uintptr_t)ws & 255) != 0) return fail(SFM_ERR_WORKSPACE, "%s: workspace must be 256-byte aligned", who);
   bind_workspace(p, ws);
-  p.args.loss5 = loss ? loss5 : nullptr;
   p.args.trace = g_trace;
   g_trace = nullptr;
   hipEvent_t ev_start = g_ev_start, ev_stop = g_ev_stop;
@@ -1257,7 +1109,9 @@ static int run(const SfmLossDesc* d, bool grad, bool loss, float gy, float* loss
   if (grad && loss) le = launch_main<true, true>(p, st, ev_start, ev_stop);
   else if (grad) le = launch_main<true, false>(p, st, ev_start, ev_stop);
   else le = launch_main<false, true>(p, st, ev_start, ev_stop);
-  if (le != hipSuccess) return fail((int)le, "%s: launch: %s", who, hipGetErrorString(le));
+  if (le != hipSuccess) return fail((int)le, "%s: launch of the main kernel: %s", who, hipGetErrorString(le));
+  const int n_pose_blocks = grad ? d->B * d->n_src : 0;
+  hipLaunchKernelGGL(finalize_kernel, dim3(n_pose_blocks + 1), dim3(64 * FINALIZE_WAVES), 0, st, p.args, loss ? loss5 : (float*)nullptr, n_pose_blocks);
   return check_launch(who);
 }
 
@@ -1275,21 +1129,6 @@ size_t sfm_loss_workspace_bytes(const SfmLossDesc* desc) {
     if (p.total > total) total = p.total;
   }
   return total;
-}
-
-int sfm_loss_workspace_init(const SfmLossDesc* desc, void* ws, size_t ws_bytes, void* stream) {
-  if (!desc) return sfm::fail(SFM_ERR_NULL, "sfm_loss_workspace_init: NULL descriptor");
-  const size_t need = desc->B > 0 ? sfm_loss_workspace_bytes(desc) : (size_t)sfm::WS_CTL_BYTES;
-  if (need == 0) return sfm::fail(SFM_ERR_CONFIG, "sfm_loss_workspace_init: %s", sfm_last_error());
-  if (!ws || ws_bytes < need) return sfm::fail(SFM_ERR_WORKSPACE, "sfm_loss_workspace_init: workspace of %zu bytes needed, got %zu", need, ws_bytes);
-  if (((uintptr_t)ws & 255) != 0) return sfm::fail(SFM_ERR_WORKSPACE, "sfm_loss_workspace_init: workspace must be 256-byte aligned");
-  hipStream_t st = (hipStream_t)stream;
-  // zeros everywhere (the counters), then the two header words: the magic and the batch size the counters are laid out for
-  hipError_t e = hipMemsetAsync(ws, 0, need, st);
-  if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)ws, (int)sfm::WS_MAGIC, 1, st);
-  if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)((char*)ws + 4), desc->B, 1, st);
-  if (e != hipSuccess) return sfm::fail((int)e, "sfm_loss_workspace_init: %s", hipGetErrorString(e));
-  return SFM_OK;
 }
 
 int sfm_loss_plan_info(const SfmLossDesc* desc, int grad, int loss, int* out, int n_out) {

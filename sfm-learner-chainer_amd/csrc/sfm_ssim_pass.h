@@ -547,12 +547,12 @@ __device__ __forceinline__ void pose_sums_raw(const SsimCtx& C, const PoseAcc& p
     v[k * 4 + 3] = acc[6 + k];
   }
   wave_sums_lockstep(v);
-  // lane 63 holds the twelve totals: it writes them THROUGH the L2 (three 16-byte sc1 stores): the wave that finishes this sample
-  // (finish_sample, sfm_loss.hip) may run on another XCD and reads them with sc1 loads
+  // lane 63 holds the twelve totals: it writes them (three 16-byte stores)
   if (C.lane == 63) {
-    st16_wt(gpm_out, v[0], v[1], v[2], v[3]);
-    st16_wt(gpm_out + 4, v[4], v[5], v[6], v[7]);
-    st16_wt(gpm_out + 8, v[8], v[9], v[10], v[11]);
+    float4* o = reinterpret_cast<float4*>(gpm_out);
+    o[0] = make_float4(v[0], v[1], v[2], v[3]);
+    o[1] = make_float4(v[4], v[5], v[6], v[7]);
+    o[2] = make_float4(v[8], v[9], v[10], v[11]);
   }
 }
 

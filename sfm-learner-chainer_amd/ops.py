@@ -347,9 +347,6 @@ class FusedLoss:
         off = (-self.ws.data_ptr()) % 256
         self._ws_ptr = self.ws.data_ptr() + off
         self._ws_bytes = nbytes
-        # the workspace carries the arrival counters of the in-launch reduction: prepared once here, left prepared by every call
-        with torch.cuda.device(dev):
-            check(lib.sfm_loss_workspace_init(C.byref(d), C.c_void_p(self._ws_ptr), nbytes, _stream(dev.index)))
         self.loss5 = torch.zeros((5,), dtype=torch.float32, device=dev)
         self.desc, self.device = d, dev
         self._desc_ref, self._ws_arg, self._loss5_arg = C.byref(d), C.c_void_p(self._ws_ptr), _p(self.loss5)
