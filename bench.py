@@ -213,6 +213,13 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def collective_line(coll, has_comm, rehearse, comm_note):
+    """config.collective of the JSON line: what issued the per-step collective -- and, loudly, when that was the fallback."""
+    direct = has_comm or rehearse or coll == "step_torch"
+    return COLLECTIVE_NOTES[coll] + ("" if direct else
+                                     " -- FALLBACK: issued through torch.distributed.all_reduce, the direct communicator could not be made: %s" % comm_note)
+
+
 def dry_run_rank(args):
     """SFM_BENCH_DRYRUN=1 (tests/test_bench_spawn_cpu.py): everything of the multi-rank plumbing EXCEPT the GPU work -- the
     rendezvous the ranks were started with (gloo instead of RCCL), the per-step collective on a 5-float row, the barrier + MAX
@@ -464,6 +471,12 @@ def main():
     rehearse = bool(os.environ.get("SFM_BENCH_REHEARSE_ONE_GPU")) and world > 1
     if rehearse:
         local = 0
+    # "if the box exposes fewer devices than ranks, report the devices found": every RANK checks for itself (the parent
+    # never touches a GPU; counting devices does not initialise one), says so in one line and leaves with a non-zero code
+    devices_found = torch.cuda.device_count()
+    if local >= devices_found:
+        sys.exit("bench.py --gpus %d: rank %d (LOCAL_RANK %d) has no device -- this box exposes %d GPU(s): %d ranks cannot be measured here "
+                 "(not measured, not a failure of the path)" % (args.gpus, rank, local, devices_found, args.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ     # under torch.distributed.run, also at N = 1
@@ -491,20 +504,13 @@ def main():
     comm, comm_note = None, None
     if use_dist and not rehearse:
         # (No multi-GPU node was available to the builder: if the direct communicator cannot be made on the node this runs on, EVERY
-        #  rank falls back to torch.distributed for the collective -- agreed through the process group that is already up -- and the
-        #  line says so, rather than losing the scaling run.)
-        try:
-            rccl = importlib.import_module(PKG + ".rccl")
-            comm = rccl.Communicator(rank, world, dev)
-        except Exception as e:       # noqa: BLE001
-            comm_note = "%s: %s" % (type(e).__name__, e)
-            sys.stderr.write("rank %d: direct RCCL communicator failed (%s)\n" % (rank, comm_note))
-        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:
-            if comm is not None:
-                comm.destroy()
-            comm, comm_note = None, comm_note or "another rank could not make the communicator"
+        #  rank falls back to torch.distributed for the collective and the line says so, rather than losing the scaling run.  The
+        #  ranks AGREE on that -- rccl.connect: local steps, agreement, id broadcast, ncclCommInitRank under a deadline, agreement --
+        #  so that no rank is left inside a collective the others never enter; tests/test_dist_cpu.py makes one rank fail at each step.)
+        rccl = importlib.import_module(PKG + ".rccl")
+        comm, comm_note = rccl.connect(rank, world, dev)
+        if comm is None:
+            sys.stderr.write("rank %d: no direct RCCL communicator (%s): the per-step collective goes through torch.distributed\n" % (rank, comm_note))
     raw_stream = torch.cuda.current_stream(dev).cuda_stream
 
     def reduce_rows(t):
@@ -582,15 +588,17 @@ def main():
             variants_ms[oc] = float(np.median([timed_block(oc) for _ in range(min(n_blocks, 5))])) / K * 1e3
     if world > 1:
         buf = torch.zeros((GRAD_BUFFER_FLOATS,), dtype=torch.float32, device=dev)
+        # through the direct communicator when there is one: the bus-bandwidth figure is then RCCL's, not that of torch's host path
+        big_reduce = (lambda: comm.all_reduce_sum_f32(buf, raw_stream)) if comm is not None else (lambda: dist.all_reduce(buf))
         for _ in range(3):
-            dist.all_reduce(buf)
+            big_reduce()
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         n_ar = 10
         for _ in range(n_ar):
-            dist.all_reduce(buf)
+            big_reduce()
         torch.cuda.synchronize()
         tt = torch.tensor([(time.perf_counter() - t0) / n_ar], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -599,6 +607,7 @@ def main():
         allreduce_probe = {"bytes": nbytes, "ms": round(t_ar * 1e3, 4), "algbw_GBs": round(nbytes / t_ar / 1e9, 1),
                            "busbw_GBs": round(2.0 * (world - 1) / world * nbytes / t_ar / 1e9, 1),
                            "xgmi_per_link_GBs": 153, "links_per_gpu": 7,
+                           "issued_through": "ncclAllReduce on the direct communicator (rccl.py)" if comm is not None else "torch.distributed.all_reduce",
                            "note": "fp32 sum all-reduce of a DispNet+PoseNet-sized gradient buffer (out-of-scope trainer traffic), "
                                    "timed only to characterise RCCL over xGMI on this node"}
         del buf
@@ -670,14 +679,12 @@ def main():
                                        "priced with profiles/%s_op_cost_microbench.txt); clock: profiles/%s_wave_stage_stamps.txt" % ((facts["tag"],) * 4)}
         out = {
             "metric": "warp+photo-loss fwd+bwd Mpixels/s @128x416x4scales; % HBM roofline",
-            "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "devices_found": devices_found, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": R.desc, "per_gpu_batch": R.B, "global_batch": R.B * world, "H": R.H, "W": R.W, "n_src": R.n_src,
                        "n_scales": R.n_scales, "mode": args.mode, "image_layout": args.layout, "warped_px_per_gpu_step": R.warped_px,
-                       "collective": (COLLECTIVE_NOTES[coll] + ("" if (comm is not None or rehearse or coll == "step_torch") else
-                                      " -- FALLBACK: issued through torch.distributed.all_reduce, the direct communicator failed: %s" % comm_note))
-                       if use_dist else None,
+                       "collective": collective_line(coll, comm is not None, rehearse, comm_note) if use_dist else None,
                        "parallelism": ("batch-sharded x%d, no exchange on the data path; RCCL all-reduce of the 5 reported scalars: %s" % (
                            world, COLLECTIVE_NOTES[coll])) if use_dist else "single GPU, no collective"},
             "timing": {"blocks": len(blocks), "steps_per_block": K, "timed_s": round(float(np.sum(blocks)), 4),

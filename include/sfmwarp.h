@@ -18,7 +18,9 @@
  *     images of any range.  The SSIM terms (models/base_model.py:126-142) form variances as E[x^2] - mu^2 in fp32, as the
  *     reference does: beyond a range of about +-16 those cancel, SSIM's denominator can reach 0, and where the reference's
  *     F.clip backward then yields a zero gradient this library may yield a non-finite one (the loss scalars stay right).
- *     A NaN anywhere in an image makes the loss NaN, as in the reference;
+ *     A NaN anywhere in an image makes the loss NaN, as in the reference.  Image values are taken to be zero or NORMAL
+ *     floats: the zero mask of models/base_model.py:96 is formed as clamp(max_c |I^_c| * 2^127, 0, 1), which is exactly 0 / 1 for those
+ *     and a fraction of 1 for a pixel whose three warped channels are all subnormal (|.| < 1.2e-38; uint8 / 127.5 - 1 has none);
  *   - return value: 0 on success; SFM_ERR_* (<0) for a rejected argument; a positive value is
  *     a hipError_t from the launch.  sfm_last_error() returns a thread-local message.
  *     No exception or abort crosses the ABI.
@@ -175,6 +177,12 @@ int sfm_loss_profile_events(void *ev_start, void *ev_stop);
  * and tuning; nothing is launched. */
 int sfm_loss_plan_info(const SfmLossDesc *desc, int grad, int loss, int *out, int n_out);
 
+/* Development / test hook: the projection of the NEXT sfm_loss_* call of the calling thread (whatever becomes of that call), then
+ * back to 0.  0 = the product (geometry built in the wave, fused roundings: DESIGN.md 3); 1 = the same per-pixel chain on the
+ * geometry of the reference's own products and divisions (euler2mat, K4 . T, batch_inv: models/transform.py:11-91,105);
+ * 2 = the reference's evaluation order per pixel as well (transform.py:105-108,122-131 and the sampler's position, :189).
+ * 1 and 2 exist for sfm_loss_fwd_bwd with SSIM and smoothness in SFM_LAYOUT_HWC (the benchmarked launches); ignored elsewhere. */
+int sfm_loss_variant(int variant);
 /* Diagnostics: the NEXT sfm_loss_* call of this thread makes every wavefront of its main kernel
  * write {start, end (100 MHz realtime counter), HW_ID, XCC_ID} as 4 x uint64 per work item into
  * buf (device memory, 32 bytes * number of items; items <= workspace_bytes / 64). NULL disables. */
@@ -196,7 +204,8 @@ int sfm_pyramid_fwd(const float *x, float *const *y, int N, int C, int H, int W,
 int sfm_pyramid_hwc_fwd(const float *x, float *const *y, int N, int G, int H, int W, int n_scales, void *stream);
 /* Development / test hook: which kernel the NEXT sfm_pyramid_hwc_fwd / sfm_pyramid_pair_hwc_fwd call of the calling thread runs,
  * then back to automatic.  0 = automatic (the band kernel that reads every input pixel once, where the shape allows),
- * 1 = the one-thread-per-output-pixel kernel.  Same values bit for bit. */
+ * 1 = the one-thread-per-output-pixel kernel.  Same values bit for bit.  The hook is consumed by that next call whatever becomes
+ * of it (empty batch, rejected argument); sfm_pyramid_fwd (planar) does not take it. */
 int sfm_pyramid_variant(int variant);
 /* Both pyramids of a step in ONE launch: tgt (N,3,H,W) and src (N,3*n_src,H,W) (base_model.py:50-57) ->
  * y_tgt[s] (N,1,h,w,3), y_src[s] (N,n_src,h,w,3), s = 0..n_scales-1: the whole loop head :69-72. */

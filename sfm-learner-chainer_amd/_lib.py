@@ -67,6 +67,7 @@ SYMBOLS = {
     "sfm_loss_plan_info": (_I, [C.POINTER(SfmLossDesc), _I, _I, C.POINTER(C.c_int), _I]),
     "sfm_loss_profile_events": (_I, [_V, _V]),
     "sfm_loss_debug_trace": (_I, [_V]),
+    "sfm_loss_variant": (_I, [_I]),
     "sfm_resize_fwd": (_I, [_FP, _FP, _I, _I, _I, _I, _I, _I, _V]),
     "sfm_disp_act_fwd": (_I, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_longlong), _I, _V]),
     "sfm_disp_act_bwd": (_I, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_longlong), _I, _V]),

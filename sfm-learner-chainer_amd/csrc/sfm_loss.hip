@@ -262,9 +262,12 @@ __device__ __forceinline__ void set_issue_prio(const int p) {   // s_setprio tak
 // gets through its instructions, not by how many waves a SIMD holds: cfg2's kernel 14.3 -> 13.4 us.  At B = 32 the same build is
 // 8.7 % slower than the four-wave one (profiles/r03_ab_small_kernels.txt), so the plan picks per launch (Plan::wide).
 // WARPED: the instantiations that also write the warped source images (SfmLossDesc.warped; LOSS kernels only).
-template <bool SSIM, bool GRAD, bool LOSS, bool EXPL, int SMODE, bool HWC, bool WARPED>
+// REF: the projection of the source passes in the reference's own evaluation order (sfm_ssim_pass.h, issue_row) -- an experiment of
+// round 5 behind sfm_loss_variant, built for the pixel-interleaved SSIM kernels of sfm_loss_fwd_bwd only.
+template <bool SSIM, bool GRAD, bool LOSS, bool EXPL, int SMODE, bool HWC, bool WARPED, int REF = 0>
 __device__ __forceinline__ void loss_body(const LossArgs& A) {
   static_assert(LOSS || !WARPED, "the warped images are an output of the forward and the fused entry points");
+  static_assert(REF == 0 || (SSIM && GRAD && LOSS && HWC && !EXPL), "the reference-order variants exist for the benchmarked kernels only");
   using HH = Halo<SSIM, GRAD, SMODE>;
   __shared__ float gacc_all[GRAD ? WAVES_PER_BLOCK * MAX_CHUNK_ROWS * 64 : 64];
   const int wave = threadIdx.x >> 6;
@@ -411,7 +414,25 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
     SsimCtx C;
     const float xf = (float)x;
     C.x0 = x - lane;
-    {
+    if constexpr (REF != 0) {
+      // the geometry of this pass from make_geom: the reference's products and divisions, nothing fused (every lane builds it:
+      // ~560 instructions per pass -- this is the variant that is measured, not the product)
+      const float* pp = nullptr;
+#pragma unroll
+      for (int k = 0; k < SFM_MAX_SRC; ++k) pp = (i == k) ? A.pose[k] : pp;
+      Geom g;
+      make_geom(pp + b * 6, A.intrinsics + (size_t)(b * A.n_scales + s) * 9, g);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        C.M1[k] = uniform(g.M[k * 3 + 1]);
+        C.P3[k] = uniform(g.P[k * 4 + 3]);
+        C.mx[k] = uniform(g.M[k * 3 + 0]) * xf + uniform(g.M[k * 3 + 2]);
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) C.Kinv[k] = uniform(g.Kinv[k]);
+#pragma unroll
+      for (int k = 0; k < 12; ++k) C.Pm[k] = uniform(g.P[k]);
+    } else {
       // the twelve numbers of this pass out of the wave's geometry rows (lane 8 i + k: row k of source i)
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
@@ -455,7 +476,7 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
     C.lane = lane;
     float* gpm_out = GRAD ? A.part_gpm + ((size_t)item * A.n_src + i) * 12 : nullptr;
     if constexpr (SSIM) {
-      ssim_source_pass<GRAD, LOSS, HWC, WARPED>(C, gacc, first, acc_pix, acc_ssim, gpm_out SFM_STAMPS_PASS);
+      ssim_source_pass<GRAD, LOSS, HWC, WARPED, REF>(C, gacc, first, acc_pix, acc_ssim, gpm_out SFM_STAMPS_PASS);
     } else {
       l1_source_pass<GRAD, LOSS, EXPL, HWC, WARPED>(C, gacc, first, acc_pix, acc_exp, gpm_out);
     }
@@ -504,6 +525,11 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
 template <bool SSIM, bool GRAD, bool LOSS, bool EXPL, int SMODE, bool HWC, bool WARPED = false>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) loss_kernel(const LossArgs A) {
   loss_body<SSIM, GRAD, LOSS, EXPL, SMODE, HWC, WARPED>(A);
+}
+// (REF, see loss_body: the fused SSIM kernels in the pixel-interleaved layout, in the reference's evaluation order)
+template <int SMODE, bool WARPED, int REF>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 3) loss_kernel_ref(const LossArgs A) {
+  loss_body<true, true, true, false, SMODE, true, WARPED, REF>(A);
 }
 // (WIDE, see above: L1 gradient kernels only)
 template <bool LOSS, int SMODE, bool HWC, bool WARPED = false>
@@ -733,6 +759,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // main kernel of the NEXT fused-loss call of this thread
 static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 static thread_local unsigned long long* g_trace = nullptr;   // sfm_loss_debug_trace
+static thread_local int g_variant = 0;                       // sfm_loss_variant: holds for the next sfm_loss_* call only
 
 // ---- work decomposition -----------------------------------------------------------------
 // One wavefront per (scale, sample, strip, chunk of rows).  A wave lives for the whole launch, so the chunk
@@ -1038,7 +1065,7 @@ static const void* kernel_ptr(bool ssim, bool expl, int smode, bool hwc, bool wi
 }
 
 template <bool GRAD, bool LOSS>
-static hipError_t launch_main(const Plan& p, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+static hipError_t launch_main(const Plan& p, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, const int variant) {
   LossArgs args = p.args;
   void* kargs[] = {&args};
   // 8 x (items of the busiest XCD): see the item mapping at the top of loss_kernel
@@ -1046,6 +1073,16 @@ static hipError_t launch_main(const Plan& p, hipStream_t st, hipEvent_t ev_start
   for (int s = 0; s < p.args.n_scales; ++s) tiles_per_sample += p.args.sc[s].tiles;
   const int per_xcd = p.args.B >= 8 ? (p.args.B / 8) * tiles_per_sample + ((p.args.B % 8) * tiles_per_sample + 7) / 8 : (p.args.items + 7) / 8;
   const void* fn = kernel_ptr<GRAD, LOSS>(p.ssim, p.expl, p.smode, p.hwc, p.wide, p.warped);
+  if constexpr (GRAD && LOSS) {   // the reference-order variants (sfm_loss_variant): fused SSIM launch, pixel-interleaved, with smoothness
+    if ((variant == 1 || variant == 2) && p.ssim && !p.expl && p.hwc && p.smode != 0) {
+      const int key = (p.smode == 2 ? 4 : 0) | (p.warped ? 2 : 0) | (variant == 2 ? 1 : 0);
+      const void* tab[8] = {(const void*)&loss_kernel_ref<1, false, 1>, (const void*)&loss_kernel_ref<1, false, 2>,
+                            (const void*)&loss_kernel_ref<1, true, 1>,  (const void*)&loss_kernel_ref<1, true, 2>,
+                            (const void*)&loss_kernel_ref<2, false, 1>, (const void*)&loss_kernel_ref<2, false, 2>,
+                            (const void*)&loss_kernel_ref<2, true, 1>,  (const void*)&loss_kernel_ref<2, true, 2>};
+      fn = tab[key];
+    }
+  }
   // With profiling events the kernel is launched through hipExtLaunchKernel: the events then carry the begin / end
   // timestamps of THIS dispatch (what rocprofv3's kernel trace reports), and no marker packets are put between the
   // launches of a step (hipEventRecord on either side of the kernel costs the step several microseconds).
@@ -1086,6 +1123,13 @@ static int cached_plan(const SfmLossDesc* d, bool grad, bool loss, float gy, Pla
 static int run(const SfmLossDesc* d, bool grad, bool loss, float gy, float* loss5, void* ws, size_t ws_bytes, void* stream,
                const char* who) {
   hipStream_t st = (hipStream_t)stream;
+  // the one-call hooks are taken -- and forgotten -- here, whatever becomes of the call
+  const int variant = g_variant;
+  g_variant = 0;
+  unsigned long long* const trace = g_trace;
+  g_trace = nullptr;
+  hipEvent_t ev_start = g_ev_start, ev_stop = g_ev_stop;
+  g_ev_start = g_ev_stop = nullptr;
   if (d && d->B == 0) {   // empty shard: nothing to launch (input pointers of empty arrays may be NULL)
     if (loss) {
       if (!loss5) return fail(SFM_ERR_NULL, "%s: loss5 is NULL", who);
@@ -1101,14 +1145,11 @@ static int run(const SfmLossDesc* d, bool grad, bool loss, float gy, float* loss
   if (!ws || ws_bytes < p.total) return fail(SFM_ERR_WORKSPACE, "%s: workspace of %zu bytes needed, got %zu", who, p.total, ws_bytes);
   if (((uintptr_t)ws & 255) != 0) return fail(SFM_ERR_WORKSPACE, "%s: workspace must be 256-byte aligned", who);
   bind_workspace(p, ws);
-  p.args.trace = g_trace;
-  g_trace = nullptr;
-  hipEvent_t ev_start = g_ev_start, ev_stop = g_ev_stop;
-  g_ev_start = g_ev_stop = nullptr;
+  p.args.trace = trace;
   hipError_t le;
-  if (grad && loss) le = launch_main<true, true>(p, st, ev_start, ev_stop);
-  else if (grad) le = launch_main<true, false>(p, st, ev_start, ev_stop);
-  else le = launch_main<false, true>(p, st, ev_start, ev_stop);
+  if (grad && loss) le = launch_main<true, true>(p, st, ev_start, ev_stop, variant);
+  else if (grad) le = launch_main<true, false>(p, st, ev_start, ev_stop, variant);
+  else le = launch_main<false, true>(p, st, ev_start, ev_stop, variant);
   if (le != hipSuccess) return fail((int)le, "%s: launch of the main kernel: %s", who, hipGetErrorString(le));
   const int n_pose_blocks = grad ? d->B * d->n_src : 0;
   hipLaunchKernelGGL(finalize_kernel, dim3(n_pose_blocks + 1), dim3(64 * FINALIZE_WAVES), 0, st, p.args, loss ? loss5 : (float*)nullptr, n_pose_blocks);
@@ -1141,6 +1182,12 @@ int sfm_loss_plan_info(const SfmLossDesc* desc, int grad, int loss, int* out, in
     int* o = out + 1 + 4 * s;
     o[0] = S.strips; o[1] = S.chunks; o[2] = S.chunk_rows; o[3] = S.tiles;
   }
+  return SFM_OK;
+}
+
+int sfm_loss_variant(int variant) {
+  if (variant < 0 || variant > 2) return sfm::fail(SFM_ERR_CONFIG, "sfm_loss_variant: %d not in [0, 2]", variant);
+  sfm::g_variant = variant;
   return SFM_OK;
 }
 

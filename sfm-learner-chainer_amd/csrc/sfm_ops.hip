@@ -811,11 +811,17 @@ static const PyramidTuning& pyramid_tuning() { static const PyramidTuning t; ret
 static thread_local int g_pyramid_variant = 0;
 
 // Launches the band kernel when its preconditions hold (returns false otherwise: the caller uses the per-pixel kernel).
-template <bool PAIR>
-static bool launch_pyramid_band(const PyramidArgs& A, int images, hipStream_t st) {
-  const int H = A.H, W = A.W;
-  const int variant = g_pyramid_variant;
+// the hook is taken -- and forgotten -- at the TOP of the entry point it applies to, whatever becomes of the call (an empty batch, a
+// rejected argument): left armed it would pick the kernel of some later, unrelated call of the thread (round-4 advisor finding)
+static int take_pyramid_variant() {
+  const int v = g_pyramid_variant;
   g_pyramid_variant = 0;
+  return v;
+}
+
+template <bool PAIR>
+static bool launch_pyramid_band(const PyramidArgs& A, int images, hipStream_t st, const int variant) {
+  const int H = A.H, W = A.W;
   if (variant == 1) return false;                                          // the per-pixel kernel was asked for
   if (H < 2 || W < 4 || (W & 3)) return false;
   uintptr_t al = (uintptr_t)A.x | (uintptr_t)A.y[0];
@@ -1079,6 +1085,7 @@ int sfm_pyramid_fwd(const float* x, float* const* y, int N, int C, int H, int W,
 }
 
 int sfm_pyramid_hwc_fwd(const float* x, float* const* y, int N, int G, int H, int W, int n_scales, void* stream) {
+  const int variant = sfm::take_pyramid_variant();
   if (N == 0) return SFM_OK;   // empty batch: nothing to do, pointers may be NULL
   SFM_REQUIRE(x && y, SFM_ERR_NULL, "sfm_pyramid_hwc_fwd: NULL pointer");
   SFM_REQUIRE(n_scales >= 1 && n_scales <= SFM_MAX_SCALES, SFM_ERR_SHAPE, "sfm_pyramid_hwc_fwd: n_scales=%d", n_scales);
@@ -1099,13 +1106,14 @@ int sfm_pyramid_hwc_fwd(const float* x, float* const* y, int N, int G, int H, in
   A.quads0 = A.begin[1];
   pyramid_steps(A);
   const int total = A.begin[n_scales];
-  if (!launch_pyramid_band<false>(A, N * G, (hipStream_t)stream))
+  if (!launch_pyramid_band<false>(A, N * G, (hipStream_t)stream, variant))
     hipLaunchKernelGGL(pyramid_hwc_fwd_kernel<false>, dim3((total + 255) / 256, N * G), dim3(256), 0, (hipStream_t)stream, A);
   return check_launch("sfm_pyramid_hwc_fwd");
 }
 
 int sfm_pyramid_pair_hwc_fwd(const float* tgt, const float* src, float* const* y_tgt, float* const* y_src, int N, int n_src, int H,
                              int W, int n_scales, void* stream) {
+  const int variant = sfm::take_pyramid_variant();
   if (N == 0) return SFM_OK;   // empty batch: nothing to do, pointers may be NULL
   SFM_REQUIRE(tgt && src && y_tgt && y_src, SFM_ERR_NULL, "sfm_pyramid_pair_hwc_fwd: NULL pointer");
   SFM_REQUIRE(n_scales >= 1 && n_scales <= SFM_MAX_SCALES, SFM_ERR_SHAPE, "sfm_pyramid_pair_hwc_fwd: n_scales=%d", n_scales);
@@ -1128,7 +1136,7 @@ int sfm_pyramid_pair_hwc_fwd(const float* tgt, const float* src, float* const* y
   A.quads0 = A.begin[1];
   pyramid_steps(A);
   const int total = A.begin[n_scales];
-  if (!launch_pyramid_band<true>(A, N * (1 + n_src), (hipStream_t)stream))
+  if (!launch_pyramid_band<true>(A, N * (1 + n_src), (hipStream_t)stream, variant))
     hipLaunchKernelGGL(pyramid_hwc_fwd_kernel<true>, dim3((total + 255) / 256, N * (1 + n_src)), dim3(256), 0, (hipStream_t)stream, A);
   return check_launch("sfm_pyramid_pair_hwc_fwd");
 }

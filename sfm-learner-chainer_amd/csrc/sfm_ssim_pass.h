@@ -36,6 +36,7 @@ __device__ Stamps g_dummy_stamps;
 struct SsimCtx {
   // uniform (SGPR)
   float M1[3], P3[3];
+  float Kinv[9], Pm[12];   // REF == 2 only (the reference's own evaluation order, see issue_row): batch_inv(K) and rows 0..2 of K4 . T
   int x0;               // column of lane 0 (uniform); the lane's column is x0 + lane
   float k_pix;   // dL/d(sum |e|)        = gy (1-alpha) / (norm_B 3 h w)   base_model.py:111,117
   float kq;      // -dL/d(sum ssim)      = -gy alpha / (norm_B 3 h w): 2 kappa of App. A.3   base_model.py:115,117,142
@@ -330,7 +331,14 @@ struct __attribute__((packed, aligned(4))) Rgb2 {   // two horizontally adjacent
 
 // HWC: the images are pixel-interleaved (SFM_LAYOUT_HWC): C.tp[0] / C.sp[0] are the (h,w,3) images of this sample /
 // (sample, source), and the three channels of a tap come with one load.
-template <bool HWC>
+// REF (experiment of round 5, SSIM gradient kernels in the pixel-interleaved layout only; picked by sfm_loss_variant):
+//   0  the product: q = D (M . pix) + P3 with M, P3 from the in-wave geometry, quotients from v_rcp + one residual correction,
+//      the in-view test on U, V directly
+//   1  the same per-pixel chain on the geometry of make_geom (exact euler2mat products, IEEE divisions, nothing fused)
+//   2  the reference's evaluation order per pixel as well (the stand-alone warp operator's ref_project, sfm_ops.hip):
+//      ray = K^-1 . pix, c = D ray, q = Pm . (c, 1), U = q0 / z (IEEE), xn = U / ((W-1)/2.) - 1, the strict test on xn, and the
+//      sampler's own position (xn + 1) (W-1) / 2 (transform.py:105-108,122-131,189) -- nothing fused
+template <bool HWC, int REF = 0>
 __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const float disp, Pipe& ps) {
   const float yf = (float)r;
   // depth = 1 / disp (base_model.py:60) from v_rcp_f32 alone (1 ulp): the quotients U = q0/z, V = q1/z below keep their residual
@@ -338,9 +346,35 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
   // 1e-7 of its parallax
   ps.D = rcp(disp);
   Proj p;
-  f2 UV, fr;
+  f2 UV, fr, cell;
   float rz;
-  if constexpr (HWC) {
+  if constexpr (HWC && REF == 2) {
+#pragma clang fp contract(off)
+    const float Dr = 1.0f / disp;                                     // base_model.py:60, IEEE division
+    ps.D = Dr;
+    const float xf = (float)(C.x0 + C.lane);
+    float ray[3], c[3], q[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      ray[j] = (C.Kinv[j * 3 + 0] * xf + C.Kinv[j * 3 + 1] * yf) + C.Kinv[j * 3 + 2];
+      c[j] = Dr * ray[j];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) q[k] = ((C.Pm[k * 4 + 0] * c[0] + C.Pm[k * 4 + 1] * c[1]) + C.Pm[k * 4 + 2] * c[2]) + C.Pm[k * 4 + 3];
+    const float z = q[2] + 1e-10f;
+    const float U = q[0] / z, V = q[1] / z;
+    const float half_w = (float)((double)C.sc.wm1 / 2.0), half_h = (float)((double)C.sc.hm1 / 2.0);
+    const float xn = U / half_w - 1.0f, yn = V / half_h - 1.0f;
+    p.inview = (xn > -1.0f) & (xn < 1.0f) & (yn > -1.0f) & (yn < 1.0f);
+    // the sampler's position on the zero-padded image (pad_taps, sfm_ops.hip): up in (1, W) for an in-view sample
+    const float up = (xn + 1.0f) * C.sc.wm1 * 0.5f + 1.0f, vp = (yn + 1.0f) * C.sc.hm1 * 0.5f + 1.0f;
+    const float fu = floorf(up), fv = floorf(vp);
+    fr.x = up - fu; fr.y = vp - fv;
+    cell.x = p.inview ? fu - 1.0f : 0.f; cell.y = p.inview ? fv - 1.0f : 0.f;   // the top-left tap, unpadded
+    UV.x = U; UV.y = V;                                               // (the backward's dL/dq2 = -(gU U + gV V) / z takes the quotients)
+    rz = 1.0f / z;
+    p.u0 = p.v0 = 0;
+  } else if constexpr (HWC) {
     // The projection of sfm_common.h's project(), with the x and y components of every step in ONE packed instruction (the same
     // IEEE operations per component: bit-identical values, two thirds of the instructions):
     //   a = M (x,y,1) ; q = D a + P[:,3] ; z = q2 + 1e-10 ; (U,V) = (q0,q1) / z ; in view iff U (W-1-U) > 0 and V (H-1-V) > 0
@@ -357,12 +391,14 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
     const f2 sg = UV * (whm1 - UV);
     p.inview = (sg.x > 0.0f) & (sg.y > 0.0f);
     fr.x = __builtin_amdgcn_fractf(UV.x); fr.y = __builtin_amdgcn_fractf(UV.y);
-    p.u0 = p.v0 = 0;   // (the pixel-interleaved gather forms its offset from UV - fr)
+    cell = UV - fr;
+    p.u0 = p.v0 = 0;   // (the pixel-interleaved gather forms its offset from the cell = UV - fr)
   } else {
     // (the planar gather needs the integer cell as well, and measured 4 % slower with the packed chain in front of it)
     const float a0 = fmaf(C.M1[0], yf, C.mx[0]), a1 = fmaf(C.M1[1], yf, C.mx[1]), a2 = fmaf(C.M1[2], yf, C.mx[2]);
     p = project(a0, a1, a2, C.P3[0], C.P3[1], C.P3[2], ps.D, C.sc, C.h, C.w);
     UV.x = p.U; UV.y = p.V; fr.x = p.fu; fr.y = p.fv; rz = p.rz;
+    cell = UV;   // (unused: the planar gather takes the integer cell of project())
   }
   ps.UV = UV; ps.f = fr;
   if constexpr (HWC) {
@@ -382,7 +418,6 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
     // instead of two conversions, two selects and a 64-bit multiply-add.  The two horizontally adjacent taps of a row are ONE
     // 24-byte access (dwordx4 + dwordx2: four separate 12-byte loads cost the gather path 40 % more time per step at 256x832), the
     // row below is the same address + 12 w.
-    const f2 cell = UV - fr;
     const float bof = fmaf(cell.y, C.w12f, cell.x * 12.f);
     // Range-checked buffer loads (MUBUF, raw descriptor): a lane whose offset is not below num_records gets ZEROS.
     //  * source taps: num_records = the image; a lane that is not in view is given an offset outside it, so all its taps are 0 and
@@ -696,7 +731,7 @@ __device__ __forceinline__ unsigned step_range(int lo, int hi) {   // bits lo ..
 }
 __device__ __forceinline__ bool step_bit(const unsigned m, const int k) { return ((m >> k) & 1u) != 0u; }
 
-template <bool GRAD, bool LOSS, bool HWC, bool WARPED>
+template <bool GRAD, bool LOSS, bool HWC, bool WARPED, int REF>
 __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const StepMasks& M, const int k, const int r, Pipe& ps, float& disp_next,
                                               RowS& s0, const RowS& s1, const RowS& s2,
                                               RowG& g0, const RowG& g1, const RowG& g2, float* gacc, const bool first,
@@ -714,7 +749,7 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const StepMasks&
   if constexpr (WARPED) store_warped_row(C, r, s0);
   SFM_STAMP(t1);
   if (step_bit(M.iss, k)) {
-    issue_row<HWC>(C, r + 1, disp_next, ps);
+    issue_row<HWC, REF>(C, r + 1, disp_next, ps);
     // the disparity of the row after that; on the last fetched row of the pass the prefetch reads the image's last row again
     disp_next = ldf(C.dp, (unsigned)min(r + 2, C.h - 1) * (unsigned)w + C.xc);
   }
@@ -742,7 +777,7 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const StepMasks&
 }
 
 // One source of one wave.  HS = halo of this pass (2 with gradients, 1 forward only).
-template <bool GRAD, bool LOSS, bool HWC, bool WARPED>
+template <bool GRAD, bool LOSS, bool HWC, bool WARPED, int REF = 0>
 __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, const bool first, float& acc_pix, float& acc_ssim,
                                                  float* gpm_out /* 12 floats in global memory, or nullptr */ SFM_STAMPS_ARG) {
   constexpr int HS = GRAD ? 2 : 1;
@@ -768,15 +803,15 @@ __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, 
   // the chunk at the top of the image: the steps before it fetch nothing and leave disp_next alone)
   // (the two disparities a pass starts from are the same for every source: the wave loaded them once, at its start, so that no
   // pass waits for a disparity before it can even form the addresses of its first gathers)
-  if (rbeg >= 0 && rbeg < C.h) issue_row<HWC>(C, rbeg, C.disp_first, ps);
+  if (rbeg >= 0 && rbeg < C.h) issue_row<HWC, REF>(C, rbeg, C.disp_first, ps);
   disp_next = C.disp_second;
   for (int k = 0; k < n; k += 3) {
     const int r = rbeg + k;
-    ssim_row_step<GRAD, LOSS, HWC, WARPED>(C, M, k, r, ps, disp_next, S0, S2, S1, G0, G2, G1, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
+    ssim_row_step<GRAD, LOSS, HWC, WARPED, REF>(C, M, k, r, ps, disp_next, S0, S2, S1, G0, G2, G1, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
     if (k + 1 < n)
-      ssim_row_step<GRAD, LOSS, HWC, WARPED>(C, M, k + 1, r + 1, ps, disp_next, S1, S0, S2, G1, G0, G2, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
+      ssim_row_step<GRAD, LOSS, HWC, WARPED, REF>(C, M, k + 1, r + 1, ps, disp_next, S1, S0, S2, G1, G0, G2, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
     if (k + 2 < n)
-      ssim_row_step<GRAD, LOSS, HWC, WARPED>(C, M, k + 2, r + 2, ps, disp_next, S2, S1, S0, G2, G1, G0, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
+      ssim_row_step<GRAD, LOSS, HWC, WARPED, REF>(C, M, k + 2, r + 2, ps, disp_next, S2, S1, S0, G2, G1, G0, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
   }
   if (GRAD) pose_sums_raw(C, gpm, gpm_out);
 }

@@ -412,10 +412,14 @@ class FusedLoss:
         self._launch(lib.sfm_loss_bwd, float(gy))
         return self.d_disps, self.d_poses, self.d_masks, self.d_srcs
 
-    def forward_backward(self, out=None):
+    def forward_backward(self, out=None, variant=0):
         """`out`: optional (5,) float32 device tensor to receive the five scalars instead of `self.loss5`
-        (lets a caller keep a log of the steps of a reporting interval and reduce it across ranks once)."""
+        (lets a caller keep a log of the steps of a reporting interval and reduce it across ranks once).
+        `variant`: development hook (sfm_loss_variant): 1 = the projection on the reference's own geometry products, 2 = in the
+        reference's evaluation order per pixel as well; only the SSIM + smoothness launches in the hwc layout have them."""
         self._zero_d_src()
         loss5 = self.loss5 if out is None else out
+        if variant:
+            check(lib.sfm_loss_variant(int(variant)))
         self._launch(lib.sfm_loss_fwd_bwd, self._loss5_arg if out is None else _p(out))
         return loss5

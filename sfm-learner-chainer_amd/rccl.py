@@ -35,12 +35,28 @@ class RcclError(RuntimeError):
 
 
 def _loaded_librccl():
-    """Path of the librccl.so this process has mapped (torch links against its own copy), or None."""
+    """Path of the librccl.so this process has mapped, or None.  Of several mapped copies (torch's own and, pulled in by another
+    extension, /opt/rocm's) the one in torch's lib directory is taken: it is the one that shares torch's HIP runtime; a torch
+    build that links the system RCCL has only that one mapped, and it is taken then."""
+    import os
+    torch_lib = os.path.join(os.path.dirname(os.path.abspath(torch.__file__)), "lib")
+    found = []
     with open("/proc/self/maps") as f:
         for line in f:
-            if "librccl.so" in line:
-                return line.split()[-1]
-    return None
+            if "librccl.so" not in line:
+                continue
+            fields = line.rstrip("\n").split(None, 5)       # address perms offset dev inode PATH (the path may contain spaces)
+            if len(fields) < 6:
+                continue
+            path = fields[5]
+            if path.endswith(" (deleted)"):
+                continue
+            if path not in found:
+                found.append(path)
+    for path in found:
+        if os.path.dirname(os.path.abspath(path)) == torch_lib:
+            return path
+    return found[0] if found else None
 
 
 _lib = None
@@ -60,6 +76,7 @@ def lib():
         L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
         L.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.ncclCommDestroy.argtypes = [C.c_void_p]
+        L.ncclCommAbort.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -80,23 +97,10 @@ def _broadcast_bytes(payload, device):
 
 
 class Communicator:
-    """One RCCL communicator per process (= per GPU).  `rank`, `world` as torch.distributed reports them; the unique id is
-    made on rank 0 and handed round by `broadcast` (default: a torch.distributed broadcast on the existing process group)."""
+    """One RCCL communicator per process (= per GPU), made by `connect` (below): never construct it on one rank alone."""
 
-    def __init__(self, rank, world, device, broadcast=None):
-        L = lib()
-        self.rank, self.world, self.device = rank, world, device
-        uid = _UniqueId()
-        if rank == 0:
-            _check(L.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
-        if world > 1:
-            raw = (broadcast or (lambda b: _broadcast_bytes(b, device)))(_id_bytes(uid) if rank == 0 else bytes(NCCL_UNIQUE_ID_BYTES))
-            if len(raw) != NCCL_UNIQUE_ID_BYTES:
-                raise RcclError("the unique id arrived with %d bytes instead of %d" % (len(raw), NCCL_UNIQUE_ID_BYTES))
-            C.memmove(C.byref(uid), raw, NCCL_UNIQUE_ID_BYTES)
-        self._comm = C.c_void_p()
-        with torch.cuda.device(device):
-            _check(L.ncclCommInitRank(C.byref(self._comm), world, uid, rank), "ncclCommInitRank")
+    def __init__(self, L, comm, rank, world, device):
+        self._L, self._comm, self.rank, self.world, self.device = L, comm, rank, world, device
 
     def all_reduce_sum_f32(self, tensor, stream=None):
         """In place, asynchronous, in stream order on `stream` (default: torch's current stream of the tensor's device)."""
@@ -104,10 +108,85 @@ class Communicator:
             raise TypeError("all_reduce_sum_f32: a contiguous float32 device tensor is required")
         st = stream if stream is not None else torch.cuda.current_stream(tensor.device).cuda_stream
         p = C.c_void_p(tensor.data_ptr())
-        _check(lib().ncclAllReduce(p, p, tensor.numel(), NCCL_FLOAT32, NCCL_SUM, self._comm, C.c_void_p(st)), "ncclAllReduce")
+        _check(self._L.ncclAllReduce(p, p, tensor.numel(), NCCL_FLOAT32, NCCL_SUM, self._comm, C.c_void_p(st)), "ncclAllReduce")
         return tensor
 
-    def destroy(self):
+    def destroy(self, abort=False):
+        """`abort`: ncclCommAbort instead of ncclCommDestroy (a communicator whose peers will never use it: nothing to wait for)."""
         if self._comm:
-            lib().ncclCommDestroy(self._comm)
+            (self._L.ncclCommAbort if abort else self._L.ncclCommDestroy)(self._comm)
             self._comm = C.c_void_p()
+
+
+def _agree(ok, device):
+    """MIN over the ranks of a 0 / 1 flag, on the process group that is already up: 1 only if every rank says 1."""
+    import torch.distributed as dist
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    if dist.get_backend() == "nccl":
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item()) == 1
+
+
+def connect(rank, world, device, init_timeout_s=None, library=None):
+    """The direct RCCL communicator of this rank, or None on EVERY rank -- agreed, so that no rank is ever left inside a
+    collective the others never enter (round-4 advisor finding: a rank that failed early went straight to the agreement while the
+    others sat in the broadcast of the id or in ncclCommInitRank).  Returns (Communicator | None, note).
+
+    Every rank runs the SAME sequence of collectives on the existing torch.distributed process group, whatever fails locally:
+      1. local steps only: bind the library; rank 0 makes the unique id;
+      2. agreement (all-reduce MIN of a success flag).  A failure anywhere ends here, on every rank, with no other collective issued;
+      3. the id's 128 bytes are broadcast;
+      4. ncclCommInitRank -- itself a collective over RCCL's bootstrap network -- under a DEADLINE (`init_timeout_s`, default
+         SFM_RCCL_INIT_TIMEOUT or 120 s): it runs on a helper thread; a rank whose call has not returned in time gives up on it (the
+         thread is left behind: a blocked bootstrap cannot be cancelled) and votes 0;
+      5. agreement.  If any rank votes 0, the ranks that DID get a communicator abort it, and every rank returns None.
+    `library`: the bound librccl (tests inject a stand-in); default `lib()`."""
+    import os
+    import threading
+    if init_timeout_s is None:
+        init_timeout_s = float(os.environ.get("SFM_RCCL_INIT_TIMEOUT", "120"))
+    note, L = None, None
+    uid = _UniqueId()
+    try:                                                            # 1. local
+        L = library() if callable(library) else (library if library is not None else lib())
+        if rank == 0:
+            _check(L.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+    except Exception as e:       # noqa: BLE001
+        note, L = "%s: %s" % (type(e).__name__, e), None
+    if world > 1 and not _agree(L is not None, device):             # 2. agreement
+        return None, note or "another rank could not bind RCCL or make the unique id"
+    if world == 1 and L is None:
+        return None, note
+    if world > 1:                                                   # 3. the id
+        raw = _broadcast_bytes(_id_bytes(uid) if rank == 0 else bytes(NCCL_UNIQUE_ID_BYTES), device)
+        C.memmove(C.byref(uid), raw[:NCCL_UNIQUE_ID_BYTES].ljust(NCCL_UNIQUE_ID_BYTES, b"\0"), NCCL_UNIQUE_ID_BYTES)
+    comm = C.c_void_p()
+    state = {}
+
+    def _init():
+        try:
+            if device is not None and getattr(device, "type", "cpu") == "cuda":
+                torch.cuda.set_device(device)                       # (the device of a thread is its own)
+            state["rc"] = L.ncclCommInitRank(C.byref(comm), world, uid, rank)
+        except Exception as e:   # noqa: BLE001
+            state["exc"] = e
+
+    th = threading.Thread(target=_init, name="ncclCommInitRank", daemon=True)   # 4. under a deadline
+    th.start()
+    th.join(init_timeout_s)
+    if th.is_alive():
+        note = "ncclCommInitRank did not return within %.0f s" % init_timeout_s
+    elif "exc" in state:
+        note = "%s: %s" % (type(state["exc"]).__name__, state["exc"])
+    elif state.get("rc", -1) != 0:
+        try:
+            note = "ncclCommInitRank failed: %s (ncclResult_t %d)" % (L.ncclGetErrorString(state["rc"]).decode(), state["rc"])
+        except Exception:        # noqa: BLE001
+            note = "ncclCommInitRank failed (ncclResult_t %r)" % (state.get("rc"),)
+    mine = Communicator(L, comm, rank, world, device) if note is None else None
+    if world > 1 and not _agree(mine is not None, device):          # 5. agreement
+        if mine is not None:
+            mine.destroy(abort=True)
+        return None, note or "another rank could not make the communicator"
+    return mine, note

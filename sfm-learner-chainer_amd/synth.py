@@ -64,13 +64,28 @@ def _smooth_field(rng, B, C, H, W, div):
     return _resize_align_corners(low, H, W)
 
 
+def _shift_replicate(x, sx, sy):
+    """x shifted by (sx, sy) pixels like np.roll, but with the border pixels REPLICATED instead of wrapped around: no seam."""
+    H, W = x.shape[-2:]
+    xi = np.clip(np.arange(W) - sx, 0, W - 1)
+    yi = np.clip(np.arange(H) - sy, 0, H - 1)
+    return x[..., yi, :][..., xi]
+
+
 def make_inputs(B=2, H=128, W=416, n_src=2, n_scales=4, seed=1, with_masks=False,
-                rot_sigma=0.01, trans_sigma=0.02):
+                rot_sigma=0.01, trans_sigma=0.02, seam="roll"):
     """Returns a dict of float32 C-contiguous arrays:
 
     tgt (B,3,H,W); src (B,n_src,3,H,W); tgt_pyr[s] (B,3,h,w); src_pyr[s] (B,3n,h,w);
     intrinsics (B,S,3,3); disps[s] (B,1,h,w); poses[i] (B,6); masks[s] (B,n,h,w) | None
+
+    seam: how a source is made from the target pattern "shifted by a few px" (SURVEY.md 8(d)): "roll" wraps the pattern around
+    (np.roll: the sources carry a seam of full contrast a few pixels from two of their borders -- the inputs of rounds 1-4,
+    kept: a step edge is the hardest case for a bilinear sampler's position accuracy); "shift" replicates the border instead
+    (no seam: image-like texture everywhere).  Same random draws in both, so everything else is identical.
     """
+    if seam not in ("roll", "shift"):
+        raise ValueError("seam must be 'roll' or 'shift', got %r" % (seam,))
     rng = np.random.RandomState(seed)
     tex = 1.4 * _smooth_field(rng, B, 3, H, W, 8) + 0.2 * _smooth_field(rng, B, 3, H, W, 2)
     tgt = np.clip(tex, -1, 1).astype(np.float32)
@@ -78,7 +93,7 @@ def make_inputs(B=2, H=128, W=416, n_src=2, n_scales=4, seed=1, with_masks=False
     for i in range(n_src):
         sx = int(rng.randint(-4, 5))
         sy = int(rng.randint(-2, 3))
-        shifted = np.roll(np.roll(tex, sx, axis=3), sy, axis=2)
+        shifted = np.roll(np.roll(tex, sx, axis=3), sy, axis=2) if seam == "roll" else _shift_replicate(tex, sx, sy)
         noise = 0.05 * rng.standard_normal(size=tex.shape).astype(np.float32)
         srcs.append(np.clip(shifted + noise, -1, 1).astype(np.float32))
     src = np.stack(srcs, axis=1)

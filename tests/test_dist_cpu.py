@@ -76,3 +76,98 @@ def test_two_rank_batch_sharding_over_gloo(tmp_path):
         lo, hi = dmod.shard_range(5, r, world)
         np.testing.assert_allclose(o["d_disp0"], ref.d_disps[0][lo:hi], rtol=0, atol=1e-5 * np.abs(ref.d_disps[0]).max())
         np.testing.assert_allclose(o["d_pose0"], ref.d_poses[0][lo:hi], rtol=0, atol=1e-5 * np.abs(ref.d_poses[0]).max())
+
+
+# ------------------------------------------------------------------------------------------------
+# rccl.connect: the agreement protocol around the direct communicator, with one rank made to fail at each step
+# ------------------------------------------------------------------------------------------------
+class _FakeRccl:
+    """Stands in for the bound librccl on a host without GPUs: the four entry points rccl.connect uses, with a failure injected on
+    rank 1 according to `mode`."""
+
+    def __init__(self, rank, mode, log):
+        self.rank, self.mode, self.log = rank, mode, log
+
+    def ncclGetUniqueId(self, p_uid):
+        for k in range(128):
+            p_uid._obj.internal[k] = (7 * k + 3) % 256
+        return 0
+
+    def ncclCommInitRank(self, p_comm, world, uid, rank):
+        import time
+        got = bytes(uid.internal)
+        assert got == bytes((7 * k + 3) % 256 for k in range(128)), "the unique id did not arrive intact"
+        if self.rank == 1 and self.mode == "init_error":
+            return 5
+        if self.rank == 1 and self.mode == "init_hang":
+            time.sleep(20)
+        p_comm._obj.value = 0x1000 + self.rank
+        self.log.append("init")
+        return 0
+
+    def ncclGetErrorString(self, rc):
+        return b"invalid usage (injected)"
+
+    def ncclCommAbort(self, comm):
+        self.log.append("abort")
+        return 0
+
+    def ncclCommDestroy(self, comm):
+        self.log.append("destroy")
+        return 0
+
+
+def _connect_worker(rank, world, port, out_dir, mode):
+    import json
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    rccl = importlib.import_module("sfm-learner-chainer_amd.rccl")
+    bench = importlib.import_module("bench")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    log = []
+
+    def library():
+        if rank == 1 and mode == "local_fail":
+            raise rccl.RcclError("librccl.so is not mapped into this process (injected)")
+        return _FakeRccl(rank, mode, log)
+
+    comm, note = rccl.connect(rank, world, torch.device("cpu"), init_timeout_s=3.0, library=library)
+    # whatever happened, the process group is still in step: the next collective matches on every rank
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    line = bench.collective_line("step", comm is not None, False, note)
+    with open(os.path.join(out_dir, "rank%d.json" % rank), "w") as f:
+        json.dump(dict(has_comm=comm is not None, note=note, log=log, sum=float(t.item()), line=line), f)
+    if comm is not None:
+        comm.destroy()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("mode", ["ok", "local_fail", "init_error", "init_hang"])
+def test_direct_communicator_failure_on_one_rank_ends_in_an_agreed_fallback(tmp_path, mode):
+    """Round-4 advisor finding + verdict item 6(a): rank 1 fails to bind the library / gets an error from ncclCommInitRank / never
+    returns from it.  BOTH ranks must end without a direct communicator (the per-step collective then goes through
+    torch.distributed), rank 0 must have given up the communicator it did get, the line must say FALLBACK, and the process group
+    must still be in step.  With no failure both ranks get their communicator."""
+    import json
+    world = 2
+    mp.spawn(_connect_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)
+    outs = [json.load(open(os.path.join(str(tmp_path), "rank%d.json" % r))) for r in range(world)]
+    for o in outs:
+        assert o["sum"] == 3.0                                   # the collective after connect() matched on both ranks
+    if mode == "ok":
+        assert all(o["has_comm"] and o["note"] is None for o in outs)
+        assert all("FALLBACK" not in o["line"] for o in outs)
+        return
+    assert not any(o["has_comm"] for o in outs), outs
+    assert all(o["note"] for o in outs)
+    assert all("FALLBACK" in o["line"] for o in outs)
+    if mode == "local_fail":
+        assert outs[0]["log"] == [] and outs[1]["log"] == []        # nobody entered ncclCommInitRank: no rank was left waiting in it
+        assert "injected" in outs[1]["note"] and "another rank" in outs[0]["note"]
+    else:
+        assert outs[0]["log"] == ["init", "abort"]                  # rank 0 had its communicator and gave it up
+        assert "abort" not in outs[1]["log"]
+        assert ("did not return" in outs[1]["note"]) if mode == "init_hang" else ("ncclCommInitRank failed" in outs[1]["note"])

@@ -82,20 +82,27 @@ def knife_widths(d, ref, cell_floor=1e-4, abs_floor=3e-5):
                 abs_thr=lambda s: np.maximum(abs_floor, value_tolerance(d, ref, s)))
 
 
-def _check_warped(fl, ref, what, d):
+VACUOUS_ALLOWANCE = 1e-3      # a pixel whose position allowance exceeds this (of the range) is in effect not compared ...
+VACUOUS_SHARE_CAP = 1e-4      # ... at most 0.01 % of a scale's pixels may be (round-4 verdict: the allowance had no cap below the image range)
+
+
+def _check_warped(fl, ref, what, d, flat=False, flat_tol=WARP_TOL, max_over_flat=None):
     """The warped images the FUSED kernel computed its loss on (SfmLossDesc.warped, written by the kernel that is benchmarked)
     against the oracle's curr_proj_img (models/base_model.py:90-94), pixel for pixel:
       * the sets of exactly-zero (not in view, :96) pixels agree except at pixels the ORACLE places within FLIP_THR of the strict
         in-view test -- those that differ are counted and printed;
-      * everywhere else |I^ - I^_oracle| <= WARP_TOL of the image range + what the fp32 uncertainty of the sampling POSITION moves
-        the bilinear sample by at that pixel: (contrast between the cell's horizontally adjacent taps) x dU + (vertical) x dV,
-        with (dU, dV) the first-order rounding bound of oracle/parity.py (1 .. 2e-4 px at U = 400; unbounded where z -> 0).  On
-        image-like texture the second term is a few 1e-5; on a step edge of contrast 2 (the wrap-around seam of synth's rolled
-        sources) NO fp32 evaluation meets a flat 1e-4: the fp32 oracle itself is 2.4e-4 from the fp64 one there.  How many pixels
-        exceed the flat WARP_TOL, and by how much, is printed.
+      * flat=True (seam-free inputs, synth.make_inputs(seam="shift"); the reference-order variants on any input): everywhere else
+        |I^ - I^_oracle| <= flat_tol of the image range, no other term -- north_star's criterion as it is written;
+      * flat=False (the rolled inputs of rounds 1-4: a wrap-around seam of contrast 2.0 in the sources): WARP_TOL of the range + what
+        the fp32 uncertainty of the sampling POSITION moves the bilinear sample by at that pixel: (contrast between the cell's
+        horizontally adjacent taps) x dU + (vertical) x dV, with (dU, dV) the first-order rounding bound of oracle/parity.py
+        (1 .. 2e-4 px at U = 400; unbounded where z -> 0).  On a step edge of contrast 2 NO fp32 evaluation meets a flat 1e-4: the
+        fp32 oracle itself is 2.4e-4 from the fp64 one there.  Pixels whose allowance exceeds VACUOUS_ALLOWANCE are in effect not
+        compared: they are counted, printed and capped at VACUOUS_SHARE_CAP of a scale.
+    `max_over_flat`: cap on the number of pixels above the flat WARP_TOL (None: only printed).
     Returns the number of pixels zeroed differently."""
     assert fl.warped is not None
-    n_flip = n_over = 0
+    n_flip = n_over = n_vac = n_px = 0
     worst = worst_flat = 0.0
     for s, (g, w) in enumerate(zip(fl.warped, ref["warped"])):
         g = to_np(g)
@@ -110,16 +117,30 @@ def _check_warped(fl, ref, what, d):
         scale = max(float(np.abs(w).max()), 1.0)
         err = np.abs(g.astype(np.float64) - w).max(axis=2)
         err[mism] = 0.0
-        tol = WARP_TOL * scale + np.minimum(value_tolerance(d, ref, s), 2.0 * scale)
+        n_px += err.size
+        if flat:
+            tol = np.full(err.shape, flat_tol * scale)
+        else:
+            allow = np.minimum(value_tolerance(d, ref, s), 2.0 * scale)
+            vac = allow > VACUOUS_ALLOWANCE * scale
+            n_vac += int(vac.sum())
+            assert vac.mean() <= VACUOUS_SHARE_CAP, "%s scale %d: %d of %d pixels (%.4f %%) carry a position allowance above %g of the range: the comparison would be vacuous there" % (
+                what, s, int(vac.sum()), vac.size, 100 * vac.mean(), VACUOUS_ALLOWANCE)
+            tol = WARP_TOL * scale + allow
         bad = err > tol
-        assert not bad.any(), "%s scale %d: %d warped pixels off by more than %g + (tap contrast x position uncertainty); worst %.3g at tolerance %.3g" % (
-            what, s, int(bad.sum()), WARP_TOL, float(err[bad].max()), float(tol[bad][np.argmax(err[bad])]))
+        assert not bad.any(), "%s scale %d: %d warped pixels off by more than %s; worst %.3g at tolerance %.3g" % (
+            what, s, int(bad.sum()), "the flat %g of the range" % flat_tol if flat else "%g + (tap contrast x position uncertainty)" % WARP_TOL,
+            float(err[bad].max()), float(tol[bad][np.argmax(err[bad])]))
         n_over += int((err > WARP_TOL * scale).sum())
         worst_flat = max(worst_flat, float(err.max()) / scale)
         worst = max(worst, float((err / tol).max()))
-    parity_note("warped pixels %s: max |I^ - I^_oracle| %.2e of the range; %d pixels above the flat %.0e (all on tap contrast x position "
-                "uncertainty; worst pixel at %.2f of its tolerance); %d pixels zeroed differently (all within %.0e of the strict test)" % (
-                    what, worst_flat, n_over, WARP_TOL, worst, n_flip, FLIP_THR))
+    if max_over_flat is not None:
+        assert n_over <= max_over_flat, "%s: %d warped pixels above the flat %g of the range (cap %d)" % (what, n_over, WARP_TOL, max_over_flat)
+    crit = ("FLAT %.0e" % flat_tol) if flat else "1e-4 + tap contrast x position uncertainty"
+    parity_note("warped pixels %s [%s]: max |I^ - I^_oracle| %.2e of the range; %d of %d pixels above the flat %.0e (worst pixel at %.2f of its tolerance); "
+                "%d pixels with an allowance above %.0e (in effect unchecked; cap %.2f %% of a scale); %d pixels zeroed differently (all within %.0e of the strict test)" % (
+                    what, crit, worst_flat, n_over, n_px, WARP_TOL, worst, n_vac, VACUOUS_ALLOWANCE, 100 * VACUOUS_SHARE_CAP, n_flip, FLIP_THR))
+    parity_row(kind="warped", case=what, criterion=crit, worst_of_range=worst_flat, over_flat=n_over, pixels=n_px, vacuous=n_vac, zeroed_differently=n_flip)
     return n_flip
 
 
@@ -634,6 +655,81 @@ def test_full_batch_vs_oracle(ops, synth, dev, cfg_name, B, H, W, n_src):
     # uncertainty of each sample's position (oracle/parity.py: 1 .. 2e-4 px here), not a hand-set constant
     _check_grads(fl, ref, n_src, what=what, ref64=ref64, **knife_widths(d, ref))
     count_in_view_mismatches(ops, dev, d, ref, "hwc", what)
+
+
+@pytest.mark.parametrize("cfg_name,B,H,W,n_src,n_scales", [
+    ("l1", 1, 128, 416, 2, 1),             # BASELINE cfg1
+    ("l1_smooth", 8, 128, 416, 2, 4),      # BASELINE cfg2
+    ("ssim_smooth", 4, 128, 416, 2, 4),    # cfg3, live smoothness, oracle-sized batch
+    ("edge_aware", 4, 128, 416, 2, 4),     # cfg3 as written
+    ("edge_aware", 32, 128, 416, 2, 4),    # cfg3 as written at its FULL batch: the launch bench.py's headline times
+])
+def test_warped_pixels_meet_the_flat_tolerance_on_seam_free_inputs(ops, synth, dev, cfg_name, B, H, W, n_src, n_scales):
+    """north_star: "within 1e-4 rel fp32 on loss AND WARPED PIXELS" -- as a statement without an allowance.  Inputs: SURVEY 8(d)'s
+    "src = tgt pattern SHIFTED by a few px" with the border replicated (synth.make_inputs(seam="shift")) instead of rolled around:
+    no artificial step edge.  Every warped pixel of the benchmarked kernel (sfm_loss_fwd_bwd, pixel-interleaved) within the FLAT
+    1e-4 of the image range of the oracle's curr_proj_img (models/base_model.py:90-94), except pixels zeroed differently, all of
+    which the oracle places within 8e-6 of the strict in-view test (transform.py:129)."""
+    cfg = CONFIGS[cfg_name]
+    d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=n_scales, seed=1, seam="shift")
+    ref = O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], None, backward=False, keep_warped=True, **cfg)
+    fl = _bind(ops, dev, d, cfg, layout="hwc", want_warped=True)
+    _check_losses(fl.forward_backward(), ref)
+    _check_warped(fl, ref, "SEAM-FREE %s B=%d %dx%d hwc" % (cfg_name, B, H, W), d, flat=True)
+
+
+def test_warped_pixels_at_256x832_on_seam_free_inputs(ops, synth, dev):
+    """BASELINE cfg5 (B=8, 256x832, 4 sources) on seam-free inputs.  At U ~ 800 one ulp of a sampling position is 6e-5 px and two
+    correct fp32 evaluations of it lie up to 3e-4 px apart: the product kernel is held to a flat 2e-4 of the range with at most
+    0.01 % of the pixels above 1e-4, next to the yardstick -- how far the fp32 ORACLE is from the fp64 one on the same inputs -- and
+    the kernel's reference-order variant (sfm_loss_variant(2): the oracle's own rounding sequence per pixel) to the flat 1e-4."""
+    cfg = CONFIGS["ssim_smooth"]
+    B, H, W, n_src = 8, 256, 832, 4
+    d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=4, seed=1, seam="shift")
+    kw = dict(backward=False, keep_warped=True, **cfg)
+    ref = O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], None, **kw)
+    ref64 = O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], None, dtype=np.float64, **kw)
+    own = sum(int(((np.abs(a - b).max(axis=2) > WARP_TOL) & ((a == 0).all(axis=2) == (b == 0).all(axis=2))).sum()) for a, b in zip(ref["warped"], ref64["warped"]))
+    n_px = sum(a.shape[0] * a.shape[1] * a.shape[3] * a.shape[4] for a in ref["warped"])
+    parity_note("yardstick SEAM-FREE cfg5: the fp32 oracle itself is more than 1e-4 of the range from the fp64 oracle at %d of %d warped pixels" % (own, n_px))
+    fl = _bind(ops, dev, d, cfg, layout="hwc", want_warped=True)
+    what = "SEAM-FREE ssim_smooth B=%d %dx%d %d src hwc" % (B, H, W, n_src)
+    _check_losses(fl.forward_backward(), ref)
+    _check_warped(fl, ref, what, d, flat=True, flat_tol=2e-4, max_over_flat=int(1e-4 * n_px))
+    # ... and the kernel against the fp64 oracle (the function itself, no fp32 evaluation's roundings): is the kernel a worse fp32
+    # evaluation than the reference's, or do two equally good ones simply lie further apart than either does from the truth?
+    k64 = sum(int(((np.abs(to_np(g).astype(np.float64) - b).max(axis=2) > WARP_TOL) & ((to_np(g) == 0).all(axis=2) == (b == 0).all(axis=2))).sum())
+              for g, b in zip(fl.warped, ref64["warped"]))
+    w64 = max(float(np.abs(to_np(g).astype(np.float64) - b).max(axis=2)[(to_np(g) == 0).all(axis=2) == (b == 0).all(axis=2)].max()) for g, b in zip(fl.warped, ref64["warped"]))
+    o64 = max(float(np.abs(a - b).max(axis=2)[(a == 0).all(axis=2) == (b == 0).all(axis=2)].max()) for a, b in zip(ref["warped"], ref64["warped"]))
+    parity_note("yardstick SEAM-FREE cfg5: the KERNEL is more than 1e-4 of the range from the fp64 oracle at %d of %d warped pixels (worst %.2e; the fp32 oracle's worst %.2e)" % (
+        k64, n_px, w64, o64))
+    _check_losses(fl.forward_backward(variant=2), ref)
+    _check_warped(fl, ref, what + " [reference-order variant]", d, flat=True)
+
+
+@pytest.mark.parametrize("motion", [None, "behind", "large"])
+def test_reference_order_variant_meets_the_flat_tolerance_on_rolled_inputs(ops, synth, dev, motion):
+    """sfm_loss_variant(2) -- the fused kernel with the projection in the reference's own evaluation order (transform.py:105-108,
+    122-131,189; nothing fused, IEEE divisions) -- against the oracle on the ROLLED inputs, seam included: every warped pixel within
+    the FLAT 1e-4, no pixel zeroed differently away from the strict test, the loss and every gradient by the usual criteria.  What
+    separates the product kernel from the flat criterion on a contrast-2.0 seam is therefore the rounding sequence of the sampling
+    position, nothing else (profiles/r05_reference_order_variants.txt: +30 % kernel time, not the product)."""
+    cfg = CONFIGS["edge_aware"]
+    kw = dict(B=4, H=128, W=416, n_src=2, n_scales=4)
+    d = synth.make_inputs(seed=1, **kw) if motion is None else make_motion_inputs(synth, motion, seed=21, **kw)
+    ref = _oracle(d, cfg)
+    ref64 = lambda: O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], None, backward=True, keep_warped=True,
+                               dtype=np.float64, **cfg)
+    what = "REFERENCE-ORDER VARIANT %s edge_aware B=4 128x416 hwc" % (motion or "default motion")
+    fl = _bind(ops, dev, d, cfg, layout="hwc", want_warped=True)
+    _check_losses(fl.forward_backward(variant=2), ref)
+    _check_warped(fl, ref, what, d, flat=True)
+    explain = lambda i, got: pose_explained_by_discontinuities(d, cfg, ref, i, got)
+    _check_grads(fl, ref, 2, what=what, ref64=ref64, explain=explain, **knife_widths(d, ref))
+    # ... and variant 1 (the reference's geometry products, the product's per-pixel chain) by the criteria of the product kernel
+    _check_losses(fl.forward_backward(variant=1), ref)
+    _check_warped(fl, ref, what.replace("REFERENCE-ORDER", "REFERENCE-GEOMETRY"), d)
 
 
 MOTIONS = {
