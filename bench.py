@@ -43,7 +43,7 @@ PKG = "sfm-learner-chainer_amd"
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_FWD, BYTES_BWD = 28, 32   # algorithmic bytes per warped pixel, SURVEY.md 8(d)
 N_SIMD = 1024                   # 256 CUs x 4 SIMDs
-PROFILE_TAGS = ("r04", "r03")         # profiles/<tag>_summary.json, _issue_model.json, _wave_stage_stamps.txt: what roofline_valu is built from
+PROFILE_TAGS = ("r05", "r04", "r03")         # profiles/<tag>_summary.json, _issue_model.json, _wave_stage_stamps.txt: what roofline_valu is built from
 GRAD_BUFFER_FLOATS = 36489060 + 3393892   # DispNet + PoseNet parameters: the ~160 MB all-reduce probe
 
 COLLECTIVE_NOTES = {
@@ -74,7 +74,23 @@ WORKLOADS = {
              "BASELINE cfg5: B=8, 256x832, 5-frame (4 src), 4 scales"),
     "cfg5_2src": (8, 256, 832, 2, 4, dict(smooth_reg=0.1, ssim_rate=0.15),
                   "BASELINE cfg5 as parenthesised: B=8, 256x832, 2 src, 4 scales"),
+    "ref_b4": (4, 128, 416, 2, 4, dict(),
+               "the regime the reference TRAINS in: B=4 (experiments/sfm_learner_v1.yml:43 train_batchsize), 128x416, 4 scales, 2 src, its live "
+               "loss (smooth_reg 0, exp_reg 0: L1 only, :14-16)"),
 }
+
+
+def csrc_sha16():
+    """Content hash of the kernel sources this run was built from (the GPU box has no .git): stored with every profile collection,
+    so that figures read from profiles/ can be told from figures of another build."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, PKG, "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")) or name == "Makefile":
+            h.update(name.encode() + b"\0" + open(os.path.join(d, name), "rb").read() + b"\0")
+    h.update(open(os.path.join(ROOT, "include", "sfmwarp.h"), "rb").read())
+    return h.hexdigest()[:16]
 
 
 class HipEvents:
@@ -256,7 +272,7 @@ def dry_run_rank(args):
 class Runner:
     """Inputs of one workload resident on the device and a bound FusedLoss; `block(K)` = K back-to-back steps."""
 
-    def __init__(self, torch, np, ops, synth, dev, workload, layout="hwc", mode="fused", batch=0, seed=1, norm_scale=1):
+    def __init__(self, torch, np, ops, synth, dev, workload, layout="hwc", mode="fused", batch=0, seed=1, norm_scale=1, want_d_src=False):
         B, H, W, n_src, n_scales, cfg, desc = WORKLOADS[workload]
         if batch > 0:
             B, desc = batch, desc + " [per-GPU batch overridden to %d]" % batch
@@ -270,7 +286,7 @@ class Runner:
         if layout == "hwc":     # the same values, pixel-interleaved
             tgt, src = [ops.to_hwc(a) for a in tgt], [ops.to_hwc(a) for a in src]
         self.common = (t(d["intrinsics"]), [t(a) for a in d["disps"]], [t(a) for a in d["poses"]])
-        self.fl = ops.FusedLoss(**cfg).bind(tgt, src, *self.common, norm_B=B * norm_scale, layout=layout)
+        self.fl = ops.FusedLoss(**cfg).bind(tgt, src, *self.common, norm_B=B * norm_scale, layout=layout, want_d_src=want_d_src)
         self.warped_px = B * n_src * sum((H >> s) * (W >> s) for s in range(n_scales))
 
     def step(self, out=None, evs=None):
@@ -385,11 +401,19 @@ def profile_facts(workload, layout, mode, kernel_name):
     (profiles/<tag>_issue_model.json: the ISA of the row step priced with profiles/<tag>_op_cost_microbench.txt) and the in-kernel
     clock (profiles/<tag>_wave_stage_stamps.txt).  Missing pieces are None."""
     import re
-    out = {"tag": None, "counters": None, "traffic_raw": None, "traffic_x2": None, "issue": None, "clock_ghz": None, "rocprof_avg_ns": None}
+    out = {"tag": None, "counters": None, "traffic_raw": None, "traffic_x2": None, "issue": None, "clock_ghz": None, "rocprof_avg_ns": None,
+           "stale": None}
     for tag in PROFILE_TAGS:
         try:
             summ = json.load(open(os.path.join(ROOT, "profiles", "%s_summary.json" % tag)))
             var = summ["variants"]["%s_%s_%s" % (workload, layout, mode)]
+            built = var["bench"].get("csrc_sha16")
+            if built != csrc_sha16():
+                # counters of ANOTHER build of the kernels: not this run's (round-4 verdict: figures read from files must say when
+                # they are not of the tree that is running)
+                out["stale"] = "profiles/%s_summary.json was collected on kernel sources %s, this run is built from %s" % (
+                    tag, built or "without a recorded hash (before round 5)", csrc_sha16())
+                return out
             if kernel_name not in var["kernels"] and kernel_name.replace(", false>(sfm", ">(sfm") in var["kernels"]:
                 kernel_name = kernel_name.replace(", false>(sfm", ">(sfm")     # profiles of round 3: before the WARPED template argument
             if kernel_name not in var["kernels"]:        # a small launch of an L1 gradient kernel runs its three-waves-per-SIMD build
@@ -626,9 +650,14 @@ def main():
                                                                     "separate" if args.mode == "fused" else "fused", args.batch)))
         guarded("graph_ms_per_step", lambda: graph_path(torch, np, R))
         guarded("link_ms_per_step", lambda: link_path(torch, np, R))
-        for name in ("cfg3", "cfg3_edge", "cfg3_large_motion", "cfg2", "cfg5", "cfg5_2src", "cfg1"):
+        for name in ("cfg3", "cfg3_edge", "cfg3_large_motion", "cfg2", "cfg5", "cfg5_2src", "cfg1", "ref_b4"):
             if name != args.workload:
                 guarded(name, lambda name=name: quick(torch, np, ev, Runner(torch, np, ops, synth, dev, name, args.layout, "fused")))
+        # the drop-in link (pyramids + loss + backward, models/base_model.py:48-124) at the reference's own training batch
+        guarded("ref_b4_link_ms_per_step", lambda: link_path(torch, np, Runner(torch, np, ops, synth, dev, "ref_b4", args.layout, "fused")))
+        # north_star's backward "scatters dL/d(depth, pose, src_img)": the same step with the OPTIONAL d_src output bound (the reference
+        # discards it in training, base_model.py:71-72 `.data`; NULL is the default) -- 12 global float atomics per warped pixel
+        guarded("cfg3_d_src", lambda: quick(torch, np, ev, Runner(torch, np, ops, synth, dev, args.workload, args.layout, "fused", args.batch, want_d_src=True)))
 
     for e4 in events.values():
         for e in e4:
@@ -664,6 +693,8 @@ def main():
             "kernel_ms_p10_p90": [round(float(np.percentile(kt, 10)), 5), round(float(np.percentile(kt, 90)), 5)],
             "bytes_per_warped_px": kbytes, "launches_timed": len(kt)}
         roofline["kernel_symbol"] = ksym
+        if facts["stale"]:
+            roofline["traffic_detail"] = {"traffic_is_null_because": facts["stale"]}
         if facts["rocprof_avg_ns"]:
             roofline["rocprof_kernel_ms_in_profiles"] = round(facts["rocprof_avg_ns"] * 1e-6, 5)
         roofline_valu = None
@@ -693,7 +724,9 @@ def main():
                        "ms_per_step_first_block": round(float(per_step[0]) * 1e3, 5), "ms_per_step_min": round(float(per_step.min()) * 1e3, 5)},
             "roofline": roofline,
             "roofline_valu": roofline_valu,
+            "roofline_valu_null_because": facts["stale"] if roofline_valu is None else None,
             "step_roofline_frac": round((BYTES_FWD + BYTES_BWD) * R.warped_px / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "csrc_sha16": csrc_sha16(),
             "loss5": [round(v, 6) for v in loss],
         }
         for oc, ms in variants_ms.items():

@@ -287,7 +287,7 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
                "s"(A.tiles_of[6]), "s"(A.tiles_of[7]), "s"(A.trace));
   const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
   int s = 0, b, t;
-  if (A.B >= 8) {
+  if ((int)A.prio_tab >= 0) {      // (bit 31 of prio_tab: deal the ITEMS out over the XCDs instead, see make_plan)
     // whole groups of eight samples: one sample of each group per XCD; the samples left over (B not a multiple of 8) are dealt out
     // item by item, round-robin over the XCDs (before round 3 they went to the first XCDs whole: B = 11 ran at 11/16)
     const int nb = A.B >> 3;                      // samples of the whole groups owned by this XCD
@@ -330,7 +330,7 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
     }
   } else {
     const int per = (int)(gridDim.x >> 3);
-    const int it = xcd * per + loc;
+    const int it = (A.prio_tab & 0x40000000u) ? loc * 8 + xcd : xcd * per + loc;   // (bit 30, experiment: items round-robin over the XCDs)
     if (it >= A.items) return;
 #pragma unroll
     for (int k = 1; k < SFM_MAX_SCALES; ++k)
@@ -795,7 +795,10 @@ struct Tuning {
   unsigned prio_tab = 0;                    // SFM_PRIO_TABLE: "0123,3210" = levels of ranks 0.. in phase 1, phase 2
   bool no_wide = false;                     // SFM_NO_WIDE: small L1 launches on the four-wave build too
   bool no_fill = false;                     // SFM_NO_FILL: no slot-filling refinement of the chunk heights (plan_chunks)
+  int deal_below = 8;                       // SFM_DEAL_ITEMS_BELOW: batches smaller than this have their ITEMS dealt out over the XCDs (8 contiguous
+                                            // ranges of the item list) instead of whole samples (b mod 8)
   Tuning() {
+    if (const char* e = getenv("SFM_DEAL_ITEMS_BELOW")) deal_below = atoi(e);
     no_wide = getenv("SFM_NO_WIDE") != nullptr;
     no_fill = getenv("SFM_NO_FILL") != nullptr;
     if (const char* e = getenv("SFM_CHUNK_ROWS")) chunk_rows = atoi(e);
@@ -959,7 +962,9 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
   A.prio_tab = 0;
   for (int r = 0; r <= A.prio_top; ++r)   // youngest preferred in the first half of the sources, oldest in the second
     A.prio_tab |= (unsigned)r << (2 * r) | (unsigned)(A.prio_top - r) << (8 + 2 * r);
-  if (tuning().has_prio) A.prio_tab = tuning().prio_tab;
+  if (tuning().has_prio) A.prio_tab = tuning().prio_tab & 0xffffu;
+  if (d->B < (tuning().deal_below > 8 ? tuning().deal_below : 8)) A.prio_tab |= 0x80000000u;   // fewer samples than XCDs (or asked for): deal items
+  if (getenv("SFM_DEAL_ROUND_ROBIN")) A.prio_tab |= 0x40000000u;
   plan_chunks(d, sw, 2 * (hs > hm ? hs : hm), slots, rows);
   int items = 0;
   for (int s = 0; s < d->n_scales; ++s) {
@@ -1071,7 +1076,7 @@ static hipError_t launch_main(const Plan& p, hipStream_t st, hipEvent_t ev_start
   // 8 x (items of the busiest XCD): see the item mapping at the top of loss_kernel
   int tiles_per_sample = 0;
   for (int s = 0; s < p.args.n_scales; ++s) tiles_per_sample += p.args.sc[s].tiles;
-  const int per_xcd = p.args.B >= 8 ? (p.args.B / 8) * tiles_per_sample + ((p.args.B % 8) * tiles_per_sample + 7) / 8 : (p.args.items + 7) / 8;
+  const int per_xcd = (int)p.args.prio_tab >= 0 ? (p.args.B / 8) * tiles_per_sample + ((p.args.B % 8) * tiles_per_sample + 7) / 8 : (p.args.items + 7) / 8;
   const void* fn = kernel_ptr<GRAD, LOSS>(p.ssim, p.expl, p.smode, p.hwc, p.wide, p.warped);
   if constexpr (GRAD && LOSS) {   // the reference-order variants (sfm_loss_variant): fused SSIM launch, pixel-interleaved, with smoothness
     if ((variant == 1 || variant == 2) && p.ssim && !p.expl && p.hwc && p.smode != 0) {
