@@ -236,6 +236,20 @@ __device__ __forceinline__ void wave_sums_lockstep(float (&v)[N]) {
   SFM_DPP_STAGE(0x143, 0xc);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
 #undef SFM_DPP_STAGE
 }
+// max over the 64 lanes of an integer, wave-uniform (DPP, the stages of wave_sum; a lane without a source lane keeps its own value)
+__device__ __forceinline__ int wave_max_i(int v) {
+#define SFM_DPP_MAX(ctrl, rmask) v = max(v, __builtin_amdgcn_update_dpp(v, v, ctrl, rmask, 0xf, false))
+  SFM_DPP_MAX(0x111, 0xf);
+  SFM_DPP_MAX(0x112, 0xf);
+  SFM_DPP_MAX(0x114, 0xf);
+  SFM_DPP_MAX(0x118, 0xf);
+  SFM_DPP_MAX(0x142, 0xa);
+  SFM_DPP_MAX(0x143, 0xc);
+#undef SFM_DPP_MAX
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_min_i(int v) { return -wave_max_i(-v); }
+
 __device__ __forceinline__ float lane63(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); }
 
 __device__ __forceinline__ float uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }

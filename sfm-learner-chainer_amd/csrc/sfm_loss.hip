@@ -264,8 +264,10 @@ __device__ __forceinline__ void set_issue_prio(const int p) {   // s_setprio tak
 // WARPED: the instantiations that also write the warped source images (SfmLossDesc.warped; LOSS kernels only).
 // REF: the projection of the source passes in the reference's own evaluation order (sfm_ssim_pass.h, issue_row) -- an experiment of
 // round 5 behind sfm_loss_variant, built for the pixel-interleaved SSIM kernels of sfm_loss_fwd_bwd only.
-template <bool SSIM, bool GRAD, bool LOSS, bool EXPL, int SMODE, bool HWC, bool WARPED, int REF = 0>
+// DSRC: the instantiations a launch with SfmLossDesc.d_src bound runs (the LDS accumulation window of sfm_ssim_pass.h, dsrc_scatter).
+template <bool SSIM, bool GRAD, bool LOSS, bool EXPL, int SMODE, bool HWC, bool WARPED, int REF = 0, bool DSRC = false>
 __device__ __forceinline__ void loss_body(const LossArgs& A) {
+  static_assert(GRAD || !DSRC, "dL/d(src) is an output of the backward");
   static_assert(LOSS || !WARPED, "the warped images are an output of the forward and the fused entry points");
   static_assert(REF == 0 || (SSIM && GRAD && LOSS && HWC && !EXPL), "the reference-order variants exist for the benchmarked kernels only");
   using HH = Halo<SSIM, GRAD, SMODE>;
@@ -370,6 +372,12 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
 
   float acc_pix = 0.f, acc_ssim = 0.f, acc_sm = 0.f, acc_exp = 0.f;
   bool first = true;
+  // the LDS window of the optional dL/d(src) (dynamic LDS: allocated by the launch only when the descriptor binds d_src)
+  extern __shared__ float dsrc_tile[];
+  if (DSRC && S.d_src) {
+#pragma unroll
+    for (int k = 0; k < DSRC_TILE_FLOATS / 64; ++k) dsrc_tile[k * 64 + lane] = 0.f;
+  }
   // the disparities every source pass of this wave starts from (see ssim_source_pass / l1_source_pass): loaded once, now
   float disp_first, disp_second;
   {
@@ -455,7 +463,8 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
     asm volatile("" : "+s"(y0p), "+s"(y1p));
     C.h = h; C.w = w; C.y0 = y0p; C.y1 = y1p;
     C.dp = S.disp + (size_t)b * P;
-    C.dsp = (GRAD && S.d_src) ? S.d_src + ((size_t)b * A.n_src + i) * 3 * P : nullptr;
+    C.dsp = (DSRC && S.d_src) ? S.d_src + ((size_t)b * A.n_src + i) * 3 * P : nullptr;
+    C.dtile = dsrc_tile;
     C.wp = WARPED ? S.warped + ((size_t)b * A.n_src + i) * 3 * P : nullptr;
     C.mp = EXPL ? S.mlog + ((size_t)b * A.n_src + i) * P : nullptr;
     C.dmp = (EXPL && GRAD) ? S.d_mask + ((size_t)b * A.n_src + i) * P : nullptr;
@@ -476,9 +485,9 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
     C.lane = lane;
     float* gpm_out = GRAD ? A.part_gpm + ((size_t)item * A.n_src + i) * 12 : nullptr;
     if constexpr (SSIM) {
-      ssim_source_pass<GRAD, LOSS, HWC, WARPED, REF>(C, gacc, first, acc_pix, acc_ssim, gpm_out SFM_STAMPS_PASS);
+      ssim_source_pass<GRAD, LOSS, HWC, WARPED, REF, DSRC>(C, gacc, first, acc_pix, acc_ssim, gpm_out SFM_STAMPS_PASS);
     } else {
-      l1_source_pass<GRAD, LOSS, EXPL, HWC, WARPED>(C, gacc, first, acc_pix, acc_exp, gpm_out);
+      l1_source_pass<GRAD, LOSS, EXPL, HWC, WARPED, DSRC>(C, gacc, first, acc_pix, acc_exp, gpm_out);
     }
     first = false;
 #ifdef SFM_STAMPS
@@ -525,6 +534,12 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
 template <bool SSIM, bool GRAD, bool LOSS, bool EXPL, int SMODE, bool HWC, bool WARPED = false>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) loss_kernel(const LossArgs A) {
   loss_body<SSIM, GRAD, LOSS, EXPL, SMODE, HWC, WARPED>(A);
+}
+// (DSRC, see loss_body: the gradient kernels of a launch that also wants dL/d(src).  Three waves per SIMD; the SSIM ones two: at
+//  three they would spill 22-34 registers to scratch)
+template <bool SSIM, bool LOSS, bool EXPL, int SMODE, bool HWC, bool WARPED = false>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, SSIM ? 2 : 3) loss_kernel_dsrc(const LossArgs A) {
+  loss_body<SSIM, true, LOSS, EXPL, SMODE, HWC, WARPED, 0, true>(A);
 }
 // (REF, see loss_body: the fused SSIM kernels in the pixel-interleaved layout, in the reference's evaluation order)
 template <int SMODE, bool WARPED, int REF>
@@ -749,6 +764,7 @@ struct Plan {
   size_t off_loss, off_gpm, total;
   bool ssim, expl, hwc;
   bool wide;     // the three-waves-per-SIMD build of an L1 gradient kernel (see loss_kernel)
+  bool dsrc;     // the launch also produces dL/d(src): the instantiations with the LDS accumulation window (three waves per SIMD)
   bool warped;   // the instantiation that also writes SfmLossDesc.warped
   int smode;
 };
@@ -785,7 +801,10 @@ static int device_cus() {
   return cus_of[dev];
 }
 
-static int waves_per_simd_of(bool ssim, bool grad, bool wide) { return ((ssim && grad) || wide) ? 3 : 4; }   // = __launch_bounds__ of loss_kernel
+static int waves_per_simd_of(bool ssim, bool grad, bool wide, bool dsrc) {   // = __launch_bounds__ of the kernel
+  if (dsrc) return ssim ? 2 : 3;
+  return ((ssim && grad) || wide) ? 3 : 4;
+}
 
 // tuning overrides (development only), read from the environment ONCE per process
 struct Tuning {
@@ -954,8 +973,11 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
     if (d->H[s] < 3 || d->W[s] < 3) return fail(SFM_ERR_SHAPE, "sfm_loss: scale %d is %dx%d, need H,W >= 3", s, d->H[s], d->W[s]);
   const int cus = device_cus();
   // (a launch is "small" when even at the smallest chunk height its waves fit the SIMDs three deep)
-  p.wide = grad && !p.ssim && !p.expl && !tuning().no_wide && max_items(d, sw) <= (long long)cus * 4 * 3;
-  const int waves_per_simd = waves_per_simd_of(p.ssim, grad, p.wide);
+  p.dsrc = false;
+  if (grad && need_outputs)
+    for (int s = 0; s < d->n_scales; ++s) p.dsrc = p.dsrc || d->d_src[s] != nullptr;
+  p.wide = grad && !p.dsrc && !p.ssim && !p.expl && !tuning().no_wide && max_items(d, sw) <= (long long)cus * 4 * 3;
+  const int waves_per_simd = waves_per_simd_of(p.ssim, grad, p.wide, p.dsrc);
   const int slots = cus * 4 * waves_per_simd;
   A.simds_per_xcd = (cus % 8 == 0) ? cus / 8 * 4 : 128;   // gfx950: 8 XCDs, 4 SIMDs per CU
   A.prio_top = waves_per_simd - 1 < 3 ? waves_per_simd - 1 : 3;
@@ -1069,6 +1091,32 @@ static const void* kernel_ptr(bool ssim, bool expl, int smode, bool hwc, bool wi
 #undef SFM_KPICK
 }
 
+// the same table for the launches that also produce dL/d(src) (loss_kernel_dsrc)
+template <bool LOSS>
+static const void* kernel_ptr_dsrc(bool ssim, bool expl, int smode, bool hwc, bool warped) {
+#define SFM_KPICK(...)                                                                                                                   \
+  do {                                                                                                                                   \
+    if constexpr (LOSS) {                                                                                                                \
+      if (warped) return hwc ? (const void*)&loss_kernel_dsrc<__VA_ARGS__, true, true> : (const void*)&loss_kernel_dsrc<__VA_ARGS__, false, true>; \
+    }                                                                                                                                    \
+    return hwc ? (const void*)&loss_kernel_dsrc<__VA_ARGS__, true, false> : (const void*)&loss_kernel_dsrc<__VA_ARGS__, false, false>;   \
+  } while (0)
+  if (expl) {
+    if (smode == 0) SFM_KPICK(false, LOSS, true, 0);
+    else if (smode == 1) SFM_KPICK(false, LOSS, true, 1);
+    else SFM_KPICK(false, LOSS, true, 2);
+  } else if (ssim) {
+    if (smode == 0) SFM_KPICK(true, LOSS, false, 0);
+    else if (smode == 1) SFM_KPICK(true, LOSS, false, 1);
+    else SFM_KPICK(true, LOSS, false, 2);
+  } else {
+    if (smode == 0) SFM_KPICK(false, LOSS, false, 0);
+    else if (smode == 1) SFM_KPICK(false, LOSS, false, 1);
+    else SFM_KPICK(false, LOSS, false, 2);
+  }
+#undef SFM_KPICK
+}
+
 template <bool GRAD, bool LOSS>
 static hipError_t launch_main(const Plan& p, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, const int variant) {
   LossArgs args = p.args;
@@ -1078,6 +1126,9 @@ static hipError_t launch_main(const Plan& p, hipStream_t st, hipEvent_t ev_start
   for (int s = 0; s < p.args.n_scales; ++s) tiles_per_sample += p.args.sc[s].tiles;
   const int per_xcd = (int)p.args.prio_tab >= 0 ? (p.args.B / 8) * tiles_per_sample + ((p.args.B % 8) * tiles_per_sample + 7) / 8 : (p.args.items + 7) / 8;
   const void* fn = kernel_ptr<GRAD, LOSS>(p.ssim, p.expl, p.smode, p.hwc, p.wide, p.warped);
+  if constexpr (GRAD) {
+    if (p.dsrc) fn = kernel_ptr_dsrc<LOSS>(p.ssim, p.expl, p.smode, p.hwc, p.warped);
+  }
   if constexpr (GRAD && LOSS) {   // the reference-order variants (sfm_loss_variant): fused SSIM launch, pixel-interleaved, with smoothness
     if ((variant == 1 || variant == 2) && p.ssim && !p.expl && p.hwc && p.smode != 0) {
       const int key = (p.smode == 2 ? 4 : 0) | (p.warped ? 2 : 0) | (variant == 2 ? 1 : 0);
@@ -1091,8 +1142,10 @@ static hipError_t launch_main(const Plan& p, hipStream_t st, hipEvent_t ev_start
   // With profiling events the kernel is launched through hipExtLaunchKernel: the events then carry the begin / end
   // timestamps of THIS dispatch (what rocprofv3's kernel trace reports), and no marker packets are put between the
   // launches of a step (hipEventRecord on either side of the kernel costs the step several microseconds).
-  if (ev_start && ev_stop) return hipExtLaunchKernel(fn, dim3(8 * per_xcd), dim3(64 * WAVES_PER_BLOCK), kargs, 0, st, ev_start, ev_stop, 0);
-  return hipLaunchKernel(fn, dim3(8 * per_xcd), dim3(64 * WAVES_PER_BLOCK), kargs, 0, st);
+  // dynamic LDS: the accumulation window of the optional dL/d(src) output (sfm_ssim_pass.h, dsrc_scatter), only when it is bound
+  const size_t smem = (GRAD && p.dsrc) ? DSRC_TILE_FLOATS * sizeof(float) : 0;
+  if (ev_start && ev_stop) return hipExtLaunchKernel(fn, dim3(8 * per_xcd), dim3(64 * WAVES_PER_BLOCK), kargs, smem, st, ev_start, ev_stop, 0);
+  return hipLaunchKernel(fn, dim3(8 * per_xcd), dim3(64 * WAVES_PER_BLOCK), kargs, smem, st);
 }
 
 // The plan of a descriptor depends only on the descriptor's bytes and the entry point: the last few are kept per

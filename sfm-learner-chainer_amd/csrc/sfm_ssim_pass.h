@@ -45,6 +45,7 @@ struct SsimCtx {
   const float* sp[3];   // source planes of this (sample, source)
   const float* dp;      // disparity plane
   float* dsp;           // d_src planes of this (sample, source) or nullptr
+  float* dtile;         // with dsp: this wave's LDS accumulation window for dL/d(src) (DSRC_ROWS x 3 x DSRC_COLS floats, see dsrc_scatter)
   float* wp;            // planes of the optional warped-image output of this (sample, source), or nullptr   base_model.py:90-94
   const float* mp;      // explainability logits of this (sample, source) or nullptr     base_model.py:104
   float* dmp;           // their gradient plane or nullptr
@@ -515,11 +516,88 @@ __device__ __forceinline__ void store_warped_row(const SsimCtx& C, const int r, 
 struct PoseAcc {
   f2 A, B, Cq;         // sum gq D, sum y gq D, sum gq   (components 0, 1)
   float A2, B2, C2;    // ... component 2
+  int dvb, dcb;        // optional dL/d(src): first source row / column of the LDS accumulation window (wave-uniform; dsrc_scatter)
 };
-__device__ __forceinline__ void zero(PoseAcc& a) { a.A = a.B = a.Cq = T_of<f2>(0.f); a.A2 = a.B2 = a.C2 = 0.f; }
+constexpr int DSRC_UNSET = 0x7fffffff;
+__device__ __forceinline__ void zero(PoseAcc& a) {
+  a.A = a.B = a.Cq = T_of<f2>(0.f); a.A2 = a.B2 = a.C2 = 0.f;
+  a.dvb = DSRC_UNSET; a.dcb = 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Optional dL/d(src) (SfmLossDesc.d_src; the reference discards it in training, models/base_model.py:71-72 `.data`): the scatter of
+// dL/dI^ over the four taps of every sample, SURVEY.md App. A.3.  Straight to memory that is 12 global float atomics per warped pixel
+// and the cfg3 step takes 1.26 ms instead of 0.057 (round 5, profiles/r05_d_src.txt: what costs is the number of 64-byte atomic
+// requests, and a wave instruction whose lanes land in different source rows is up to 64 of them).  The wave therefore accumulates in
+// LDS where it can: a window of DSRC_ROWS source rows x DSRC_COLS columns x 3 channels that slides down the source image with the
+// wave's output rows (a source row receives from two consecutive output rows).  A row that leaves the window is added to memory
+// ONCE -- one dense 256-byte atomic per 64 texels and channel -- and cleared.  Taps outside the window go to memory directly, as
+// before: the result is the same sum either way.  What the window catches depends on how far the taps of one row of samples spread
+// VERTICALLY, i.e. on the depth field: on synth's inputs (disparity 0.5 .. 9.5 with per-pixel noise: +-7 rows of parallax spread
+// inside a 60-pixel row segment at 128x416) 39 % of the taps at scale 0, 59 / 81 / 94 % at scales 1 / 2 / 3 -- the step 0.87 ms;
+// with every tap inside it would be 0.24 ms (the same launch with the direct path removed).
+// ------------------------------------------------------------------------------------------
+constexpr int DSRC_ROWS = 4, DSRC_COLS = 128;
+constexpr int DSRC_TILE_FLOATS = DSRC_ROWS * 3 * DSRC_COLS;
+
+// rows [v0, v1) of the window (at most DSRC_ROWS of them) -> memory, and cleared
+__device__ __forceinline__ void dsrc_flush(const SsimCtx& C, const int v0, const int v1, const int cb) {
+  for (int v = v0; v < v1; ++v) {
+    float* row = C.dtile + (v & (DSRC_ROWS - 1)) * (3 * DSRC_COLS);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int j = 0; j < DSRC_COLS / 64; ++j) {
+        float* t = row + c * DSRC_COLS + j * 64 + C.lane;
+        const float val = *t;
+        *t = 0.f;
+        // (a texel outside the image never received anything: taps are taken in view only)
+        if (val != 0.f) atomicAdd(C.dsp + (size_t)c * C.P + (unsigned)(v * C.w + cb + j * 64 + C.lane), val);
+      }
+  }
+}
+
+__device__ __forceinline__ void dsrc_scatter(const SsimCtx& C, const Proj& p, const bool act, const float* gI, PoseAcc& gpm) {
+  const int big = 0x3fffffff;
+  const int vlo = wave_min_i(act ? p.v0 : big), vhi = wave_max_i(act ? p.v0 + 1 : -big);
+  if (vhi < vlo) return;                                   // (wave-uniform) no sample of this row is in view
+  if (gpm.dvb == DSRC_UNSET) {                             // first such row of the pass: place the window around its taps
+    const int ulo = wave_min_i(act ? p.u0 : big), uhi = wave_max_i(act ? p.u0 + 1 : -big);
+    gpm.dcb = ((ulo + uhi) >> 1) - DSRC_COLS / 2;
+    gpm.dvb = vlo;
+  }
+  const int nvb = max(gpm.dvb, vhi - (DSRC_ROWS - 1));     // the window has to reach the lowest tap row
+  if (nvb > gpm.dvb) {
+    dsrc_flush(C, gpm.dvb, min(nvb, gpm.dvb + DSRC_ROWS), gpm.dcb);
+    gpm.dvb = nvb;
+  }
+  if (act) {
+    const float w00 = (1.f - p.fu) * (1.f - p.fv), w01 = p.fu * (1.f - p.fv), w10 = (1.f - p.fu) * p.fv, w11 = p.fu * p.fv;
+    const float wt[4] = {w00, w01, w10, w11};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int v = p.v0 + (k >> 1), u = p.u0 + (k & 1);
+      const bool inside = (unsigned)(v - gpm.dvb) < (unsigned)DSRC_ROWS && (unsigned)(u - gpm.dcb) < (unsigned)DSRC_COLS;
+      if (inside) {
+        float* t = C.dtile + (v & (DSRC_ROWS - 1)) * (3 * DSRC_COLS) + (u - gpm.dcb);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) __hip_atomic_fetch_add(t + c * DSRC_COLS, gI[c] * wt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+        float* ds = C.dsp + (unsigned)(v * C.w + u);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) atomicAdd(ds + c * C.P, gI[c] * wt[k]);
+      }
+    }
+  }
+}
+// end of a pass: what is left in the window
+__device__ __forceinline__ void dsrc_finish(const SsimCtx& C, const PoseAcc& gpm) {
+  if (C.dsp != nullptr && gpm.dvb != DSRC_UNSET) dsrc_flush(C, gpm.dvb, gpm.dvb + DSRC_ROWS, gpm.dcb);
+}
 
 // From dL/dI^ of one pixel (already contracted with dI^/du, dI^/dv and 1/z into gq = (gq0, gq1)) to its
 // share of d_depth (LDS tile), of the 12 sums of dL/dPm and, optionally, of dL/d(src).
+template <bool DSRC>
 __device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& s2, const int rc, const f2 gq,
                                                   const float* gI, float* gacc, const bool first, PoseAcc& gpm) {
   const int h = C.h, w = C.w;
@@ -545,20 +623,12 @@ __device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& 
   gpm.A += t; gpm.A2 += t2;
   gpm.B = vfma(T_of<f2>(yf), t, gpm.B); gpm.B2 = fmaf(yf, t2, gpm.B2);
   gpm.Cq += gq; gpm.C2 += gq2;
-  if (C.dsp != nullptr) {   // optional dL/d(src): scatter of dL/dI^ over the four taps (uniform branch)
+  // (DSRC: the instantiations a launch with SfmLossDesc.d_src bound runs.  A run-time branch here -- rounds 1-4 -- costs the kernels
+  //  of every OTHER launch registers: with the window code behind it the SSIM gradient kernels spill 32 VGPRs)
+  if (DSRC && C.dsp != nullptr) {   // optional dL/d(src): scatter of dL/dI^ over the four taps, through the LDS window
     const float a0 = fmaf(C.M1[0], yf, C.mx[0]), a1 = fmaf(C.M1[1], yf, C.mx[1]), a2 = fmaf(C.M1[2], yf, C.mx[2]);
     const Proj p = project(a0, a1, a2, C.P3[0], C.P3[1], C.P3[2], s2.D, C.sc, h, w);
-    if (p.inview && C.outf != 0.f) {
-      float* ds = C.dsp + (unsigned)(p.v0 * w + p.u0);
-      const float w00 = (1.f - p.fu) * (1.f - p.fv), w01 = p.fu * (1.f - p.fv), w10 = (1.f - p.fu) * p.fv, w11 = p.fu * p.fv;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        atomicAdd(ds + c * C.P, gI[c] * w00);
-        atomicAdd(ds + c * C.P + 1, gI[c] * w01);
-        atomicAdd(ds + c * C.P + w, gI[c] * w10);
-        atomicAdd(ds + c * C.P + w + 1, gI[c] * w11);
-      }
-    }
+    dsrc_scatter(C, p, p.inview && C.outf != 0.f, gI, gpm);
   }
 }
 
@@ -697,7 +767,7 @@ __device__ __forceinline__ f2 contract_uv(const RowS& s, const f2 gp, const floa
 
 // Stage C at row rc (the row in s2; partials of the rows rc-1, rc, rc+1 in g2, g1, g0): dL/dI^ -> dL/d(u,v) -> dL/dq -> d_depth
 // tile and the sums of dL/dPm.
-template <bool LOSS>
+template <bool LOSS, bool DSRC>
 __device__ __forceinline__ void ssim_stage_c_row(const SsimCtx& C, const int rc, const RowS& s2, const RowG& g2, const RowG& g1,
                                                  const RowG& g0, float* gacc, const bool first, PoseAcc& gpm, float& acc_pix) {
   const float kpn = C.k_pix * s2.nm;
@@ -709,7 +779,7 @@ __device__ __forceinline__ void ssim_stage_c_row(const SsimCtx& C, const int rc,
   // and I^ - I is at hand (with the fused kernel stage B would form it a second time, one row earlier)
   if (LOSS) acc_pix = fmaf(vabs_sum(dp) + vabs_sum(ds), s2.nm * C.outf, acc_pix);
   const float gI[3] = {gp.x, gp.y, gs};
-  geometry_backward(C, s2, rc, contract_uv(s2, gp, gs), gI, gacc, first, gpm);
+  geometry_backward<DSRC>(C, s2, rc, contract_uv(s2, gp, gs), gI, gacc, first, gpm);
 }
 
 // Which stages run on which step of a pass, as bit k of one 32-bit word per question (a pass has at most 32 steps): every
@@ -731,7 +801,7 @@ __device__ __forceinline__ unsigned step_range(int lo, int hi) {   // bits lo ..
 }
 __device__ __forceinline__ bool step_bit(const unsigned m, const int k) { return ((m >> k) & 1u) != 0u; }
 
-template <bool GRAD, bool LOSS, bool HWC, bool WARPED, int REF>
+template <bool GRAD, bool LOSS, bool HWC, bool WARPED, int REF, bool DSRC>
 __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const StepMasks& M, const int k, const int r, Pipe& ps, float& disp_next,
                                               RowS& s0, const RowS& s1, const RowS& s2,
                                               RowG& g0, const RowG& g1, const RowG& g2, float* gacc, const bool first,
@@ -767,7 +837,7 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const StepMasks&
   // ---------------- C: gradients at row r-2 ----------------
   if (GRAD) {
     if (step_bit(M.c, k)) {
-      ssim_stage_c_row<LOSS>(C, r - 2, s2, g2, g1, g0, gacc, first, gpm, acc_pix);
+      ssim_stage_c_row<LOSS, DSRC>(C, r - 2, s2, g2, g1, g0, gacc, first, gpm, acc_pix);
     }
   }
   SFM_STAMP(t4);
@@ -777,7 +847,7 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const StepMasks&
 }
 
 // One source of one wave.  HS = halo of this pass (2 with gradients, 1 forward only).
-template <bool GRAD, bool LOSS, bool HWC, bool WARPED, int REF = 0>
+template <bool GRAD, bool LOSS, bool HWC, bool WARPED, int REF = 0, bool DSRC = false>
 __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, const bool first, float& acc_pix, float& acc_ssim,
                                                  float* gpm_out /* 12 floats in global memory, or nullptr */ SFM_STAMPS_ARG) {
   constexpr int HS = GRAD ? 2 : 1;
@@ -807,18 +877,21 @@ __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, 
   disp_next = C.disp_second;
   for (int k = 0; k < n; k += 3) {
     const int r = rbeg + k;
-    ssim_row_step<GRAD, LOSS, HWC, WARPED, REF>(C, M, k, r, ps, disp_next, S0, S2, S1, G0, G2, G1, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
+    ssim_row_step<GRAD, LOSS, HWC, WARPED, REF, DSRC>(C, M, k, r, ps, disp_next, S0, S2, S1, G0, G2, G1, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
     if (k + 1 < n)
-      ssim_row_step<GRAD, LOSS, HWC, WARPED, REF>(C, M, k + 1, r + 1, ps, disp_next, S1, S0, S2, G1, G0, G2, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
+      ssim_row_step<GRAD, LOSS, HWC, WARPED, REF, DSRC>(C, M, k + 1, r + 1, ps, disp_next, S1, S0, S2, G1, G0, G2, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
     if (k + 2 < n)
-      ssim_row_step<GRAD, LOSS, HWC, WARPED, REF>(C, M, k + 2, r + 2, ps, disp_next, S2, S1, S0, G2, G1, G0, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
+      ssim_row_step<GRAD, LOSS, HWC, WARPED, REF, DSRC>(C, M, k + 2, r + 2, ps, disp_next, S2, S1, S0, G2, G1, G0, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
   }
-  if (GRAD) pose_sums_raw(C, gpm, gpm_out);
+  if (GRAD) {
+    if (DSRC) dsrc_finish(C, gpm);
+    pose_sums_raw(C, gpm, gpm_out);
+  }
 }
 
 // Photometric pass WITHOUT SSIM for one (wave, source): L1 (+ explainability weighting, base_model.py:103-109).
 // Everything is per pixel, so there is no ring; the loads of row r+1 are in flight while row r is finished.
-template <bool GRAD, bool LOSS, bool EXPL, bool HWC, bool WARPED>
+template <bool GRAD, bool LOSS, bool EXPL, bool HWC, bool WARPED, bool DSRC = false>
 __device__ __forceinline__ void l1_source_pass(const SsimCtx& C, float* gacc, const bool first, float& acc_pix, float& acc_exp,
                                                float* gpm_out) {
   PoseAcc gpm;    // A_k, B_k, C_k of geometry_backward
@@ -852,10 +925,13 @@ __device__ __forceinline__ void l1_source_pass(const SsimCtx& C, float* gacc, co
         // d/dlogit of (1-alpha) mean(err sigmoid) + exp_reg mean(softplus(-logit))
         if (C.outf != 0.f) stf_wt(C.dmp, (unsigned)r * (unsigned)C.w + C.xc, C.k_pix * e1 * sgm * (1.f - sgm) + C.k_exp * (sgm - 1.f));
       }
-      geometry_backward(C, s0, r, contract_uv(s0, gp, gs), gI, gacc, first, gpm);
+      geometry_backward<DSRC>(C, s0, r, contract_uv(s0, gp, gs), gI, gacc, first, gpm);
     }
   }
-  if (GRAD) pose_sums_raw(C, gpm, gpm_out);
+  if (GRAD) {
+    if (DSRC) dsrc_finish(C, gpm);
+    pose_sums_raw(C, gpm, gpm_out);
+  }
 }
 
 }  // namespace sfm

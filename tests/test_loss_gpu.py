@@ -799,6 +799,36 @@ def test_large_motion_vs_oracle(ops, synth, dev, motion, cfg_name, B, H, W, n_sr
     count_in_view_mismatches(ops, dev, d, ref, layout, what)
 
 
+@pytest.mark.parametrize("cfg_name", ["edge_aware", "l1_smooth", "explain"])
+@pytest.mark.parametrize("motion", [None, "medium", "large", "behind"])
+def test_d_src_through_the_lds_window(ops, synth, dev, motion, cfg_name):
+    """The optional dL/d(src) output (north_star: the backward "scatters dL/d(depth, pose, src_img)") at the BASELINE frame size:
+    the kernels accumulate it in a wave-private LDS window of 4 source rows x 128 columns that slides with the wave and reaches
+    memory once per source row (csrc/sfm_ssim_pass.h, dsrc_scatter); taps outside the window go to memory directly.  Default motion
+    keeps every tap inside the window; `medium` / `large` / `behind` (wide and mirrored footprints, most of the frame out of view)
+    exercise the direct path and windows that jump.  d_src element-wise against the oracle outside the scatter footprints of
+    knife-edge pixels, loss and the other gradients by the usual criteria (the launch runs another instantiation of the kernel)."""
+    cfg = CONFIGS[cfg_name]
+    kw = dict(B=4, H=128, W=416, n_src=2, n_scales=4, with_masks=True)      # (the inputs of test_large_motion_vs_oracle)
+    d = synth.make_inputs(seed=21, **kw) if motion is None else make_motion_inputs(synth, motion, seed=21, **kw)
+    ref = _oracle(d, cfg, want_d_src=True)
+    ref64 = lambda: O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], d["masks"], backward=True, want_d_src=True,
+                               keep_warped=True, dtype=np.float64, **cfg)
+    explain = lambda i, got: pose_explained_by_discontinuities(d, cfg, ref, i, got)
+    what = "D_SRC %s %s B=4 128x416 hwc" % (motion or "default motion", cfg_name)
+    fl = _bind(ops, dev, d, cfg, want_d_src=True, layout="hwc")
+    _check_losses(fl.forward_backward(), ref)
+    _check_grads(fl, ref, 2, check_src=True, check_mask=bool(cfg.get("exp_reg")), what=what, ref64=ref64, explain=explain, **knife_widths(d, ref))
+    # the same through the separate backward entry point, accumulated twice: d_src is ADDED to what the buffers hold (sfmwarp.h)
+    first = [to_np(t).copy() for t in fl.d_srcs]
+    fl.d_srcs, keep = fl.d_srcs, fl._zero_d_src
+    fl._zero_d_src = lambda: None
+    fl.backward(1.0)
+    fl._zero_d_src = keep
+    for a, t, w in zip(first, fl.d_srcs, ref["d_srcs"]):
+        np.testing.assert_allclose(to_np(t), 2.0 * a, rtol=0, atol=2e-5 * max(float(np.abs(w).max()), 1e-30))
+
+
 @pytest.mark.parametrize("motion", ["medium", "behind"])
 def test_large_motion_full_batch_vs_oracle(ops, synth, dev, motion):
     """The same at BASELINE cfg3's FULL batch (B=32, as written: edge-aware smoothness), pixel-interleaved: the launch bench.py's

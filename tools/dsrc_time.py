@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""Timing of the fused step with the optional dL/d(src) output bound (development; SFMWARP_LIB selects the build)."""
+import importlib, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+bench = importlib.import_module("bench")
+PKG = "sfm-learner-chainer_amd"
+ops = importlib.import_module(PKG + ".ops"); synth = importlib.import_module(PKG + ".synth")
+dev = torch.device("cuda", 0)
+wl = sys.argv[1] if len(sys.argv) > 1 else "cfg3_edge"
+ev = bench.HipEvents()
+for want in (False, True):
+    R = bench.Runner(torch, np, ops, synth, dev, wl, "hwc", "fused", want_d_src=want)
+    q = bench.quick(torch, np, ev, R)
+    print("%s d_src=%s: step %.2f us, main kernel %.2f us" % (wl, want, q["ms_per_step"] * 1e3, q["main_kernel_ms"] * 1e3), flush=True)
