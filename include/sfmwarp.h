@@ -231,6 +231,24 @@ int sfm_disp_act_bwd(const float *const *disp, const float *const *g_disp, float
  * ---------------------------------------------------------------------------------------- */
 int sfm_augment_fwd(const float *imgs, const float *params, float *out, int B, int F, int C, int H, int W, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * DEVELOPMENT ONLY -- environment variables the library reads ONCE per process (at the first call that needs them; setting them
+ * later has no effect).  They move work between wavefronts or pick another kernel for the same arithmetic; none changes a result
+ * beyond the summation order of the per-wave partial sums.  Not part of the interface: names and meaning may change.
+ *   fused loss (csrc/sfm_loss.hip, struct Tuning):
+ *     SFM_CHUNK_ROWS=n            rows of a wave's chunk at every scale (4..28) instead of the planned heights
+ *     SFM_CHUNK_ROWS_LIST=a,b,..  the same per scale
+ *     SFM_NO_FILL                 no slot-filling refinement of the chunk heights (plan_chunks)
+ *     SFM_NO_WIDE                 small L1 launches on the four-waves-per-SIMD build too
+ *     SFM_PRIO_TABLE=abc,def      issue-priority levels of the dispatch rounds in the first / second half of the sources
+ *     SFM_DEAL_ITEMS_BELOW=n      batches smaller than n (default 8) have their items, not whole samples, dealt over the XCDs
+ *   image pyramid (csrc/sfm_ops.hip, struct PyramidTuning):
+ *     SFM_PYRAMID_BAND_ROWS=n     input rows per band of the band kernel
+ *     SFM_PYRAMID_THREADS=n       threads per workgroup of the band kernel
+ * One-call hooks with the same purpose are entry points above: sfm_loss_variant, sfm_pyramid_variant, sfm_loss_profile_events,
+ * sfm_loss_debug_trace.  Diagnostic BUILDS (never the product): -DSFM_STAMPS (`make stamps`), -DSFM_FIN_STAMPS.
+ * ---------------------------------------------------------------------------------------- */
+
 #ifdef __cplusplus
 }
 #endif

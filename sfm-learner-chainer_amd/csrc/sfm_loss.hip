@@ -332,7 +332,7 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
     }
   } else {
     const int per = (int)(gridDim.x >> 3);
-    const int it = (A.prio_tab & 0x40000000u) ? loc * 8 + xcd : xcd * per + loc;   // (bit 30, experiment: items round-robin over the XCDs)
+    const int it = xcd * per + loc;
     if (it >= A.items) return;
 #pragma unroll
     for (int k = 1; k < SFM_MAX_SCALES; ++k)
@@ -815,7 +815,8 @@ struct Tuning {
   bool no_wide = false;                     // SFM_NO_WIDE: small L1 launches on the four-wave build too
   bool no_fill = false;                     // SFM_NO_FILL: no slot-filling refinement of the chunk heights (plan_chunks)
   int deal_below = 8;                       // SFM_DEAL_ITEMS_BELOW: batches smaller than this have their ITEMS dealt out over the XCDs (8 contiguous
-                                            // ranges of the item list) instead of whole samples (b mod 8)
+                                            // ranges of the item list) instead of whole samples (b mod 8).  Measured at B = 8 (9): cfg5_2src +9.9 %,
+                                            // cfg5 +3 %, cfg2 +1.6 %; items round-robin +22 .. +48 % (profiles/r05_wave_stage_stamps_cfg5_2src.txt)
   Tuning() {
     if (const char* e = getenv("SFM_DEAL_ITEMS_BELOW")) deal_below = atoi(e);
     no_wide = getenv("SFM_NO_WIDE") != nullptr;
@@ -986,7 +987,6 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
     A.prio_tab |= (unsigned)r << (2 * r) | (unsigned)(A.prio_top - r) << (8 + 2 * r);
   if (tuning().has_prio) A.prio_tab = tuning().prio_tab & 0xffffu;
   if (d->B < (tuning().deal_below > 8 ? tuning().deal_below : 8)) A.prio_tab |= 0x80000000u;   // fewer samples than XCDs (or asked for): deal items
-  if (getenv("SFM_DEAL_ROUND_ROBIN")) A.prio_tab |= 0x40000000u;
   plan_chunks(d, sw, 2 * (hs > hm ? hs : hm), slots, rows);
   int items = 0;
   for (int s = 0; s < d->n_scales; ++s) {

@@ -51,3 +51,19 @@ def test_a_failing_rank_fails_the_run():
 def test_world_size_mismatch_is_refused():
     r = run(2, {"WORLD_SIZE": "3", "RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stderr + r.stdout)
+
+
+def test_a_rank_without_a_device_says_so_and_fails():
+    """"if the box exposes fewer devices than ranks, report the devices found".  On this host there are none: the real
+    rank body (no dry run) must leave with one clear line and a non-zero code, before any HIP call, instead of a bare runtime error."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "SFM_BENCH_DRYRUN"):
+        env.pop(k, None)
+    import torch
+    if torch.cuda.device_count() > 0:
+        import pytest
+        pytest.skip("this host has a GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "exposes 0 GPU(s)" in (r.stderr + r.stdout), (r.stdout[-500:], r.stderr[-500:])
+    assert not json_lines(r.stdout)

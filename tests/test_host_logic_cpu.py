@@ -3,6 +3,8 @@ type_check / argument / report / no_backprop_mode), the reference-named wrappers
 handling, batch sharding, the bench plumbing.  No kernel is launched."""
 import importlib
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -195,7 +197,10 @@ def test_rccl_binding_finds_the_library_torch_loaded():
     import importlib
     rccl = importlib.import_module("sfm-learner-chainer_amd.rccl")
     path = rccl._loaded_librccl()
-    assert path and "torch" in path, path
+    # torch's own copy where torch ships one (the copy that shares its HIP runtime), else the system library torch links
+    import torch
+    own = os.path.join(os.path.dirname(os.path.abspath(torch.__file__)), "lib", "librccl.so")
+    assert path and (os.path.dirname(os.path.abspath(path)) == os.path.dirname(own) if os.path.exists(own) else "librccl" in path), path
     L = rccl.lib()
     for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclAllReduce", "ncclCommDestroy", "ncclGetErrorString"):
         assert hasattr(L, name), name

@@ -27,11 +27,14 @@ synth = importlib.import_module(PKG + ".synth")
 
 def load(path):
     lib = C.CDLL(os.path.abspath(path), mode=os.RTLD_LOCAL)
-    for name in ("sfm_loss_workspace_bytes", "sfm_loss_workspace_init", "sfm_loss_fwd", "sfm_loss_bwd", "sfm_loss_fwd_bwd", "sfm_loss_profile_events"):
+    for name in ("sfm_loss_workspace_bytes", "sfm_loss_fwd", "sfm_loss_bwd", "sfm_loss_fwd_bwd", "sfm_loss_profile_events"):
         res, args = _lib.SYMBOLS[name]
-        fn = getattr(lib, name, None)      # (a build of ABI v4 has no sfm_loss_workspace_init: its workspace needs no preparation)
-        if fn is not None:
-            fn.restype, fn.argtypes = res, args
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    # (an experimental build may want its workspace prepared -- the round-5 in-launch finish did: profiles/r05_finish_in_launch.txt)
+    init = getattr(lib, "sfm_loss_workspace_init", None)
+    if init is not None:
+        init.restype, init.argtypes = C.c_int, [C.POINTER(_lib.SfmLossDesc), C.c_void_p, C.c_size_t, C.c_void_p]
     return lib
 
 

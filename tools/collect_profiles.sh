@@ -6,7 +6,7 @@
 #   usage: tools/collect_profiles.sh <tag> [workload=cfg3_edge] [layout=hwc] [mode=fused]
 #   e.g.   for w in cfg3_edge cfg3 cfg2 cfg5 cfg5_2src; do tools/collect_profiles.sh r04 $w; done; tools/collect_profiles.sh r04 cfg3_edge planar
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 WL=${2:-cfg3_edge}
 LAYOUT=${3:-hwc}
 MODE=${4:-fused}
