@@ -376,7 +376,7 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
   extern __shared__ float dsrc_tile[];
   if (DSRC && S.d_src) {
 #pragma unroll
-    for (int k = 0; k < DSRC_TILE_FLOATS / 64; ++k) dsrc_tile[k * 64 + lane] = 0.f;
+    for (int k = 0; k < dsrc_tile_floats(SSIM ? 8 : 4) / 64; ++k) dsrc_tile[k * 64 + lane] = 0.f;
   }
   // the disparities every source pass of this wave starts from (see ssim_source_pass / l1_source_pass): loaded once, now
   float disp_first, disp_second;
@@ -1143,7 +1143,7 @@ static hipError_t launch_main(const Plan& p, hipStream_t st, hipEvent_t ev_start
   // timestamps of THIS dispatch (what rocprofv3's kernel trace reports), and no marker packets are put between the
   // launches of a step (hipEventRecord on either side of the kernel costs the step several microseconds).
   // dynamic LDS: the accumulation window of the optional dL/d(src) output (sfm_ssim_pass.h, dsrc_scatter), only when it is bound
-  const size_t smem = (GRAD && p.dsrc) ? DSRC_TILE_FLOATS * sizeof(float) : 0;
+  const size_t smem = (GRAD && p.dsrc) ? dsrc_tile_floats(p.ssim ? 8 : 4) * sizeof(float) : 0;
   if (ev_start && ev_stop) return hipExtLaunchKernel(fn, dim3(8 * per_xcd), dim3(64 * WAVES_PER_BLOCK), kargs, smem, st, ev_start, ev_stop, 0);
   return hipLaunchKernel(fn, dim3(8 * per_xcd), dim3(64 * WAVES_PER_BLOCK), kargs, smem, st);
 }

@@ -45,7 +45,7 @@ struct SsimCtx {
   const float* sp[3];   // source planes of this (sample, source)
   const float* dp;      // disparity plane
   float* dsp;           // d_src planes of this (sample, source) or nullptr
-  float* dtile;         // with dsp: this wave's LDS accumulation window for dL/d(src) (DSRC_ROWS x 3 x DSRC_COLS floats, see dsrc_scatter)
+  float* dtile;         // with dsp: this wave's LDS accumulation window for dL/d(src) (rows x (3 planes + tags) x DSRC_COLS words, see dsrc_scatter)
   float* wp;            // planes of the optional warped-image output of this (sample, source), or nullptr   base_model.py:90-94
   const float* mp;      // explainability logits of this (sample, source) or nullptr     base_model.py:104
   float* dmp;           // their gradient plane or nullptr
@@ -529,75 +529,105 @@ __device__ __forceinline__ void zero(PoseAcc& a) {
 // dL/dI^ over the four taps of every sample, SURVEY.md App. A.3.  Straight to memory that is 12 global float atomics per warped pixel
 // and the cfg3 step takes 1.26 ms instead of 0.057 (round 5, profiles/r05_d_src.txt: what costs is the number of 64-byte atomic
 // requests, and a wave instruction whose lanes land in different source rows is up to 64 of them).  The wave therefore accumulates in
-// LDS where it can: a window of DSRC_ROWS source rows x DSRC_COLS columns x 3 channels that slides down the source image with the
-// wave's output rows (a source row receives from two consecutive output rows).  A row that leaves the window is added to memory
+// LDS where it can: a window of 8 (SSIM kernels) or 4 source rows x DSRC_COLS columns x 3 channels that slides down the source image
+// with the wave's output rows (a source row receives from two consecutive output rows).  A row that leaves the window is added to memory
 // ONCE -- one dense 256-byte atomic per 64 texels and channel -- and cleared.  Taps outside the window go to memory directly, as
 // before: the result is the same sum either way.  What the window catches depends on how far the taps of one row of samples spread
 // VERTICALLY, i.e. on the depth field: on synth's inputs (disparity 0.5 .. 9.5 with per-pixel noise: +-7 rows of parallax spread
-// inside a 60-pixel row segment at 128x416) 39 % of the taps at scale 0, 59 / 81 / 94 % at scales 1 / 2 / 3 -- the step 0.87 ms;
-// with every tap inside it would be 0.24 ms (the same launch with the direct path removed).
+// inside a 60-pixel row segment at 128x416 hold 83 % of the taps) roughly two thirds at scale 0 and nearly all at the small scales --
+// the cfg3 step 0.51 ms (profiles/r05_d_src.txt).
 // ------------------------------------------------------------------------------------------
-constexpr int DSRC_ROWS = 4, DSRC_COLS = 128;
-constexpr int DSRC_TILE_FLOATS = DSRC_ROWS * 3 * DSRC_COLS;
+// ------------------------------------------------------------------------------------------
+// Window geometry: DR source rows (a power of two: 8 in the SSIM kernels, which run two waves per SIMD, 4 in the others) x DSRC_COLS
+// columns; per texel three accumulators (planar: [row][channel][column]) and one TAG word (see below): 16 bytes.
+constexpr int DSRC_COLS = 96;
+__host__ __device__ constexpr int dsrc_tile_floats(const int dr) { return dr * 4 * DSRC_COLS; }
 
-// rows [v0, v1) of the window (at most DSRC_ROWS of them) -> memory, and cleared
+// rows [v0, v1) of the window (at most DR of them) -> memory, and cleared
+template <int DR>
 __device__ __forceinline__ void dsrc_flush(const SsimCtx& C, const int v0, const int v1, const int cb) {
   for (int v = v0; v < v1; ++v) {
-    float* row = C.dtile + (v & (DSRC_ROWS - 1)) * (3 * DSRC_COLS);
+    float* row = C.dtile + (v & (DR - 1)) * (3 * DSRC_COLS);
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int j = 0; j < DSRC_COLS / 64; ++j) {
-        float* t = row + c * DSRC_COLS + j * 64 + C.lane;
-        const float val = *t;
-        *t = 0.f;
-        // (a texel outside the image never received anything: taps are taken in view only)
-        if (val != 0.f) atomicAdd(C.dsp + (size_t)c * C.P + (unsigned)(v * C.w + cb + j * 64 + C.lane), val);
+      for (int j = 0; j < (DSRC_COLS + 63) / 64; ++j) {
+        const int col = j * 64 + C.lane;
+        if (col < DSRC_COLS) {
+          float* t = row + c * DSRC_COLS + col;
+          const float val = *t;
+          *t = 0.f;
+          // (a texel outside the image never received anything: taps are taken in view only)
+          if (val != 0.f) atomicAdd(C.dsp + (size_t)c * C.P + (unsigned)(v * C.w + cb + col), val);
+        }
       }
   }
 }
 
-__device__ __forceinline__ void dsrc_scatter(const SsimCtx& C, const Proj& p, const bool act, const float* gI, PoseAcc& gpm) {
-  const int big = 0x3fffffff;
-  const int vlo = wave_min_i(act ? p.v0 : big), vhi = wave_max_i(act ? p.v0 + 1 : -big);
-  if (vhi < vlo) return;                                   // (wave-uniform) no sample of this row is in view
-  if (gpm.dvb == DSRC_UNSET) {                             // first such row of the pass: place the window around its taps
-    const int ulo = wave_min_i(act ? p.u0 : big), uhi = wave_max_i(act ? p.u0 + 1 : -big);
-    gpm.dcb = ((ulo + uhi) >> 1) - DSRC_COLS / 2;
-    gpm.dvb = vlo;
+// One tap of every lane into the window.  ds_add_f32 would be the obvious instruction and is unusable: 564 cycles per wave
+// instruction per SIMD on gfx950 (profiles/r05_op_cost_microbench.txt; it cost round 2 a factor five on the pose sums).  Plain
+// read-add-write instead, made safe against two lanes of the SAME instruction landing on one texel (minification, folds) by a tag
+// word per texel: every pending lane writes its lane id, reads it back, and the lane whose id survived does its three
+// read-add-writes; the others go round again (wave-uniform loop; one trip unless lanes collide).  LDS operations of a wave execute
+// in order, and the window is private to the wave.
+template <int DR>
+__device__ __forceinline__ void dsrc_add(const SsimCtx& C, bool pend, const int slot /* row * DSRC_COLS + column */, const float* val) {
+  // (volatile: the read-back must come from LDS -- left to itself the compiler forwards the lane's own store to it)
+  volatile int* tag = reinterpret_cast<volatile int*>(C.dtile + DR * 3 * DSRC_COLS) + slot;
+  float* t = C.dtile + (slot / DSRC_COLS) * (3 * DSRC_COLS) + (slot % DSRC_COLS);
+  while (__builtin_amdgcn_ballot_w64(pend) != 0) {
+    if (pend) *tag = C.lane;
+    if (pend && *tag == C.lane) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) t[c * DSRC_COLS] += val[c];
+      pend = false;
+    }
   }
-  const int nvb = max(gpm.dvb, vhi - (DSRC_ROWS - 1));     // the window has to reach the lowest tap row
+}
+
+template <int DR>
+__device__ __forceinline__ void dsrc_scatter(const SsimCtx& C, const Proj& p, const bool act, const float* gI, PoseAcc& gpm) {
+  // the window follows the MEAN tap row of the wave's current output row (the spread around it is what the depth field makes it:
+  // anchored at the lowest tap row it would spend itself on the upper tail)
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(act);
+  if (m == 0) return;                                      // (wave-uniform) no sample of this row is in view
+  const int cnt = __builtin_popcountll(m);
+  const float vsum = wave_sum(act ? (float)p.v0 : 0.f);
+  const int vmid = (int)(vsum / (float)cnt);               // v0 >= 0 in view: truncation is floor
+  if (gpm.dvb == DSRC_UNSET) {                             // first such row of the pass: place the window around its taps
+    const float usum = wave_sum(act ? (float)p.u0 : 0.f);
+    gpm.dcb = (int)(usum / (float)cnt) - DSRC_COLS / 2 + 1;
+    gpm.dvb = vmid - DR / 2 + 1;
+  }
+  const int nvb = max(gpm.dvb, vmid - DR / 2 + 1);
   if (nvb > gpm.dvb) {
-    dsrc_flush(C, gpm.dvb, min(nvb, gpm.dvb + DSRC_ROWS), gpm.dcb);
+    dsrc_flush<DR>(C, gpm.dvb, min(nvb, gpm.dvb + DR), gpm.dcb);
     gpm.dvb = nvb;
   }
-  if (act) {
-    const float w00 = (1.f - p.fu) * (1.f - p.fv), w01 = p.fu * (1.f - p.fv), w10 = (1.f - p.fu) * p.fv, w11 = p.fu * p.fv;
-    const float wt[4] = {w00, w01, w10, w11};
+  const float w00 = (1.f - p.fu) * (1.f - p.fv), w01 = p.fu * (1.f - p.fv), w10 = (1.f - p.fu) * p.fv, w11 = p.fu * p.fv;
+  const float wt[4] = {w00, w01, w10, w11};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int v = p.v0 + (k >> 1), u = p.u0 + (k & 1);
-      const bool inside = (unsigned)(v - gpm.dvb) < (unsigned)DSRC_ROWS && (unsigned)(u - gpm.dcb) < (unsigned)DSRC_COLS;
-      if (inside) {
-        float* t = C.dtile + (v & (DSRC_ROWS - 1)) * (3 * DSRC_COLS) + (u - gpm.dcb);
+  for (int k = 0; k < 4; ++k) {
+    const int v = p.v0 + (k >> 1), u = p.u0 + (k & 1);
+    const bool inside = act && (unsigned)(v - gpm.dvb) < (unsigned)DR && (unsigned)(u - gpm.dcb) < (unsigned)DSRC_COLS;
+    const float val[3] = {gI[0] * wt[k], gI[1] * wt[k], gI[2] * wt[k]};
+    dsrc_add<DR>(C, inside, (v & (DR - 1)) * DSRC_COLS + (u - gpm.dcb), val);
+    if (act && !inside) {                                  // outside the window (above, below or beside it): straight to memory
+      float* ds = C.dsp + (unsigned)(v * C.w + u);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) __hip_atomic_fetch_add(t + c * DSRC_COLS, gI[c] * wt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      } else {
-        float* ds = C.dsp + (unsigned)(v * C.w + u);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) atomicAdd(ds + c * C.P, gI[c] * wt[k]);
-      }
+      for (int c = 0; c < 3; ++c) atomicAdd(ds + c * C.P, val[c]);
     }
   }
 }
 // end of a pass: what is left in the window
+template <int DR>
 __device__ __forceinline__ void dsrc_finish(const SsimCtx& C, const PoseAcc& gpm) {
-  if (C.dsp != nullptr && gpm.dvb != DSRC_UNSET) dsrc_flush(C, gpm.dvb, gpm.dvb + DSRC_ROWS, gpm.dcb);
+  if (C.dsp != nullptr && gpm.dvb != DSRC_UNSET) dsrc_flush<DR>(C, gpm.dvb, gpm.dvb + DR, gpm.dcb);
 }
 
 // From dL/dI^ of one pixel (already contracted with dI^/du, dI^/dv and 1/z into gq = (gq0, gq1)) to its
 // share of d_depth (LDS tile), of the 12 sums of dL/dPm and, optionally, of dL/d(src).
-template <bool DSRC>
+template <int DR /* rows of the dL/d(src) window; 0: the output is not produced */>
 __device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& s2, const int rc, const f2 gq,
                                                   const float* gI, float* gacc, const bool first, PoseAcc& gpm) {
   const int h = C.h, w = C.w;
@@ -625,10 +655,10 @@ __device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& 
   gpm.Cq += gq; gpm.C2 += gq2;
   // (DSRC: the instantiations a launch with SfmLossDesc.d_src bound runs.  A run-time branch here -- rounds 1-4 -- costs the kernels
   //  of every OTHER launch registers: with the window code behind it the SSIM gradient kernels spill 32 VGPRs)
-  if (DSRC && C.dsp != nullptr) {   // optional dL/d(src): scatter of dL/dI^ over the four taps, through the LDS window
+  if (DR != 0 && C.dsp != nullptr) {   // optional dL/d(src): scatter of dL/dI^ over the four taps, through the LDS window
     const float a0 = fmaf(C.M1[0], yf, C.mx[0]), a1 = fmaf(C.M1[1], yf, C.mx[1]), a2 = fmaf(C.M1[2], yf, C.mx[2]);
     const Proj p = project(a0, a1, a2, C.P3[0], C.P3[1], C.P3[2], s2.D, C.sc, h, w);
-    dsrc_scatter(C, p, p.inview && C.outf != 0.f, gI, gpm);
+    dsrc_scatter<DR == 0 ? 4 : DR>(C, p, p.inview && C.outf != 0.f, gI, gpm);
   }
 }
 
@@ -779,7 +809,7 @@ __device__ __forceinline__ void ssim_stage_c_row(const SsimCtx& C, const int rc,
   // and I^ - I is at hand (with the fused kernel stage B would form it a second time, one row earlier)
   if (LOSS) acc_pix = fmaf(vabs_sum(dp) + vabs_sum(ds), s2.nm * C.outf, acc_pix);
   const float gI[3] = {gp.x, gp.y, gs};
-  geometry_backward<DSRC>(C, s2, rc, contract_uv(s2, gp, gs), gI, gacc, first, gpm);
+  geometry_backward<DSRC ? 8 : 0>(C, s2, rc, contract_uv(s2, gp, gs), gI, gacc, first, gpm);
 }
 
 // Which stages run on which step of a pass, as bit k of one 32-bit word per question (a pass has at most 32 steps): every
@@ -884,7 +914,7 @@ __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, 
       ssim_row_step<GRAD, LOSS, HWC, WARPED, REF, DSRC>(C, M, k + 2, r + 2, ps, disp_next, S2, S1, S0, G2, G1, G0, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
   }
   if (GRAD) {
-    if (DSRC) dsrc_finish(C, gpm);
+    if (DSRC) dsrc_finish<8>(C, gpm);
     pose_sums_raw(C, gpm, gpm_out);
   }
 }
@@ -925,11 +955,11 @@ __device__ __forceinline__ void l1_source_pass(const SsimCtx& C, float* gacc, co
         // d/dlogit of (1-alpha) mean(err sigmoid) + exp_reg mean(softplus(-logit))
         if (C.outf != 0.f) stf_wt(C.dmp, (unsigned)r * (unsigned)C.w + C.xc, C.k_pix * e1 * sgm * (1.f - sgm) + C.k_exp * (sgm - 1.f));
       }
-      geometry_backward<DSRC>(C, s0, r, contract_uv(s0, gp, gs), gI, gacc, first, gpm);
+      geometry_backward<DSRC ? 4 : 0>(C, s0, r, contract_uv(s0, gp, gs), gI, gacc, first, gpm);
     }
   }
   if (GRAD) {
-    if (DSRC) dsrc_finish(C, gpm);
+    if (DSRC) dsrc_finish<4>(C, gpm);
     pose_sums_raw(C, gpm, gpm_out);
   }
 }
