@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import sfm_oracle as O
-from test_loss_gpu import CONFIGS, _bind, _check_grads, _check_losses, _oracle
+from test_loss_gpu import CONFIGS, KEYS, _bind, _check_grads, _check_losses, _oracle
 from util import to_np
 
 pytestmark = pytest.mark.gpu
@@ -182,6 +182,52 @@ def test_random_shapes_and_modes(ops, synth, dev, B, H, W, n_src, n_scales, cfg_
     from test_loss_gpu import pose_explained_by_discontinuities
     _check_grads(fl, ref, n_src, check_mask=bool(cfg.get("exp_reg")), what="sweep %s %dx%d" % (cfg_name, H, W), ref64=ref64,
                  explain=lambda i, got: pose_explained_by_discontinuities(d, cfg, ref, i, got))
+
+
+@pytest.mark.parametrize("B,H,W,n_src,n_scales,cfg_name", [(2, 14, 30, 2, 1, "ssim_smooth"), (3, 16, 26, 3, 1, "edge_aware"), (1, 12, 40, 2, 1, "l1_smooth")])
+def test_inadmissible_inputs_are_right_where_they_can_be(ops, synth, dev, B, H, W, n_src, n_scales, cfg_name):
+    """The sweep above re-draws an input whose knife-edge share is inadmissible (round-4 verdict: "the suite never shows what the
+    kernel does on an inadmissible input").  Here such inputs are SOUGHT -- tiny frames, where a handful of pixels on the strict
+    in-view test is percents of everything -- and the kernel is held to what holds on any input: the loss within 1e-4 plus the
+    ORACLE-side bound of what the pixels on the strict test can move it by; warped pixels zeroed differently only within 8e-6 of
+    that test and equal elsewhere by the criterion of _check_warped; every gradient finite; d_disp element-wise 2e-3 outside the
+    knife mask -- with NO cap on the mask's share, which is printed -- and d_pose within 5 % in relative L2 (its sums carry the
+    flipped pixels whole)."""
+    from test_loss_gpu import _check_warped, knife_cap, knife_mask, GRAD_TOL
+    from oracle.parity import rel_l2
+    from util import parity_note
+    cfg = CONFIGS[cfg_name]
+    found = None
+    for seed in range(300, 700):
+        d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=n_scales, seed=seed)
+        ref = O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], None, backward=True, keep_warped=True, **cfg)
+        flip_reach = sum(float((ref["margin"][s_] < 8e-6).sum()) * 3.0 / (B * ref["margin"][s_].shape[-2] * ref["margin"][s_].shape[-1])
+                         for s_ in range(n_scales))
+        over = any(knife_mask(ref, s_)[0].mean() > knife_cap(H * W) for s_ in range(n_scales))
+        if flip_reach > 5e-4 or over:
+            found = (seed, d, ref, flip_reach)
+            break
+    assert found is not None, "no inadmissible input among 400 seeds: the case no longer tests anything"
+    seed, d, ref, flip_reach = found
+    fl = _bind(ops, dev, d, cfg, layout="hwc", want_warped=True)
+    got = to_np(fl.forward_backward())
+    for k, name in enumerate(KEYS):
+        want = ref[name]
+        assert abs(got[k] - want) <= 1e-4 * max(abs(want), 1e-6) + flip_reach, (name, got[k], want, flip_reach)
+    n_flip = _check_warped(fl, ref, "INADMISSIBLE %s B=%d %dx%d seed %d" % (cfg_name, B, H, W, seed), d)
+    shares = []
+    for s_ in range(n_scales):
+        m = knife_mask(ref, s_)[0][:, None]
+        shares.append(float(m.mean()))
+        g, w = to_np(fl.d_disps[s_]), ref["d_disps"][s_]
+        assert np.isfinite(g).all()
+        err = np.abs(g - w) * ~m
+        assert err.max() <= GRAD_TOL * np.abs(w).max(), (s_, err.max() / np.abs(w).max())
+    l2 = max(rel_l2(to_np(g), w) for g, w in zip(fl.d_poses, ref["d_poses"]))
+    assert all(np.isfinite(to_np(g)).all() for g in fl.d_poses) and l2 <= 0.05, l2
+    parity_note("INADMISSIBLE input %s B=%d %dx%d seed %d: pixels on the strict test can move the loss by %.1e (admissible: 5e-4), knife share %s; "
+                "kernel: loss within 1e-4 + that bound, %d pixels zeroed differently, d_disp 2e-3 outside the (uncapped) mask, d_pose relative L2 %.1e" % (
+                    cfg_name, B, H, W, seed, flip_reach, ", ".join("%.2f %%" % (100 * v) for v in shares), n_flip, l2))
 
 
 @pytest.mark.parametrize("rows", [4, 28])
