@@ -721,7 +721,9 @@ def main():
             "timing": {"blocks": len(blocks), "steps_per_block": K, "timed_s": round(float(np.sum(blocks)), 4),
                        "ms_per_step_median": round(ms_step, 5), "ms_per_step_p10": round(float(np.percentile(per_step, 10)) * 1e3, 5),
                        "ms_per_step_p90": round(float(np.percentile(per_step, 90)) * 1e3, 5),
-                       "ms_per_step_first_block": round(float(per_step[0]) * 1e3, 5), "ms_per_step_min": round(float(per_step.min()) * 1e3, 5)},
+                       "ms_per_step_first_block": round(float(per_step[0]) * 1e3, 5), "ms_per_step_min": round(float(per_step.min()) * 1e3, 5),
+                       # the blocks in time order, thinned to at most 48 entries: how the box's state moved while it was measured
+                       "ms_per_step_series": [round(float(v) * 1e3, 4) for v in per_step[::max(1, len(per_step) // 48)]]},
             "roofline": roofline,
             "roofline_valu": roofline_valu,
             "roofline_valu_null_because": facts["stale"] if roofline_valu is None else None,
