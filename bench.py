@@ -336,14 +336,14 @@ def quick(torch, np, ev, runner, min_time=0.12, k=25):
             "step_roofline_frac": round((BYTES_FWD + BYTES_BWD) * runner.warped_px / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
-def link_path(torch, np, runner, min_time=0.12, k=25):
+def link_path(torch, np, runner, min_time=0.12, k=25, use_graph=False):
     """The drop-in path a user of the reference calls: SFMLearnerLoss.__call__ from FULL-RESOLUTION frames (pyramid
     launch included) + loss.backward() (models/base_model.py:48-124), buffers cached across calls."""
     links = importlib.import_module(PKG + ".links")
     cs = importlib.import_module(PKG + ".chainer_surface")
     r = runner
     model = links.SFMLearnerLoss(dict(seq_len=r.n_src + 1, smooth_reg=r.cfg.get("smooth_reg", 0.0), exp_reg=0.0,
-                                      ssim_rate=r.cfg.get("ssim_rate", 0.0)), smooth_mode=r.cfg.get("smooth_mode", "second_order"))
+                                      ssim_rate=r.cfg.get("ssim_rate", 0.0)), smooth_mode=r.cfg.get("smooth_mode", "second_order"), use_graph=use_graph)
     K, disps, poses = r.common
     vd, vp = [cs.Variable(a) for a in disps], [cs.Variable(a) for a in poses]
     tgt, src = r.full
@@ -655,6 +655,9 @@ def main():
                 guarded(name, lambda name=name: quick(torch, np, ev, Runner(torch, np, ops, synth, dev, name, args.layout, "fused")))
         # the drop-in link (pyramids + loss + backward, models/base_model.py:48-124) at the reference's own training batch
         guarded("ref_b4_link_ms_per_step", lambda: link_path(torch, np, Runner(torch, np, ops, synth, dev, "ref_b4", args.layout, "fused")))
+        # ... and with the link's HIP-graph replay (SFMLearnerLoss(use_graph=True): pyramid + loss launches of a call whose arrays repeat
+        # the previous call's addresses are replayed from one graph): what is left when the host side of the link is out of the way
+        guarded("ref_b4_link_graph_ms_per_step", lambda: link_path(torch, np, Runner(torch, np, ops, synth, dev, "ref_b4", args.layout, "fused"), use_graph=True))
         # north_star's backward "scatters dL/d(depth, pose, src_img)": the same step with the OPTIONAL d_src output bound (the reference
         # discards it in training, base_model.py:71-72 `.data`; NULL is the default) -- 12 global float atomics per warped pixel
         guarded("cfg3_d_src", lambda: quick(torch, np, ev, Runner(torch, np, ops, synth, dev, args.workload, args.layout, "fused", args.batch, want_d_src=True)))

@@ -60,22 +60,34 @@ class InvalidType(TypeError):
     """chainer.utils.type_check.InvalidType"""
 
 
+_DTYPE_CHARS = {torch.float32: "f", torch.float64: "d", torch.float16: "e", torch.int32: "i", torch.int64: "l", torch.bool: "?"}
+
+
 class _DType:
     def __init__(self, t):
         self._t = t
-        self.char = {torch.float32: "f", torch.float64: "d", torch.float16: "e", torch.int32: "i",
-                     torch.int64: "l", torch.bool: "?"}.get(t, "O")
+        self.char = _DTYPE_CHARS.get(t, "O")
         self.kind = "f" if t.is_floating_point else "i"
 
     def __eq__(self, other):
         return other is self._t or getattr(other, "_t", None) is self._t or other == self.char
 
+    __hash__ = None
+
+
+_DTYPES = {}     # one _DType per torch dtype: a Function call builds a _TypeInfo per input, every call (the link: six per step)
+
 
 class _TypeInfo:
+    __slots__ = ("shape", "ndim", "dtype", "name")
+
     def __init__(self, a, name):
         self.shape = tuple(a.shape)
         self.ndim = a.dim()
-        self.dtype = _DType(a.dtype)
+        dt = _DTYPES.get(a.dtype)
+        if dt is None:
+            dt = _DTYPES[a.dtype] = _DType(a.dtype)
+        self.dtype = dt
         self.name = name
 
 

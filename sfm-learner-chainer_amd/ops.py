@@ -215,14 +215,31 @@ def pyramid_pair_hwc(tgt, src, n_scales, out=None, per_pixel=False):
         yt, ys = out
         if len(yt) != n_scales or tuple(yt[0].shape) != (N, 1, H, W, 3) or tuple(ys[0].shape) != (N, n_src, H, W, 3):
             raise TypeError("pyramid_pair_hwc: `out` does not match the inputs")
+        ptrs = getattr(out, "_ptrs", None)      # (the pointer arrays of buffers this function allocated: built once, a step is 15-60 us)
     else:
         yt = [torch.empty((N, 1, H >> s, W >> s, 3), dtype=torch.float32, device=tgt.device) for s in range(n_scales)]
         ys = [torch.empty((N, n_src, H >> s, W >> s, 3), dtype=torch.float32, device=tgt.device) for s in range(n_scales)]
-    with torch.cuda.device(tgt.device):
+        out, ptrs = _PyramidPair((yt, ys)), None
+    if ptrs is None:
+        ptrs = (_ptr_array(yt), _ptr_array(ys))
+        if isinstance(out, _PyramidPair):
+            out._ptrs = ptrs
+    idx = tgt.device.index
+    if torch.cuda.current_device() == idx:
         if per_pixel:
             check(lib.sfm_pyramid_variant(1))
-        check(lib.sfm_pyramid_pair_hwc_fwd(_p(tgt), _p(src), _ptr_array(yt), _ptr_array(ys), N, n_src, H, W, n_scales, _stream()))
-    return yt, ys
+        check(lib.sfm_pyramid_pair_hwc_fwd(_p(tgt), _p(src), ptrs[0], ptrs[1], N, n_src, H, W, n_scales, _stream(idx)))
+    else:
+        with torch.cuda.device(tgt.device):
+            if per_pixel:
+                check(lib.sfm_pyramid_variant(1))
+            check(lib.sfm_pyramid_pair_hwc_fwd(_p(tgt), _p(src), ptrs[0], ptrs[1], N, n_src, H, W, n_scales, _stream(idx)))
+    return out
+
+
+class _PyramidPair(tuple):
+    """(tgt pyramid, src pyramid) as `pyramid_pair_hwc` returns it; carries the ctypes pointer arrays of its buffers so that a caller
+    that hands it back as `out` does not pay for rebuilding them every step."""
 
 
 def to_hwc(x):

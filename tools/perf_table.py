@@ -84,7 +84,8 @@ out = ["| workload | ms/step | Mpix/s | dominant kernel us: HIP events / rocprof
        "|---|---|---|---|---|---|"] + rows
 extra = []
 for key, label in (("graph_ms_per_step", "the headline step replayed from a HIP graph"), ("link_ms_per_step", "through the drop-in link `SFMLearnerLoss` (pyramids + loss + backward), cfg3 as written"),
-                   ("ref_b4_link_ms_per_step", "through the link at the reference's training batch (B=4, L1 only)")):
+                   ("ref_b4_link_ms_per_step", "through the link at the reference's training batch (B=4, L1 only)"),
+                   ("ref_b4_link_graph_ms_per_step", "... the same with `SFMLearnerLoss(use_graph=True)` (HIP-graph replay of the call)")):
     if isinstance(b.get(key), (int, float)):
         extra.append("| %s | %.4f | - | - | - | - |" % (label, b[key]))
 out += extra
