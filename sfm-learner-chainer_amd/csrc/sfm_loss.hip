@@ -606,11 +606,46 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const Los
     // up to two rounds of loads one wave does alone (cfg3: the block's other waves leave at once, no LDS, no barrier: 1 us
     // faster than sharing); more are spread over all the waves of the block
     const int nw = total > 128 ? FINALIZE_WAVES : 1;    // block-uniform
+    // One-wave blocks (cfg3) get a HELPER: wave 1 builds the Jacobian of the Euler chain, dR/d(theta_k) with the clip mask of
+    // transform.py:23 folded in, while wave 0 waits for the partials and folds them -- the rotation (a load round trip + ~150
+    // dependent instructions) was on wave 0's path between the arrival of the pose and the fold: 0.45 us of a 3.1 us chain, and the
+    // 150-instruction pose_backward at its end becomes 27 multiply-adds (stamps: tools/trace_finalize.py).
+    const bool helper = nw == 1 && wave == 1;
+    __shared__ float jac[27];
+    if (helper) {
+      const float pi = 3.14159265358979323846f;
+      float ang[3], sn[3], cs[3], msk[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ang[k] = pp[b * 6 + k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        sincos_pi(fminf(fmaxf(ang[k], -pi), pi), &sn[k], &cs[k]);
+        msk[k] = (ang[k] > -pi && ang[k] < pi) ? 1.f : 0.f;        // F.clip backward
+      }
+      const float X[9] = {1.f, 0.f, 0.f, 0.f, cs[0], -sn[0], 0.f, sn[0], cs[0]}, dX[9] = {0.f, 0.f, 0.f, 0.f, -sn[0], -cs[0], 0.f, cs[0], -sn[0]};
+      const float Y[9] = {cs[1], 0.f, sn[1], 0.f, 1.f, 0.f, -sn[1], 0.f, cs[1]}, dY[9] = {-sn[1], 0.f, cs[1], 0.f, 0.f, 0.f, -cs[1], 0.f, -sn[1]};
+      const float Z[9] = {cs[2], -sn[2], 0.f, sn[2], cs[2], 0.f, 0.f, 0.f, 1.f}, dZ[9] = {-sn[2], -cs[2], 0.f, cs[2], -sn[2], 0.f, 0.f, 0.f, 0.f};
+      float XY[9], dXY[9], XdY[9], J[27];
+      mat3_mul(X, Y, XY);
+      mat3_mul(dX, Y, dXY);
+      mat3_mul(X, dY, XdY);
+      mat3_mul(dXY, Z, J);          // dR/d(theta_x) = (X' Y) Z      (R = (X Y) Z, transform.py:39)
+      mat3_mul(XdY, Z, J + 9);      // dR/d(theta_y) = (X Y') Z
+      mat3_mul(XY, dZ, J + 18);     // dR/d(theta_z) = (X Y) Z'
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 27; ++k) jac[k] = J[k] * msk[k / 9];
+      }
+      __syncthreads();
+      return;
+    }
     if (wave >= nw) return;
     if (stamp) SFM_FSTAMP(1);
-    float pose6[6];
+    float pose6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (nw > 1) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) pose6[k] = pp[b * 6 + k];
+      for (int k = 0; k < 6; ++k) pose6[k] = pp[b * 6 + k];
+    }
     float gT3[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) gT3[k] = 0.f;
@@ -652,7 +687,7 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const Los
     if (has0) SFM_FIN_FETCH(idx0, a0, a1, a2, Ka)
     if (has1) SFM_FIN_FETCH(idx1, c0, c1, c2, Kc)
     Rot rot;
-    if (wave == 0) euler2mat(pose6, rot);      // (wave-uniform; the result is only read by lane 0 of wave 0)
+    if (nw > 1 && wave == 0) euler2mat(pose6, rot);      // (wave-uniform; the result is only read by lane 0 of wave 0)
 #ifdef SFM_FIN_STAMPS
     if (stamp && rot.R[0] != 77.f) SFM_FSTAMP(2);
 #endif
@@ -688,6 +723,28 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const Los
 #ifdef SFM_FIN_STAMPS
     if (stamp && gT[0] != 77.f) SFM_FSTAMP(4);
 #endif
+    if (nw == 1) {         // the helper's Jacobian: d_pose[k] = <dL/dR, dR/d(theta_k)>, d_pose[3 + k] = dL/dt_k
+      __syncthreads();
+      if (lane == 0) {
+        float d[6];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          float a = 0.f;
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a = fmaf(gT[r * 4 + c], jac[k * 9 + r * 3 + c], a);
+          d[k] = a;
+          d[3 + k] = gT[k * 4 + 3];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dp[b * 6 + k] = d[k];
+#ifdef SFM_FIN_STAMPS
+        if (stamp && d[0] != 77.f) SFM_FSTAMP(5);
+#endif
+      }
+      return;
+    }
     if (lane == 0) {
       float d[6];
       pose_backward(pose6, rot, gT, d);
