@@ -53,7 +53,9 @@ COLLECTIVE_NOTES = {
 }
 VARIANT_KEYS = {"step": "per_step_collective_variant", "interval": "interval_variant", "step_torch": "per_step_torch_variant"}
 
-SYNTH_KW = {"cfg3_large_motion": dict(rot_sigma=0.05, trans_sigma=0.10)}   # everything else: synth.make_inputs' defaults
+SMOOTH_DISP = dict(disp_div=32, disp_noise=0.0)
+SYNTH_KW = {"cfg3_large_motion": dict(rot_sigma=0.05, trans_sigma=0.10),   # everything else: synth.make_inputs' defaults
+            "cfg3_smooth_disp": SMOOTH_DISP, "cfg5_2src_smooth_disp": SMOOTH_DISP}
 
 WORKLOADS = {
     # name: (B per GPU, H, W, n_src, n_scales, loss config, description)
@@ -74,6 +76,11 @@ WORKLOADS = {
              "BASELINE cfg5: B=8, 256x832, 5-frame (4 src), 4 scales"),
     "cfg5_2src": (8, 256, 832, 2, 4, dict(smooth_reg=0.1, ssim_rate=0.15),
                   "BASELINE cfg5 as parenthesised: B=8, 256x832, 2 src, 4 scales"),
+    "cfg3_smooth_disp": (32, 128, 416, 2, 4, dict(smooth_reg=0.1, ssim_rate=0.15, smooth_mode="edge_aware"),
+                         "BASELINE cfg3 as written on a SMOOTH disparity field (logit low-passed at 1/32 of the resolution, no per-pixel noise, "
+                         "instead of synth's default 1/4 + 0.1 N(0,1): neighbouring samples' taps stay in neighbouring texels)"),
+    "cfg5_2src_smooth_disp": (8, 256, 832, 2, 4, dict(smooth_reg=0.1, ssim_rate=0.15),
+                              "BASELINE cfg5 as parenthesised (B=8, 256x832, 2 src) on the SMOOTH disparity field"),
     "ref_b4": (4, 128, 416, 2, 4, dict(),
                "the regime the reference TRAINS in: B=4 (experiments/sfm_learner_v1.yml:43 train_batchsize), 128x416, 4 scales, 2 src, its live "
                "loss (smooth_reg 0, exp_reg 0: L1 only, :14-16)"),
@@ -650,7 +657,7 @@ def main():
                                                                     "separate" if args.mode == "fused" else "fused", args.batch)))
         guarded("graph_ms_per_step", lambda: graph_path(torch, np, R))
         guarded("link_ms_per_step", lambda: link_path(torch, np, R))
-        for name in ("cfg3", "cfg3_edge", "cfg3_large_motion", "cfg2", "cfg5", "cfg5_2src", "cfg1", "ref_b4"):
+        for name in ("cfg3", "cfg3_edge", "cfg3_large_motion", "cfg3_smooth_disp", "cfg2", "cfg5", "cfg5_2src", "cfg5_2src_smooth_disp", "cfg1", "ref_b4"):
             if name != args.workload:
                 guarded(name, lambda name=name: quick(torch, np, ev, Runner(torch, np, ops, synth, dev, name, args.layout, "fused")))
         # the drop-in link (pyramids + loss + backward, models/base_model.py:48-124) at the reference's own training batch
@@ -661,6 +668,8 @@ def main():
         # north_star's backward "scatters dL/d(depth, pose, src_img)": the same step with the OPTIONAL d_src output bound (the reference
         # discards it in training, base_model.py:71-72 `.data`; NULL is the default) -- 12 global float atomics per warped pixel
         guarded("cfg3_d_src", lambda: quick(torch, np, ev, Runner(torch, np, ops, synth, dev, args.workload, args.layout, "fused", args.batch, want_d_src=True)))
+        # ... and on the smooth disparity field, where the taps of a row of samples stay inside the wave's LDS accumulation window
+        guarded("cfg3_d_src_smooth_disp", lambda: quick(torch, np, ev, Runner(torch, np, ops, synth, dev, "cfg3_smooth_disp", args.layout, "fused", want_d_src=True)))
 
     for e4 in events.values():
         for e in e4:

@@ -73,7 +73,7 @@ def _shift_replicate(x, sx, sy):
 
 
 def make_inputs(B=2, H=128, W=416, n_src=2, n_scales=4, seed=1, with_masks=False,
-                rot_sigma=0.01, trans_sigma=0.02, seam="roll"):
+                rot_sigma=0.01, trans_sigma=0.02, seam="roll", disp_div=4, disp_noise=0.1):
     """Returns a dict of float32 C-contiguous arrays:
 
     tgt (B,3,H,W); src (B,n_src,3,H,W); tgt_pyr[s] (B,3,h,w); src_pyr[s] (B,3n,h,w);
@@ -83,6 +83,12 @@ def make_inputs(B=2, H=128, W=416, n_src=2, n_scales=4, seed=1, with_masks=False
     (np.roll: the sources carry a seam of full contrast a few pixels from two of their borders -- the inputs of rounds 1-4,
     kept: a step edge is the hardest case for a bilinear sampler's position accuracy); "shift" replicates the border instead
     (no seam: image-like texture everywhere).  Same random draws in both, so everything else is identical.
+
+    disp_div, disp_noise: the disparity logit is uniform noise at 1/disp_div of the scale's resolution, bilinearly upsampled, plus
+    disp_noise * N(0,1) per pixel.  The defaults (4, 0.1: the inputs of every round's headline) make a ROUGH field -- the disparity
+    swings over most of its range within four pixels, so that neighbouring samples' taps lie several source rows apart (what a
+    bilinear gather and the optional d_src scatter pay for: profiles/r05_d_src.txt).  (32, 0.0) is a field as smooth as a network's
+    disparity map away from object boundaries; bench.py reports both (`*_smooth_disp`).  Same random draws either way.
     """
     if seam not in ("roll", "shift"):
         raise ValueError("seam must be 'roll' or 'shift', got %r" % (seam,))
@@ -117,7 +123,7 @@ def make_inputs(B=2, H=128, W=416, n_src=2, n_scales=4, seed=1, with_masks=False
     disps, masks = [], []
     for s in range(n_scales):
         h, w = H // (2 ** s), W // (2 ** s)
-        n = _smooth_field(rng, B, 1, h, w, 4) * 1.5 + 0.1 * rng.standard_normal(size=(B, 1, h, w)).astype(np.float32)
+        n = _smooth_field(rng, B, 1, h, w, disp_div) * 1.5 + np.float32(disp_noise) * rng.standard_normal(size=(B, 1, h, w)).astype(np.float32)
         disps.append(np.ascontiguousarray(10.0 / (1.0 + np.exp(-n)) + 0.01, dtype=np.float32))
         if with_masks:
             masks.append(np.ascontiguousarray(

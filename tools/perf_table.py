@@ -64,14 +64,17 @@ if drv:
     row("... with the driver's `--steps 20 --warmup 5`", drv["ms_per_step"], drv["value"], drv["roofline"]["kernel_ms"] * 1e3, None, drv["roofline"]["frac"], drv["step_roofline_frac"])
 NAMES = [("cfg3", "cfg3, 2nd-order smoothness (the reference's live code)", "cfg3_hwc_fused"),
          ("cfg3_large_motion", "cfg3 as written, large-motion inputs", None),
+         ("cfg3_smooth_disp", "cfg3 as written on a SMOOTH disparity field (logit low-passed at 1/32 of the resolution, no per-pixel noise)", None),
          ("other_layout", "cfg3 as written, planar layout", "cfg3_edge_planar_fused"),
          ("other_mode", "cfg3 as written, separate fwd + bwd", "cfg3_edge_hwc_separate"),
          ("cfg2", "cfg2 B=8, L1 + smoothness", "cfg2_hwc_fused"),
          ("cfg5", "cfg5 B=8 256x832, 4 src", "cfg5_hwc_fused"),
          ("cfg5_2src", "cfg5 as parenthesised (2 src)", "cfg5_2src_hwc_fused"),
+         ("cfg5_2src_smooth_disp", "cfg5 as parenthesised (2 src) on the smooth disparity field", None),
          ("cfg1", "cfg1 B=1, 1 scale, L1", None),
          ("ref_b4", "the reference's training regime: B=4, 4 scales, L1 only (`sfm_learner_v1.yml`)", "ref_b4_hwc_fused"),
-         ("cfg3_d_src", "cfg3 as written with the optional dL/d(src) bound", None)]
+         ("cfg3_d_src", "cfg3 as written with the optional dL/d(src) bound", None),
+         ("cfg3_d_src_smooth_disp", "... the same on the smooth disparity field", None)]
 for key, label, variant in NAMES:
     q = b.get(key)
     if not isinstance(q, dict) or "ms_per_step" not in q:
