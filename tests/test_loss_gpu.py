@@ -678,6 +678,29 @@ def test_warped_pixels_meet_the_flat_tolerance_on_seam_free_inputs(ops, synth, d
     _check_warped(fl, ref, "SEAM-FREE %s B=%d %dx%d hwc" % (cfg_name, B, H, W), d, flat=True)
 
 
+@pytest.mark.parametrize("cfg_name,B,H,W", [
+    ("edge_aware", 4, 128, 416),     # BASELINE cfg3 as written, oracle-sized batch
+    ("ssim_smooth", 2, 256, 832),    # the 256x832 frame of cfg5 (2 sources)
+])
+def test_smooth_disparity_field_vs_oracle(ops, synth, dev, cfg_name, B, H, W):
+    """The inputs of bench.py's `*_smooth_disp` keys (synth.make_inputs(disp_div=32, disp_noise=0): a disparity field as smooth as a
+    network's away from object boundaries; neighbouring samples' taps stay in neighbouring texels, which is where the gather runs
+    8-15 % faster, profiles/r05_process_modes.txt 3.) against the oracle: the five scalars, the warped pixels and every gradient by the
+    criteria of the default (rough) field -- a coherent warp is a different regime of the same kernel (in-view sets with long straight
+    borders, cell boundaries crossed by whole runs of lanes at once), not an easier one."""
+    cfg = CONFIGS[cfg_name]
+    d = synth.make_inputs(B=B, H=H, W=W, n_src=2, n_scales=4, seed=1, disp_div=32, disp_noise=0.0)
+    ref = _oracle(d, cfg)
+    fl = _bind(ops, dev, d, cfg, layout="hwc", want_warped=True)
+    what = "SMOOTH DISPARITY %s B=%d %dx%d hwc" % (cfg_name, B, H, W)
+    _check_losses(fl.forward_backward(), ref)
+    _check_warped(fl, ref, what + " [sfm_loss_fwd_bwd]", d)
+    ref64 = lambda: O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], None, backward=True,
+                               dtype=np.float64, **cfg)
+    _check_grads(fl, ref, 2, what=what, ref64=ref64, **knife_widths(d, ref))
+    count_in_view_mismatches(ops, dev, d, ref, "hwc", what)
+
+
 def test_warped_pixels_at_256x832_on_seam_free_inputs(ops, synth, dev):
     """BASELINE cfg5 (B=8, 256x832, 4 sources) on seam-free inputs.  At U ~ 800 one ulp of a sampling position is 6e-5 px and two
     correct fp32 evaluations of it lie up to 3e-4 px apart: the product kernel is held to a flat 2e-4 of the range with at most
