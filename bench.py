@@ -510,6 +510,12 @@ def main():
                  "(not measured, not a failure of the path)" % (args.gpus, rank, local, devices_found, args.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # Experiment knob (profiles/r05_process_modes.txt): SFM_BENCH_ARENA_GB=g reserves ONE g-GiB block with the caching allocator before
+    # anything else is allocated and hands it back to the allocator's pool, so that every array of the run is carved out of one
+    # hipMalloc (one contiguous mapping) instead of a dozen separate ones.
+    if os.environ.get("SFM_BENCH_ARENA_GB"):
+        arena = torch.empty((int(float(os.environ["SFM_BENCH_ARENA_GB"]) * (1 << 30)),), dtype=torch.uint8, device=dev)
+        del arena
     use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ     # under torch.distributed.run, also at N = 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
