@@ -30,7 +30,7 @@ run(); torch.cuda.synchronize()
 raw = buf.cpu().numpy()
 nz = int((raw != 0).any(axis=1).sum())
 if os.environ.get("SFM_TRACE_DUMP"):
-    np.save(os.environ["SFM_TRACE_DUMP"], raw[:nz])
+    np.save(os.environ["SFM_TRACE_DUMP"], raw if os.environ.get("SFM_TRACE_DUMP_FULL") else raw[:nz])
 stamps = os.environ.get("SFMWARP_LIB", "").endswith("stamps.so")
 SW = int(os.environ.get('SFM_STAMP_WORDS', '8'))
 n_items = int(os.environ['SFM_TRACE_ITEMS']) if 'SFM_TRACE_ITEMS' in os.environ else (nz // (1 + SW // 4) if stamps else nz)
