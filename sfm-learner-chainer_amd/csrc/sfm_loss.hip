@@ -571,14 +571,50 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 constexpr int FINALIZE_WAVES = 16;   // waves of the block that sums the loss partials (the pose blocks use one)
 
-__global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const LossArgs A, float* __restrict__ loss5, const int n_pose_blocks) {
+// The first fourteen dwords of the argument block are PRELOADED into scalar registers by the dispatcher (-mllvm
+// -amdgpu-kernarg-preload-count=14 in the Makefile; every other kernel of this file takes one by-value struct, which is never preloaded):
+// what a pose block needs to form the addresses of its first loads is there when the wave starts, instead of one scalar round trip
+// later (tools/anyorder_probe.hip: 0.15 us per kernel on this stack; stamps of this kernel: 0.5 us from its start to "tiles known").
+//   q_bsc: B | n_src << 16 | n_scales << 20 | COMPACT << 24 | POSE << 25 | LOSS << 26;  q_t01 .. q_t67: tiles_of[] as 16-bit halves;
+//   q_loss_back: bytes from part_loss up to part_gpm (both lie in the caller's workspace: the loss block's pointer without a round trip).
+// COMPACT = 0 (a tile count or B beyond 16 bits: planar frames of tens of megapixels): the fields are read from the struct, as before.
+constexpr unsigned FIN_COMPACT = 1u << 24, FIN_POSE = 1u << 25, FIN_LOSS = 1u << 26;
+__global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const float* __restrict__ q_gpm, const float* __restrict__ q_intr,
+                                                                       const float* __restrict__ q_pose0, const float* __restrict__ q_pose1,
+                                                                       const unsigned q_bsc, const unsigned q_t01, const unsigned q_t23,
+                                                                       const unsigned q_t45, const unsigned q_t67, const unsigned q_loss_back,
+                                                                       const LossArgs A, float* __restrict__ loss5) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  static_assert(SFM_MAX_SCALES == 8, "four packed words of tile counts");
+  const bool compact = (q_bsc & FIN_COMPACT) != 0;
+  int hB, h_src, h_scales, h_items, tlh[SFM_MAX_SCALES], ibh[SFM_MAX_SCALES];
+  const float *h_gpm, *h_intr, *h_loss;
+  if (compact) {          // (uniform)
+    hB = (int)(q_bsc & 0xffffu); h_src = (int)((q_bsc >> 16) & 0xfu); h_scales = (int)((q_bsc >> 20) & 0xfu);
+    const unsigned tw[4] = {q_t01, q_t23, q_t45, q_t67};
+    int run = 0;
+#pragma unroll
+    for (int k = 0; k < SFM_MAX_SCALES; ++k) {
+      tlh[k] = (int)((tw[k >> 1] >> (16 * (k & 1))) & 0xffffu);
+      ibh[k] = run;                              // make_plan: item_begin of a scale = B x the tiles of the scales before it
+      run += hB * tlh[k];
+    }
+    h_items = run;
+    h_gpm = q_gpm; h_intr = q_intr;
+    h_loss = reinterpret_cast<const float*>(reinterpret_cast<const char*>(q_gpm) - q_loss_back);
+  } else {
+    hB = A.B; h_src = A.n_src; h_scales = A.n_scales;
+#pragma unroll
+    for (int k = 0; k < SFM_MAX_SCALES; ++k) { tlh[k] = A.tiles_of[k]; ibh[k] = A.item_begin_of[k]; }
+    h_gpm = A.part_gpm; h_intr = A.intrinsics; h_loss = A.part_loss; h_items = A.items;
+  }
+  const int n_pose_blocks = (q_bsc & FIN_POSE) ? hB * h_src : 0;
   if ((int)blockIdx.x < n_pose_blocks) {
     // d_pose of (b, i): every lane folds its tiles of every scale into K_s^T . gPm (linear), one in-register wave reduction (DPP).
     // A sample with many tiles (308 at cfg2, 376 at cfg5) is spread over the sixteen waves of the block, so that its partials are
     // fetched in ONE round of independent loads instead of up to six dependent rounds (-1 us on those steps); the waves' sums meet
     // in LDS and are added in wave order: a fixed order, the result does not depend on timing.
-    const int b = blockIdx.x / A.n_src, i = blockIdx.x - b * A.n_src;
+    const int b = blockIdx.x / h_src, i = blockIdx.x - b * h_src;
     const bool stamp = blockIdx.x == 0;
     if (stamp) SFM_FSTAMP(0);
     __shared__ float pose_red[FINALIZE_WAVES][12];
@@ -589,16 +625,24 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const Los
     // rotation (euler2mat: ~150 dependent instructions) under the shadow of the partials.
     int tl[SFM_MAX_SCALES], ib[SFM_MAX_SCALES];
 #pragma unroll
-    for (int k = 0; k < SFM_MAX_SCALES; ++k) { tl[k] = A.tiles_of[k]; ib[k] = A.item_begin_of[k]; }
+    for (int k = 0; k < SFM_MAX_SCALES; ++k) { tl[k] = tlh[k]; ib[k] = ibh[k]; }
     const float* pp = nullptr;
     float* dp = nullptr;
 #pragma unroll
     for (int k = 0; k < SFM_MAX_SRC; ++k) {
-      const float* pk = A.pose[k];
-      float* dk = A.d_pose[k];
-      asm volatile("" : "+s"(pk), "+s"(dk));   // (keeps the selection from being folded back into an indexed load)
-      pp = (i == k) ? pk : pp;
+      float* dk = A.d_pose[k];                 // (needed at the very end: its round trip hides behind everything else)
+      asm volatile("" : "+s"(dk));             // (keeps the selection from being folded back into an indexed load)
       dp = (i == k) ? dk : dp;
+    }
+    if (compact && i < 2) {                    // (uniform) the pose pointers of the first two sources are preloaded
+      pp = (i == 0) ? q_pose0 : q_pose1;
+    } else {
+#pragma unroll
+      for (int k = 0; k < SFM_MAX_SRC; ++k) {
+        const float* pk = A.pose[k];
+        asm volatile("" : "+s"(pk));
+        pp = (i == k) ? pk : pp;
+      }
     }
     int total = 0;
 #pragma unroll
@@ -639,7 +683,11 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const Los
       __syncthreads();
       return;
     }
-    if (wave >= nw) return;
+    // ... and, when the sample has more than 64 tiles (cfg3: 96), a SECOND folding wave: wave 2 takes the tiles from 64 on, so that no lane
+    // folds two tiles one after the other (a fold is ~110 dependent instructions, 0.3 us of the 2.5 us chain); its twelve sums reach wave 0
+    // through LDS behind the barrier the helper needs anyway, and are added after wave 0's own: a fixed order.
+    const bool second = nw == 1 && wave == 2 && total > 64;
+    if (wave >= nw && !second) return;
     if (stamp) SFM_FSTAMP(1);
     float pose6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (nw > 1) {
@@ -658,9 +706,9 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const Los
         if ((idx_) >= off_ + tl[k] && s_ == k) { off_ += tl[k]; s_ = k + 1; }                                                     \
     int ibs_ = ib[0], tls_ = tl[0];                                                                                               \
     _Pragma("unroll") for (int k = 1; k < SFM_MAX_SCALES; ++k) { ibs_ = (s_ == k) ? ib[k] : ibs_; tls_ = (s_ == k) ? tl[k] : tls_; } \
-    const float4* p_ = reinterpret_cast<const float4*>(A.part_gpm + ((size_t)(ibs_ + b * tls_ + ((idx_) - off_)) * A.n_src + i) * 12); \
+    const float4* p_ = reinterpret_cast<const float4*>(h_gpm + ((size_t)(ibs_ + b * tls_ + ((idx_) - off_)) * h_src + i) * 12);  \
     v0_ = p_[0]; v1_ = p_[1]; v2_ = p_[2];                                                                                        \
-    const float* Kp_ = A.intrinsics + ((size_t)b * A.n_scales + s_) * 9;                                                          \
+    const float* Kp_ = h_intr + ((size_t)b * h_scales + s_) * 9;                                                                  \
     _Pragma("unroll") for (int k = 0; k < 9; ++k) K_[k] = Kp_[k];                                                                 \
   }
     // the tile's raw pose sums S_k = (sum x A_k, B_k, A_k, C_k) (pose_sums_raw) -> dL/dPm[k][j] = Kinv[j] . S_k[0:3], [k][3] = S_k[3];
@@ -680,8 +728,8 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const Los
             gT3[r * 4 + c] += K_[0 * 3 + r] * g_[0 * 4 + c] + K_[1 * 3 + r] * g_[1 * 4 + c] + K_[2 * 3 + r] * g_[2 * 4 + c];      \
   }
     const int stride = 64 * nw;
-    const int idx0 = threadIdx.x, idx1 = idx0 + stride;
-    const bool has0 = idx0 < total, has1 = idx1 < total;
+    const int idx0 = nw == 1 ? lane + (second ? 64 : 0) : (int)threadIdx.x, idx1 = idx0 + stride;
+    const bool has0 = idx0 < total, has1 = nw > 1 && idx1 < total;      // (one-wave blocks: the tiles from 64 on belong to wave 2)
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, c0 = a0, c1 = a0, c2 = a0;
     float Ka[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, Kc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (has0) SFM_FIN_FETCH(idx0, a0, a1, a2, Ka)
@@ -693,10 +741,11 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const Los
 #endif
     if (has0) SFM_FIN_FOLD(a0, a1, a2, Ka)
     if (has1) SFM_FIN_FOLD(c0, c1, c2, Kc)
-    for (int idx = idx1 + stride; idx < total; idx += stride) {   // (samples of more than 2048 tiles)
-      SFM_FIN_FETCH(idx, a0, a1, a2, Ka)
-      SFM_FIN_FOLD(a0, a1, a2, Ka)
-    }
+    if (nw > 1)
+      for (int idx = idx1 + stride; idx < total; idx += stride) {   // (samples of more than 2048 tiles)
+        SFM_FIN_FETCH(idx, a0, a1, a2, Ka)
+        SFM_FIN_FOLD(a0, a1, a2, Ka)
+      }
 #undef SFM_FIN_FETCH
 #undef SFM_FIN_FOLD
 #ifdef SFM_FIN_STAMPS
@@ -724,7 +773,19 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const Los
     if (stamp && gT[0] != 77.f) SFM_FSTAMP(4);
 #endif
     if (nw == 1) {         // the helper's Jacobian: d_pose[k] = <dL/dR, dR/d(theta_k)>, d_pose[3 + k] = dL/dt_k
+      if (second) {        // (wave 2: hand the sums of the tiles from 64 on to wave 0)
+        if (lane == 0) {
+#pragma unroll
+          for (int k = 0; k < 12; ++k) pose_red[1][k] = gT[k];
+        }
+        __syncthreads();
+        return;
+      }
       __syncthreads();
+      if (total > 64) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) gT[k] += pose_red[1][k];
+      }
       if (lane == 0) {
         float d[6];
 #pragma unroll
@@ -756,53 +817,44 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const Los
     }
     return;
   }
-  if (loss5 == nullptr) return;
-  // the five reported scalars: per-lane fp64 partial sums over the items, then a fixed-order in-register
-  // wave reduction of (hi, lo) float pairs (DPP), recombined in fp64
-  // (16 waves, so that the partials are fetched in one or two rounds of independent loads; the waves' sums
-  // meet in LDS and are added in wave order: the result does not depend on timing)
+  if (!(q_bsc & FIN_LOSS)) return;
+  // the five reported scalars.  Every lane sums its items in fp64 (sixteen waves: one round of independent loads at cfg3); the 1024
+  // lane sums of each scalar meet in LDS, and FOUR waves -- one per scalar, so one per SIMD -- add their scalar's sixteen wave
+  // columns lane by lane in wave order and reduce the 64 lane sums in registers ((hi, lo) float pair, DPP): a fixed order, the
+  // result does not depend on timing.  (Until round 5 each of the sixteen waves ran a DPP reduction of all four scalars: 150
+  // instructions x four waves per SIMD = 0.9 us between the arrival of the partials and the barrier; now 0.4.)
   SFM_FSTAMP(8);
-  __shared__ double wave_red[FINALIZE_WAVES][4];
+  __shared__ double lane_acc[4][FINALIZE_WAVES][64];
+  __shared__ double scalar_red[4];
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  const float4* pl = reinterpret_cast<const float4*>(A.part_loss);
+  const float4* pl = reinterpret_cast<const float4*>(h_loss);
 #pragma unroll 4
-  for (int t = threadIdx.x; t < A.items; t += 64 * FINALIZE_WAVES) {
+  for (int t = threadIdx.x; t < h_items; t += 64 * FINALIZE_WAVES) {
     const float4 v = pl[t];
     acc[0] += (double)v.x; acc[1] += (double)v.y; acc[2] += (double)v.z; acc[3] += (double)v.w;
   }
 #ifdef SFM_FIN_STAMPS
   if (acc[0] != 77.0) SFM_FSTAMP(9);
 #endif
-  {
-    float hl[8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      hl[2 * k] = (float)acc[k];
-      hl[2 * k + 1] = (float)(acc[k] - (double)hl[2 * k]);
-    }
-    wave_sums_lockstep(hl);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const double r = (double)lane63(hl[2 * k]) + (double)lane63(hl[2 * k + 1]);
-      if (lane == 0) wave_red[wave][k] = r;
-    }
-  }
+  for (int k = 0; k < 4; ++k) lane_acc[k][wave][lane] = acc[k];
   __syncthreads();
   SFM_FSTAMP(10);
-  if (wave == 0) {
-    // lane k < 4 adds the sixteen wave sums of scalar k in wave order (four chains side by side instead of 64 additions in a row)
-    double mine = 0.0;
-    if (lane < 4)
-      for (int wv = 0; wv < FINALIZE_WAVES; ++wv) mine += wave_red[wv][lane];
-    double red[4];
+  if (wave >= 4) return;
+  {
+    double m = 0.0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const unsigned long long bits = __builtin_bit_cast(unsigned long long, mine);
-      const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, k), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), k);
-      red[k] = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-    }
-    if (lane != 0) return;
-    const double pixel = red[0], ssim = red[1], smooth = red[2], expl = red[3];
+    for (int wv = 0; wv < FINALIZE_WAVES; ++wv) m += lane_acc[wave][wv][lane];
+    float hl[2];
+    hl[0] = (float)m;
+    hl[1] = (float)(m - (double)hl[0]);
+    wave_sums_lockstep(hl);
+    const double r = (double)lane63(hl[0]) + (double)lane63(hl[1]);
+    if (lane == 0) scalar_red[wave] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double pixel = scalar_red[0], ssim = scalar_red[1], smooth = scalar_red[2], expl = scalar_red[3];
     const double a = (double)A.alpha;
     loss5[0] = (float)((1.0 - a) * pixel + a * ssim + smooth + expl);   // base_model.py:117-118
     loss5[1] = (float)pixel;
@@ -1267,7 +1319,18 @@ static int run(const SfmLossDesc* d, bool grad, bool loss, float gy, float* loss
   else le = launch_main<false, true>(p, st, ev_start, ev_stop, variant);
   if (le != hipSuccess) return fail((int)le, "%s: launch of the main kernel: %s", who, hipGetErrorString(le));
   const int n_pose_blocks = grad ? d->B * d->n_src : 0;
-  hipLaunchKernelGGL(finalize_kernel, dim3(n_pose_blocks + 1), dim3(64 * FINALIZE_WAVES), 0, st, p.args, loss ? loss5 : (float*)nullptr, n_pose_blocks);
+  {
+    const LossArgs& a = p.args;
+    bool compact = a.B <= 0xffff && a.n_src <= 15 && a.n_scales <= 15;
+    for (int k = 0; k < SFM_MAX_SCALES; ++k) compact = compact && a.tiles_of[k] >= 0 && a.tiles_of[k] <= 0xffff;
+    unsigned tw[4] = {0, 0, 0, 0};
+    if (compact)
+      for (int k = 0; k < SFM_MAX_SCALES; ++k) tw[k >> 1] |= (unsigned)a.tiles_of[k] << (16 * (k & 1));
+    const unsigned bsc = (compact ? ((unsigned)a.B | (unsigned)a.n_src << 16 | (unsigned)a.n_scales << 20 | FIN_COMPACT) : 0u) |
+                         (grad ? FIN_POSE : 0u) | (loss ? FIN_LOSS : 0u);
+    hipLaunchKernelGGL(finalize_kernel, dim3(n_pose_blocks + 1), dim3(64 * FINALIZE_WAVES), 0, st, (const float*)a.part_gpm, a.intrinsics,
+                       a.pose[0], a.pose[1], bsc, tw[0], tw[1], tw[2], tw[3], (unsigned)(p.off_gpm - p.off_loss), p.args, loss ? loss5 : (float*)nullptr);
+  }
   return check_launch(who);
 }
 
