@@ -666,16 +666,27 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const flo
         sincos_pi(fminf(fmaxf(ang[k], -pi), pi), &sn[k], &cs[k]);
         msk[k] = (ang[k] > -pi && ang[k] < pi) ? 1.f : 0.f;        // F.clip backward
       }
-      const float X[9] = {1.f, 0.f, 0.f, 0.f, cs[0], -sn[0], 0.f, sn[0], cs[0]}, dX[9] = {0.f, 0.f, 0.f, 0.f, -sn[0], -cs[0], 0.f, cs[0], -sn[0]};
-      const float Y[9] = {cs[1], 0.f, sn[1], 0.f, 1.f, 0.f, -sn[1], 0.f, cs[1]}, dY[9] = {-sn[1], 0.f, cs[1], 0.f, 0.f, 0.f, -cs[1], 0.f, -sn[1]};
-      const float Z[9] = {cs[2], -sn[2], 0.f, sn[2], cs[2], 0.f, 0.f, 0.f, 1.f}, dZ[9] = {-sn[2], -cs[2], 0.f, cs[2], -sn[2], 0.f, 0.f, 0.f, 0.f};
-      float XY[9], dXY[9], XdY[9], J[27];
-      mat3_mul(X, Y, XY);
-      mat3_mul(dX, Y, dXY);
-      mat3_mul(X, dY, XdY);
-      mat3_mul(dXY, Z, J);          // dR/d(theta_x) = (X' Y) Z      (R = (X Y) Z, transform.py:39)
-      mat3_mul(XdY, Z, J + 9);      // dR/d(theta_y) = (X Y') Z
-      mat3_mul(XY, dZ, J + 18);     // dR/d(theta_z) = (X Y) Z'
+      // R = (X Y) Z (transform.py:27-39); its derivatives in CLOSED FORM -- the products with the zeros and ones of X, Y, Z and of their
+      // derivatives written out (30 instructions instead of the 160 of six general 3x3 products: the helper is what the folding waves
+      // wait for at the barrier):
+      //   X Y  = [[cy, 0, sy], [sx sy, cx, -sx cy], [-cx sy, sx, cx cy]]
+      //   X'Y  = [[0, 0, 0], [cx sy, -sx, -cx cy], [sx sy, cx, -sx cy]]          X Y' = [[-sy, 0, cy], [sx cy, 0, sx sy], [-cx cy, 0, -cx sy]]
+      //   M Z  = [M0 cz + M1 sz, -M0 sz + M1 cz, M2] (columns)                   M Z' = [-M0 sz + M1 cz, -M0 cz - M1 sz, 0]
+      const float sx = sn[0], cx = cs[0], sy = sn[1], cy = cs[1], sz = sn[2], cz = cs[2];
+      const float sxsy = sx * sy, sxcy = sx * cy, cxsy = cx * sy, cxcy = cx * cy;
+      float J[27];
+      // dR/d(theta_x) = (X'Y) Z
+      J[0] = 0.f; J[1] = 0.f; J[2] = 0.f;
+      J[3] = fmaf(cxsy, cz, -(sx * sz)); J[4] = -fmaf(cxsy, sz, sx * cz); J[5] = -cxcy;
+      J[6] = fmaf(sxsy, cz, cx * sz);    J[7] = fmaf(-sxsy, sz, cx * cz); J[8] = -sxcy;
+      // dR/d(theta_y) = (X Y') Z      (the middle column of X Y' is zero)
+      J[9] = -(sy * cz);   J[10] = sy * sz;      J[11] = cy;
+      J[12] = sxcy * cz;   J[13] = -(sxcy * sz); J[14] = sxsy;
+      J[15] = -(cxcy * cz); J[16] = cxcy * sz;   J[17] = -cxsy;
+      // dR/d(theta_z) = (X Y) Z'
+      J[18] = -(cy * sz);                  J[19] = -(cy * cz);                    J[20] = 0.f;
+      J[21] = fmaf(-sxsy, sz, cx * cz);    J[22] = -fmaf(sxsy, cz, cx * sz);      J[23] = 0.f;
+      J[24] = fmaf(cxsy, sz, sx * cz);     J[25] = fmaf(cxsy, cz, -(sx * sz));    J[26] = 0.f;
       if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < 27; ++k) jac[k] = J[k] * msk[k / 9];
@@ -748,6 +759,53 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const flo
       }
 #undef SFM_FIN_FETCH
 #undef SFM_FIN_FOLD
+    if (nw == 1) {
+      // One-wave blocks: every LANE contracts its folded sums with the helper's Jacobian -- d_pose[k] = <dL/dR, dR/d(theta_k)>,
+      // d_pose[3 + k] = dL/dt_k are linear in them -- so that SIX values go through the wave reduction instead of twelve and nothing is
+      // left to do behind it (the reduction was 0.44 us of the chain, the contraction by one lane at its end another 0.2).
+      __syncthreads();                       // the helper's Jacobian (waves 0, 1 and, with more than 64 tiles, 2)
+      float d[6];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float a = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) a = fmaf(gT3[r * 4 + c], jac[k * 9 + r * 3 + c], a);
+        d[k] = a;
+        d[3 + k] = gT3[k * 4 + 3];
+      }
+#ifdef SFM_FIN_STAMPS
+      if (stamp && d[0] != 77.f) SFM_FSTAMP(3);
+#endif
+      wave_sums_lockstep(d);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) d[k] = lane63(d[k]);
+#ifdef SFM_FIN_STAMPS
+      if (stamp && d[0] != 77.f) SFM_FSTAMP(4);
+#endif
+      if (total > 64) {                      // (block-uniform) wave 2's six sums are added after wave 0's own: a fixed order
+        if (second) {
+          if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) pose_red[1][k] = d[k];
+          }
+          __syncthreads();
+          return;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d[k] += pose_red[1][k];
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dp[b * 6 + k] = d[k];
+#ifdef SFM_FIN_STAMPS
+        if (stamp && d[0] != 77.f) SFM_FSTAMP(5);
+#endif
+      }
+      return;
+    }
 #ifdef SFM_FIN_STAMPS
     if (stamp && gT3[0] != 77.f) SFM_FSTAMP(3);
 #endif
@@ -755,7 +813,7 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const flo
     float gT[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) gT[k] = lane63(gT3[k]);
-    if (nw > 1) {          // (every wave of the block is here: none left above)
+    {                      // (nw > 1: every wave of the block is here: none left above)
       if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < 12; ++k) pose_red[wave][k] = gT[k];
@@ -772,40 +830,6 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const flo
 #ifdef SFM_FIN_STAMPS
     if (stamp && gT[0] != 77.f) SFM_FSTAMP(4);
 #endif
-    if (nw == 1) {         // the helper's Jacobian: d_pose[k] = <dL/dR, dR/d(theta_k)>, d_pose[3 + k] = dL/dt_k
-      if (second) {        // (wave 2: hand the sums of the tiles from 64 on to wave 0)
-        if (lane == 0) {
-#pragma unroll
-          for (int k = 0; k < 12; ++k) pose_red[1][k] = gT[k];
-        }
-        __syncthreads();
-        return;
-      }
-      __syncthreads();
-      if (total > 64) {
-#pragma unroll
-        for (int k = 0; k < 12; ++k) gT[k] += pose_red[1][k];
-      }
-      if (lane == 0) {
-        float d[6];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          float a = 0.f;
-#pragma unroll
-          for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) a = fmaf(gT[r * 4 + c], jac[k * 9 + r * 3 + c], a);
-          d[k] = a;
-          d[3 + k] = gT[k * 4 + 3];
-        }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) dp[b * 6 + k] = d[k];
-#ifdef SFM_FIN_STAMPS
-        if (stamp && d[0] != 77.f) SFM_FSTAMP(5);
-#endif
-      }
-      return;
-    }
     if (lane == 0) {
       float d[6];
       pose_backward(pose6, rot, gT, d);
@@ -842,9 +866,11 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const flo
   SFM_FSTAMP(10);
   if (wave >= 4) return;
   {
-    double m = 0.0;
+    static_assert(FINALIZE_WAVES % 4 == 0, "four chains of wave columns");
+    double m4[4] = {0.0, 0.0, 0.0, 0.0};   // (four chains side by side instead of sixteen additions in a row; combined in a fixed order)
 #pragma unroll
-    for (int wv = 0; wv < FINALIZE_WAVES; ++wv) m += lane_acc[wave][wv][lane];
+    for (int wv = 0; wv < FINALIZE_WAVES; ++wv) m4[wv & 3] += lane_acc[wave][wv][lane];
+    const double m = (m4[0] + m4[1]) + (m4[2] + m4[3]);
     float hl[2];
     hl[0] = (float)m;
     hl[1] = (float)(m - (double)hl[0]);
