@@ -565,8 +565,10 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 #ifdef SFM_FIN_STAMPS   // diagnostic build only: 100 MHz time stamps of finalize_kernel's stages into the debug trace buffer (tools/trace_finalize.py)
 #define SFM_FSTAMP(slot) do { if (A.trace && threadIdx.x == 0) A.trace[200000 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define SFM_FSTAMP_F(slot) do { if (A.trace && threadIdx.x == 64) A.trace[200000 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)   // first FOLDING wave
 #else
 #define SFM_FSTAMP(slot) do { } while (0)
+#define SFM_FSTAMP_F(slot) do { } while (0)
 #endif
 
 constexpr int FINALIZE_WAVES = 16;   // waves of the block that sums the loss partials (the pose blocks use one)
@@ -617,12 +619,10 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const flo
     const int b = blockIdx.x / h_src, i = blockIdx.x - b * h_src;
     const bool stamp = blockIdx.x == 0;
     if (stamp) SFM_FSTAMP(0);
-    __shared__ float pose_red[FINALIZE_WAVES][12];
-    // This block is a chain of round trips to memory with little arithmetic between them, so it is written to need TWO: every field
-    // of the argument block it uses is fetched unconditionally and at once (tile counts of all SFM_MAX_SCALES scales -- zero beyond
-    // n_scales --, all pose pointers: the one of source i is selected, not loaded through an index), then the pose and up to two
-    // rounds of partials go out together.  While they are in flight wave 0 has nothing to do; when the pose arrives it builds the
-    // rotation (euler2mat: ~150 dependent instructions) under the shadow of the partials.
+    __shared__ float pose_red[FINALIZE_WAVES][6];
+    // This block is a chain of round trips to memory with little arithmetic between them, so it is written to need ONE: what the
+    // addresses of the first loads are formed from arrives preloaded (above), and the pose (helper wave) and the partials (folding
+    // waves) go out together; the pose pointer of source i is selected, never loaded through an index.
     int tl[SFM_MAX_SCALES], ib[SFM_MAX_SCALES];
 #pragma unroll
     for (int k = 0; k < SFM_MAX_SCALES; ++k) { tl[k] = tlh[k]; ib[k] = ibh[k]; }
@@ -647,14 +647,17 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const flo
     int total = 0;
 #pragma unroll
     for (int k = 0; k < SFM_MAX_SCALES; ++k) total += tl[k];
-    // up to two rounds of loads one wave does alone (cfg3: the block's other waves leave at once, no LDS, no barrier: 1 us
-    // faster than sharing); more are spread over all the waves of the block
-    const int nw = total > 128 ? FINALIZE_WAVES : 1;    // block-uniform
-    // One-wave blocks (cfg3) get a HELPER: wave 1 builds the Jacobian of the Euler chain, dR/d(theta_k) with the clip mask of
-    // transform.py:23 folded in, while wave 0 waits for the partials and folds them -- the rotation (a load round trip + ~150
-    // dependent instructions) was on wave 0's path between the arrival of the pose and the fold: 0.45 us of a 3.1 us chain, and the
-    // 150-instruction pose_backward at its end becomes 27 multiply-adds (stamps: tools/trace_finalize.py).
-    const bool helper = nw == 1 && wave == 1;
+    // The block's waves: the FIRST one is the HELPER -- it builds the Jacobian of the Euler chain, dR/d(theta_k) with the clip mask of
+    // transform.py:23 folded in, while the others wait for their partials; the next nfold waves FOLD, one tile per lane (cfg3: 96 tiles,
+    // two waves; cfg2 / cfg5: 308 / 376, five / six waves; a sample of more than 960 tiles goes round again), the rest leave at once.
+    // Every lane contracts its folded sums with the Jacobian -- d_pose[k] = <dL/dR, dR/d(theta_k)>, d_pose[3 + k] = dL/dt_k are linear
+    // in them -- so SIX values go through the wave reduction (not twelve) and nothing is left to do behind it; the folding waves' six sums
+    // meet in LDS and are added in wave order: a fixed order, the result does not depend on timing.
+    // (Rounds 3-5 had two forms: one wave + helper for samples of up to 128 tiles, sixteen waves, twelve sums each and a 150-instruction
+    //  pose_backward by one lane at the very end for the others.)
+    const int nfold = min((total + 63) / 64, FINALIZE_WAVES - 1);    // block-uniform, >= 1
+    const bool helper = wave == 0;         // (the wave that is launched FIRST: its chain -- pose, sincos, Jacobian -- is the longest)
+    const int fw = wave - 1;               // folding wave 0 .. nfold-1
     __shared__ float jac[27];
     if (helper) {
       const float pi = 3.14159265358979323846f;
@@ -694,17 +697,8 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const flo
       __syncthreads();
       return;
     }
-    // ... and, when the sample has more than 64 tiles (cfg3: 96), a SECOND folding wave: wave 2 takes the tiles from 64 on, so that no lane
-    // folds two tiles one after the other (a fold is ~110 dependent instructions, 0.3 us of the 2.5 us chain); its twelve sums reach wave 0
-    // through LDS behind the barrier the helper needs anyway, and are added after wave 0's own: a fixed order.
-    const bool second = nw == 1 && wave == 2 && total > 64;
-    if (wave >= nw && !second) return;
-    if (stamp) SFM_FSTAMP(1);
-    float pose6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (nw > 1) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) pose6[k] = pp[b * 6 + k];
-    }
+    if (fw >= nfold) return;
+    if (stamp) SFM_FSTAMP_F(1);
     float gT3[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) gT3[k] = 0.f;
@@ -738,107 +732,59 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const flo
         _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                             \
             gT3[r * 4 + c] += K_[0 * 3 + r] * g_[0 * 4 + c] + K_[1 * 3 + r] * g_[1 * 4 + c] + K_[2 * 3 + r] * g_[2 * 4 + c];      \
   }
-    const int stride = 64 * nw;
-    const int idx0 = nw == 1 ? lane + (second ? 64 : 0) : (int)threadIdx.x, idx1 = idx0 + stride;
-    const bool has0 = idx0 < total, has1 = nw > 1 && idx1 < total;      // (one-wave blocks: the tiles from 64 on belong to wave 2)
-    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, c0 = a0, c1 = a0, c2 = a0;
-    float Ka[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, Kc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (has0) SFM_FIN_FETCH(idx0, a0, a1, a2, Ka)
-    if (has1) SFM_FIN_FETCH(idx1, c0, c1, c2, Kc)
-    Rot rot;
-    if (nw > 1 && wave == 0) euler2mat(pose6, rot);      // (wave-uniform; the result is only read by lane 0 of wave 0)
-#ifdef SFM_FIN_STAMPS
-    if (stamp && rot.R[0] != 77.f) SFM_FSTAMP(2);
-#endif
-    if (has0) SFM_FIN_FOLD(a0, a1, a2, Ka)
-    if (has1) SFM_FIN_FOLD(c0, c1, c2, Kc)
-    if (nw > 1)
-      for (int idx = idx1 + stride; idx < total; idx += stride) {   // (samples of more than 2048 tiles)
-        SFM_FIN_FETCH(idx, a0, a1, a2, Ka)
-        SFM_FIN_FOLD(a0, a1, a2, Ka)
-      }
+    const int stride = 64 * nfold;
+    const int idx0 = fw * 64 + lane;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+    float Ka[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (idx0 < total) SFM_FIN_FETCH(idx0, a0, a1, a2, Ka)
+    if (stamp) SFM_FSTAMP_F(2);
+    if (idx0 < total) SFM_FIN_FOLD(a0, a1, a2, Ka)
+    for (int idx = idx0 + stride; idx < total; idx += stride) {   // (samples of more than 960 tiles)
+      SFM_FIN_FETCH(idx, a0, a1, a2, Ka)
+      SFM_FIN_FOLD(a0, a1, a2, Ka)
+    }
 #undef SFM_FIN_FETCH
 #undef SFM_FIN_FOLD
-    if (nw == 1) {
-      // One-wave blocks: every LANE contracts its folded sums with the helper's Jacobian -- d_pose[k] = <dL/dR, dR/d(theta_k)>,
-      // d_pose[3 + k] = dL/dt_k are linear in them -- so that SIX values go through the wave reduction instead of twelve and nothing is
-      // left to do behind it (the reduction was 0.44 us of the chain, the contraction by one lane at its end another 0.2).
-      __syncthreads();                       // the helper's Jacobian (waves 0, 1 and, with more than 64 tiles, 2)
-      float d[6];
+    __syncthreads();                       // the helper's Jacobian (the helper and the folding waves)
+    float d[6];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        float a = 0.f;
+    for (int k = 0; k < 3; ++k) {
+      float a = 0.f;
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+      for (int r = 0; r < 3; ++r)
 #pragma unroll
-          for (int c = 0; c < 3; ++c) a = fmaf(gT3[r * 4 + c], jac[k * 9 + r * 3 + c], a);
-        d[k] = a;
-        d[3 + k] = gT3[k * 4 + 3];
-      }
-#ifdef SFM_FIN_STAMPS
-      if (stamp && d[0] != 77.f) SFM_FSTAMP(3);
-#endif
-      wave_sums_lockstep(d);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) d[k] = lane63(d[k]);
-#ifdef SFM_FIN_STAMPS
-      if (stamp && d[0] != 77.f) SFM_FSTAMP(4);
-#endif
-      if (total > 64) {                      // (block-uniform) wave 2's six sums are added after wave 0's own: a fixed order
-        if (second) {
-          if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) pose_red[1][k] = d[k];
-          }
-          __syncthreads();
-          return;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 6; ++k) d[k] += pose_red[1][k];
-      }
-      if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) dp[b * 6 + k] = d[k];
-#ifdef SFM_FIN_STAMPS
-        if (stamp && d[0] != 77.f) SFM_FSTAMP(5);
-#endif
-      }
-      return;
+        for (int c = 0; c < 3; ++c) a = fmaf(gT3[r * 4 + c], jac[k * 9 + r * 3 + c], a);
+      d[k] = a;
+      d[3 + k] = gT3[k * 4 + 3];
     }
 #ifdef SFM_FIN_STAMPS
-    if (stamp && gT3[0] != 77.f) SFM_FSTAMP(3);
+    if (stamp && d[0] != 77.f) SFM_FSTAMP_F(3);
 #endif
-    wave_sums_lockstep(gT3);
-    float gT[12];
+    wave_sums_lockstep(d);
 #pragma unroll
-    for (int k = 0; k < 12; ++k) gT[k] = lane63(gT3[k]);
-    {                      // (nw > 1: every wave of the block is here: none left above)
+    for (int k = 0; k < 6; ++k) d[k] = lane63(d[k]);
+#ifdef SFM_FIN_STAMPS
+    if (stamp && d[0] != 77.f) SFM_FSTAMP_F(4);
+#endif
+    if (nfold > 1) {                       // (block-uniform)
       if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < 12; ++k) pose_red[wave][k] = gT[k];
+        for (int k = 0; k < 6; ++k) pose_red[fw][k] = d[k];
       }
       __syncthreads();
-      if (wave != 0) return;
-      // lane k < 12 adds the sixteen partial sums of component k in wave order, then the twelve totals go to every lane
-      float a = 0.f;
-      if (lane < 12)
-        for (int wv = 0; wv < FINALIZE_WAVES; ++wv) a += pose_red[wv][lane];
-#pragma unroll
-      for (int k = 0; k < 12; ++k) gT[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), k));
-    }
-#ifdef SFM_FIN_STAMPS
-    if (stamp && gT[0] != 77.f) SFM_FSTAMP(4);
-#endif
-    if (lane == 0) {
-      float d[6];
-      pose_backward(pose6, rot, gT, d);
+      if (fw != 0) return;
+      if (lane < 6) {                      // lane k adds the folding waves' sums of component k in wave order and stores it
+        float a = pose_red[0][lane];
+        for (int wv = 1; wv < nfold; ++wv) a += pose_red[wv][lane];
+        dp[b * 6 + lane] = a;
+      }
+    } else if (lane == 0) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) dp[b * 6 + k] = d[k];
-#ifdef SFM_FIN_STAMPS
-      if (stamp && d[0] != 77.f) SFM_FSTAMP(5);
-#endif
     }
+#ifdef SFM_FIN_STAMPS
+    if (stamp && d[0] != 77.f) SFM_FSTAMP_F(5);
+#endif
     return;
   }
   if (!(q_bsc & FIN_LOSS)) return;
