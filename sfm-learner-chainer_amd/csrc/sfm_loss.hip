@@ -265,8 +265,51 @@ __device__ __forceinline__ void set_issue_prio(const int p) {   // s_setprio tak
 // REF: the projection of the source passes in the reference's own evaluation order (sfm_ssim_pass.h, issue_row) -- an experiment of
 // round 5 behind sfm_loss_variant, built for the pixel-interleaved SSIM kernels of sfm_loss_fwd_bwd only.
 // DSRC: the instantiations a launch with SfmLossDesc.d_src bound runs (the LDS accumulation window of sfm_ssim_pass.h, dsrc_scatter).
+// What a wave needs before anything else -- which item it is -- arrives PRELOADED in scalar registers (the dispatcher delivers the
+// first dwords of the argument block with the wave: -mllvm -amdgpu-kernarg-preload-count, see finalize_kernel): the main kernels
+// take these ten dwords in front of the by-value struct, so that the first scalar round trip of a wave is already the one for its
+// scale's entry (rounds 3-5: header, then entry: two dependent round trips with the whole chip waiting at the start of a launch).
+//   h_bn: B | n_src << 16 | n_scales << 20 | prio_top << 24 | COMPACT << 31;  h_t01 .. h_t67: tiles_of[] as 16-bit halves.
+// COMPACT = 0 (a tile count or B beyond 16 bits): the header is read from the struct, as before.
+#define SFM_HDR_PARAMS const unsigned h_bn, const int h_items, const int h_simds, const unsigned h_prio, const unsigned h_t01, const unsigned h_t23, \
+                       const unsigned h_t45, const unsigned h_t67, unsigned long long* const h_trace
+#define SFM_HDR_ARGS h_bn, h_items, h_simds, h_prio, h_t01, h_t23, h_t45, h_t67, h_trace
+struct Hdr {
+  int B, n_src, n_scales, items, simds_per_xcd, prio_top;
+  unsigned prio_tab;
+  int tiles_of[SFM_MAX_SCALES], item_begin_of[SFM_MAX_SCALES];
+  unsigned long long* trace;
+};
+__device__ __forceinline__ Hdr make_hdr(const LossArgs& A, SFM_HDR_PARAMS) {
+  Hdr H;
+  if (h_bn >> 31) {      // (uniform)
+    H.B = (int)(h_bn & 0xffffu); H.n_src = (int)((h_bn >> 16) & 0xfu); H.n_scales = (int)((h_bn >> 20) & 0xfu); H.prio_top = (int)((h_bn >> 24) & 0x3u);
+    H.items = h_items; H.simds_per_xcd = h_simds; H.prio_tab = h_prio; H.trace = h_trace;
+    const unsigned tw[4] = {h_t01, h_t23, h_t45, h_t67};
+    int run = 0;
+#pragma unroll
+    for (int k = 0; k < SFM_MAX_SCALES; ++k) {
+      H.tiles_of[k] = (int)((tw[k >> 1] >> (16 * (k & 1))) & 0xffffu);
+      H.item_begin_of[k] = run;          // make_plan: item_begin of a scale = B x the tiles of the scales before it
+      run += H.B * H.tiles_of[k];
+    }
+  } else {
+    // The header of the argument block is fetched in ONE batch of scalar loads, before anything branches on it: left to where each
+    // field is first used, the loads end up behind one another's branches -- eight dependent round trips to a cold scalar cache at the
+    // start of every wave, with the whole chip waiting.
+    asm volatile("" ::"s"(A.B), "s"(A.n_src), "s"(A.n_scales), "s"(A.items), "s"(A.simds_per_xcd), "s"(A.prio_top), "s"(A.prio_tab),
+                 "s"(A.tiles_of[0]), "s"(A.tiles_of[1]), "s"(A.tiles_of[2]), "s"(A.tiles_of[3]), "s"(A.tiles_of[4]), "s"(A.tiles_of[5]),
+                 "s"(A.tiles_of[6]), "s"(A.tiles_of[7]), "s"(A.trace));
+    H.B = A.B; H.n_src = A.n_src; H.n_scales = A.n_scales; H.items = A.items; H.simds_per_xcd = A.simds_per_xcd; H.prio_top = A.prio_top;
+    H.prio_tab = A.prio_tab; H.trace = A.trace;
+#pragma unroll
+    for (int k = 0; k < SFM_MAX_SCALES; ++k) { H.tiles_of[k] = A.tiles_of[k]; H.item_begin_of[k] = A.item_begin_of[k]; }
+  }
+  return H;
+}
+
 template <bool SSIM, bool GRAD, bool LOSS, bool EXPL, int SMODE, bool HWC, bool WARPED, int REF = 0, bool DSRC = false>
-__device__ __forceinline__ void loss_body(const LossArgs& A) {
+__device__ __forceinline__ void loss_body(const Hdr& H, const LossArgs& A) {
   static_assert(GRAD || !DSRC, "dL/d(src) is an output of the backward");
   static_assert(LOSS || !WARPED, "the warped images are an output of the forward and the fused entry points");
   static_assert(REF == 0 || (SSIM && GRAD && LOSS && HWC && !EXPL), "the reference-order variants exist for the benchmarked kernels only");
@@ -281,51 +324,46 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
   // With fewer than 8 samples the items are dealt out as 8 contiguous ranges instead.  Placement only affects
   // speed, never the result (the partial sums are indexed by the item id, not by the block).
   static_assert(WAVES_PER_BLOCK == 1, "item mapping assumes one wavefront per workgroup");
-  // The header of the argument block is fetched in ONE batch of scalar loads, before anything branches on it: left to where each
-  // field is first used, the loads end up behind one another's branches -- eight dependent round trips to a cold scalar cache at the
-  // start of every wave, with the whole chip waiting.
-  asm volatile("" ::"s"(A.B), "s"(A.n_src), "s"(A.n_scales), "s"(A.items), "s"(A.simds_per_xcd), "s"(A.prio_top), "s"(A.prio_tab),
-               "s"(A.tiles_of[0]), "s"(A.tiles_of[1]), "s"(A.tiles_of[2]), "s"(A.tiles_of[3]), "s"(A.tiles_of[4]), "s"(A.tiles_of[5]),
-               "s"(A.tiles_of[6]), "s"(A.tiles_of[7]), "s"(A.trace));
+  // (the header H: preloaded kernel arguments, see make_hdr)
   const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
   int s = 0, b, t;
-  if ((int)A.prio_tab >= 0) {      // (bit 31 of prio_tab: deal the ITEMS out over the XCDs instead, see make_plan)
+  if ((int)H.prio_tab >= 0) {      // (bit 31 of prio_tab: deal the ITEMS out over the XCDs instead, see make_plan)
     // whole groups of eight samples: one sample of each group per XCD; the samples left over (B not a multiple of 8) are dealt out
     // item by item, round-robin over the XCDs (before round 3 they went to the first XCDs whole: B = 11 ran at 11/16)
-    const int nb = A.B >> 3;                      // samples of the whole groups owned by this XCD
+    const int nb = H.B >> 3;                      // samples of the whole groups owned by this XCD
     int rem = loc;
     bool found = false;
 #pragma unroll
     for (int k = 0; k < SFM_MAX_SCALES; ++k) {
-      if (k < A.n_scales && !found) {
-        const int cnt = nb * A.tiles_of[k];
+      if (k < H.n_scales && !found) {
+        const int cnt = nb * H.tiles_of[k];
         if (rem < cnt) { s = k; found = true; }
         else rem -= cnt;
       }
     }
     if (found) {
-      int tls = A.tiles_of[0];
+      int tls = H.tiles_of[0];
 #pragma unroll
-      for (int k = 1; k < SFM_MAX_SCALES; ++k) tls = (s == k) ? A.tiles_of[k] : tls;
+      for (int k = 1; k < SFM_MAX_SCALES; ++k) tls = (s == k) ? H.tiles_of[k] : tls;
       const int bl = rem / tls;
       t = rem - bl * tls;
       b = xcd + 8 * bl;
     } else {
       int T = 0;
 #pragma unroll
-      for (int k = 0; k < SFM_MAX_SCALES; ++k) T += A.tiles_of[k];     // (0 beyond n_scales)
+      for (int k = 0; k < SFM_MAX_SCALES; ++k) T += H.tiles_of[k];     // (0 beyond n_scales)
       const int q = rem * 8 + xcd;                // index among the left-over samples' items
-      const int left = A.B & 7;
+      const int left = H.B & 7;
       if (q >= left * T) return;   // whole wavefront leaves; no block-level synchronisation anywhere in this kernel
       const int br = q / T;
       int wi = q - br * T;
-      b = (A.B & ~7) + br;
+      b = (H.B & ~7) + br;
       bool hit = false;
 #pragma unroll
       for (int k = 0; k < SFM_MAX_SCALES; ++k) {
         if (!hit) {
-          if (wi < A.tiles_of[k]) { s = k; hit = true; }
-          else wi -= A.tiles_of[k];
+          if (wi < H.tiles_of[k]) { s = k; hit = true; }
+          else wi -= H.tiles_of[k];
         }
       }
       t = wi;
@@ -333,13 +371,13 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
   } else {
     const int per = (int)(gridDim.x >> 3);
     const int it = xcd * per + loc;
-    if (it >= A.items) return;
+    if (it >= H.items) return;
 #pragma unroll
     for (int k = 1; k < SFM_MAX_SCALES; ++k)
-      if (k < A.n_scales && it >= A.item_begin_of[k]) s = k;
-    int tls = A.tiles_of[0], ibs = A.item_begin_of[0];
+      if (k < H.n_scales && it >= H.item_begin_of[k]) s = k;
+    int tls = H.tiles_of[0], ibs = H.item_begin_of[0];
 #pragma unroll
-    for (int k = 1; k < SFM_MAX_SCALES; ++k) { tls = (s == k) ? A.tiles_of[k] : tls; ibs = (s == k) ? A.item_begin_of[k] : ibs; }
+    for (int k = 1; k < SFM_MAX_SCALES; ++k) { tls = (s == k) ? H.tiles_of[k] : tls; ibs = (s == k) ? H.item_begin_of[k] : ibs; }
     const int idx = it - ibs;
     b = idx / tls;
     t = idx - b * tls;
@@ -350,14 +388,14 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
                "s"(S.chunk_rows), "s"(S.inv_cnt), "s"(S.k_pix), "s"(S.kq));
   const int item = S.item_begin + b * S.tiles + t;
   unsigned long long t_start = 0;
-  if (A.trace) t_start = __builtin_amdgcn_s_memrealtime();
+  if (H.trace) t_start = __builtin_amdgcn_s_memrealtime();
   // Issue priority.  The SIMD arbiter prefers the oldest wave, so of the co-resident waves of a SIMD one runs ahead
   // and the SIMD ends its launch with a lone wave at half its throughput (profiles/r01_wave_stage_stamps.txt).  The
   // dispatcher places workgroups j, j + S, j + 2S ... of an XCD (S = its SIMD count) on the same SIMD in that age
   // order, so the dispatch round is the age rank: the youngest is preferred during the first half of the sources,
   // the oldest during the second, and the waves of a SIMD finish closer together.  Only ever affects speed.
-  const int prio_rank = min((int)(blockIdx.x >> 3) / A.simds_per_xcd, A.prio_top);
-  set_issue_prio((int)((A.prio_tab >> (2 * prio_rank)) & 3u));
+  const int prio_rank = min((int)(blockIdx.x >> 3) / H.simds_per_xcd, H.prio_top);
+  set_issue_prio((int)((H.prio_tab >> (2 * prio_rank)) & 3u));
   const int chunk = t / S.strips;
   const int strip = t - chunk * S.strips;
   const int h = S.h, w = S.w;
@@ -389,7 +427,7 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
   }
   // the geometry of every source pass of this wave (sfm_ssim_pass.h, build_wave_geom), its loads in the same batch as the disparities
   static_assert(SFM_MAX_SRC * 8 <= 64, "one group of eight lanes per source");
-  const WaveGeom WG = build_wave_geom(A.pose, A.n_src, b, A.intrinsics + (size_t)(b * A.n_scales + s) * 9, lane);
+  const WaveGeom WG = build_wave_geom(A.pose, H.n_src, b, A.intrinsics + (size_t)(b * H.n_scales + s) * 9, lane);
 #ifdef SFM_STAMPS
   Stamps st = {0, 0, 0, 0, 0};
   unsigned long long ts0 = 0, cyc_smooth = 0, cyc_src = 0;
@@ -401,14 +439,14 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
   // (Measured round 3 with a run-time table, commit 40da7e8: every wave first +2 %, oldest first / middle between the sources /
   // youngest last +4...7 %, the other mixed orders within noise of this one: profiles/r03_smooth_position_sweep.txt.)
   const bool smooth_last = (SMODE != 0) && (prio_rank == 1);
-  const int n_phases = A.n_src + (SMODE != 0 ? 1 : 0);
+  const int n_phases = H.n_src + (SMODE != 0 ? 1 : 0);
   for (int ph = 0; ph < n_phases; ++ph) {
     const int i = (SMODE != 0 && !smooth_last) ? ph - 1 : ph;   // source of this phase; -1 or n_src = the smoothness pass
 #ifdef SFM_STAMPS
     unsigned long long tp0 = 0, tp1 = 0;
     SFM_STAMP(tp0);
 #endif
-    if (SMODE != 0 && (i < 0 || i >= A.n_src)) {
+    if (SMODE != 0 && (i < 0 || i >= H.n_src)) {
       if (SMODE == 1) smooth2_pass<GRAD, LOSS>(A, S, S.disp + (size_t)b * P, lane, x, xin, outl, y0, y1, gacc, acc_sm, !first);
       else smooth_edge_pass<GRAD, LOSS, HWC>(A, S, S.disp + (size_t)b * P, S.tgt + (size_t)b * 3 * P, lane, x, xin, outl, y0, y1, gacc, acc_sm, !first);
       first = false;
@@ -418,7 +456,7 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
 #endif
       continue;
     }
-    if (i * 2 >= A.n_src) set_issue_prio((int)((A.prio_tab >> (8 + 2 * prio_rank)) & 3u));
+    if (i * 2 >= H.n_src) set_issue_prio((int)((H.prio_tab >> (8 + 2 * prio_rank)) & 3u));
     SsimCtx C;
     const float xf = (float)x;
     C.x0 = x - lane;
@@ -429,7 +467,7 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
 #pragma unroll
       for (int k = 0; k < SFM_MAX_SRC; ++k) pp = (i == k) ? A.pose[k] : pp;
       Geom g;
-      make_geom(pp + b * 6, A.intrinsics + (size_t)(b * A.n_scales + s) * 9, g);
+      make_geom(pp + b * 6, A.intrinsics + (size_t)(b * H.n_scales + s) * 9, g);
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         C.M1[k] = uniform(g.M[k * 3 + 1]);
@@ -452,7 +490,7 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       C.tp[k] = S.tgt + ((size_t)b * 3 + k) * P;
-      C.sp[k] = S.src + (((size_t)b * A.n_src + i) * 3 + k) * P;
+      C.sp[k] = S.src + (((size_t)b * H.n_src + i) * 3 + k) * P;
     }
     C.k_pix = S.k_pix;
     C.kq = S.kq;
@@ -463,11 +501,11 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
     asm volatile("" : "+s"(y0p), "+s"(y1p));
     C.h = h; C.w = w; C.y0 = y0p; C.y1 = y1p;
     C.dp = S.disp + (size_t)b * P;
-    C.dsp = (DSRC && S.d_src) ? S.d_src + ((size_t)b * A.n_src + i) * 3 * P : nullptr;
+    C.dsp = (DSRC && S.d_src) ? S.d_src + ((size_t)b * H.n_src + i) * 3 * P : nullptr;
     C.dtile = dsrc_tile;
-    C.wp = WARPED ? S.warped + ((size_t)b * A.n_src + i) * 3 * P : nullptr;
-    C.mp = EXPL ? S.mlog + ((size_t)b * A.n_src + i) * P : nullptr;
-    C.dmp = (EXPL && GRAD) ? S.d_mask + ((size_t)b * A.n_src + i) * P : nullptr;
+    C.wp = WARPED ? S.warped + ((size_t)b * H.n_src + i) * 3 * P : nullptr;
+    C.mp = EXPL ? S.mlog + ((size_t)b * H.n_src + i) * P : nullptr;
+    C.dmp = (EXPL && GRAD) ? S.d_mask + ((size_t)b * H.n_src + i) * P : nullptr;
     C.P = P;
     C.sc = sc;
     C.xc = (unsigned)min(max(x, 0), w - 1);
@@ -483,7 +521,7 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
     C.xinf = xin ? 1.f : 0.f;
     C.outf = outl ? 1.f : 0.f;
     C.lane = lane;
-    float* gpm_out = GRAD ? A.part_gpm + ((size_t)item * A.n_src + i) * 12 : nullptr;
+    float* gpm_out = GRAD ? A.part_gpm + ((size_t)item * H.n_src + i) * 12 : nullptr;
     if constexpr (SSIM) {
       ssim_source_pass<GRAD, LOSS, HWC, WARPED, REF, DSRC>(C, gacc, first, acc_pix, acc_ssim, gpm_out SFM_STAMPS_PASS);
     } else {
@@ -501,15 +539,15 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
       for (int q = y0; q < y1; ++q) stf_wt(o, (unsigned)(q * w + x), gacc[(q - y0) * 64 + lane]);
     }
   }
-  if (A.trace && lane == 0) {   // timing-only diagnostics; never read by any kernel
-    unsigned long long* o = A.trace + (size_t)item * 4;
+  if (H.trace && lane == 0) {   // timing-only diagnostics; never read by any kernel
+    unsigned long long* o = H.trace + (size_t)item * 4;
     o[0] = t_start;
     o[1] = __builtin_amdgcn_s_memrealtime();
     o[2] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
     o[3] = (__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) & 0xf) | ((unsigned long long)blockIdx.x << 8);   // HW_REG_XCC_ID, workgroup
 #ifdef SFM_STAMPS
     {
-      unsigned long long* q = A.trace + (size_t)A.items * 4 + (size_t)item * 8;
+      unsigned long long* q = H.trace + (size_t)H.items * 4 + (size_t)item * 8;
       unsigned long long ts3 = 0;
       SFM_STAMP(ts3);
       q[0] = st.a_fin; q[1] = st.a_iss; q[2] = st.b; q[3] = st.c; q[4] = st.steps > 0 ? st.steps : 1;   // (the L1 passes carry no per-stage stamps)
@@ -532,24 +570,24 @@ __device__ __forceinline__ void loss_body(const LossArgs& A) {
 }
 
 template <bool SSIM, bool GRAD, bool LOSS, bool EXPL, int SMODE, bool HWC, bool WARPED = false>
-__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) loss_kernel(const LossArgs A) {
-  loss_body<SSIM, GRAD, LOSS, EXPL, SMODE, HWC, WARPED>(A);
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) loss_kernel(SFM_HDR_PARAMS, const LossArgs A) {
+  loss_body<SSIM, GRAD, LOSS, EXPL, SMODE, HWC, WARPED>(make_hdr(A, SFM_HDR_ARGS), A);
 }
 // (DSRC, see loss_body: the gradient kernels of a launch that also wants dL/d(src).  Three waves per SIMD; the SSIM ones two: at
 //  three they would spill 22-34 registers to scratch)
 template <bool SSIM, bool LOSS, bool EXPL, int SMODE, bool HWC, bool WARPED = false>
-__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, SSIM ? 2 : 3) loss_kernel_dsrc(const LossArgs A) {
-  loss_body<SSIM, true, LOSS, EXPL, SMODE, HWC, WARPED, 0, true>(A);
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, SSIM ? 2 : 3) loss_kernel_dsrc(SFM_HDR_PARAMS, const LossArgs A) {
+  loss_body<SSIM, true, LOSS, EXPL, SMODE, HWC, WARPED, 0, true>(make_hdr(A, SFM_HDR_ARGS), A);
 }
 // (REF, see loss_body: the fused SSIM kernels in the pixel-interleaved layout, in the reference's evaluation order)
 template <int SMODE, bool WARPED, int REF>
-__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 3) loss_kernel_ref(const LossArgs A) {
-  loss_body<true, true, true, false, SMODE, true, WARPED, REF>(A);
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 3) loss_kernel_ref(SFM_HDR_PARAMS, const LossArgs A) {
+  loss_body<true, true, true, false, SMODE, true, WARPED, REF>(make_hdr(A, SFM_HDR_ARGS), A);
 }
 // (WIDE, see above: L1 gradient kernels only)
 template <bool LOSS, int SMODE, bool HWC, bool WARPED = false>
-__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 3) loss_kernel_wide(const LossArgs A) {
-  loss_body<false, true, LOSS, false, SMODE, HWC, WARPED>(A);
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 3) loss_kernel_wide(SFM_HDR_PARAMS, const LossArgs A) {
+  loss_body<false, true, LOSS, false, SMODE, HWC, WARPED>(make_hdr(A, SFM_HDR_ARGS), A);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1201,7 +1239,17 @@ static const void* kernel_ptr_dsrc(bool ssim, bool expl, int smode, bool hwc, bo
 template <bool GRAD, bool LOSS>
 static hipError_t launch_main(const Plan& p, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, const int variant) {
   LossArgs args = p.args;
-  void* kargs[] = {&args};
+  // the preloaded header (make_hdr): B, n_src, n_scales, prio_top and the tile counts packed
+  bool compact = args.B <= 0xffff && args.n_src <= 15 && args.n_scales <= 15 && args.prio_top <= 3;
+  for (int k = 0; k < SFM_MAX_SCALES; ++k) compact = compact && args.tiles_of[k] >= 0 && args.tiles_of[k] <= 0xffff;
+  unsigned h_bn = 0, h_t[4] = {0, 0, 0, 0}, h_prio = args.prio_tab;
+  int h_items = args.items, h_simds = args.simds_per_xcd;
+  unsigned long long* h_trace = args.trace;
+  if (compact) {
+    h_bn = (unsigned)args.B | (unsigned)args.n_src << 16 | (unsigned)args.n_scales << 20 | (unsigned)args.prio_top << 24 | 1u << 31;
+    for (int k = 0; k < SFM_MAX_SCALES; ++k) h_t[k >> 1] |= (unsigned)args.tiles_of[k] << (16 * (k & 1));
+  }
+  void* kargs[] = {&h_bn, &h_items, &h_simds, &h_prio, &h_t[0], &h_t[1], &h_t[2], &h_t[3], &h_trace, &args};
   // 8 x (items of the busiest XCD): see the item mapping at the top of loss_kernel
   int tiles_per_sample = 0;
   for (int s = 0; s < p.args.n_scales; ++s) tiles_per_sample += p.args.sc[s].tiles;
