@@ -181,7 +181,10 @@ int sfm_loss_plan_info(const SfmLossDesc *desc, int grad, int loss, int *out, in
  * back to 0.  0 = the product (geometry built in the wave, fused roundings: DESIGN.md 3); 1 = the same per-pixel chain on the
  * geometry of the reference's own products and divisions (euler2mat, K4 . T, batch_inv: models/transform.py:11-91,105);
  * 2 = the reference's evaluation order per pixel as well (transform.py:105-108,122-131 and the sampler's position, :189).
- * 1 and 2 exist for sfm_loss_fwd_bwd with SSIM and smoothness in SFM_LAYOUT_HWC (the benchmarked launches); ignored elsewhere. */
+ * 1 and 2 exist for sfm_loss_fwd_bwd with SSIM and smoothness in SFM_LAYOUT_HWC (the benchmarked launches); ignored elsewhere.
+ * 3 = every entry point, same arithmetic: the kernels read the header of their argument block from the struct instead of taking it
+ * as preloaded scalar arguments -- the path of a batch or a tile count beyond 16 bits, which no test could reach otherwise
+ * (results are bit-identical to 0). */
 int sfm_loss_variant(int variant);
 /* Diagnostics: the NEXT sfm_loss_* call of this thread makes every wavefront of its main kernel
  * write {start, end (100 MHz realtime counter), HW_ID, XCC_ID} as 4 x uint64 per work item into

@@ -1240,7 +1240,8 @@ template <bool GRAD, bool LOSS>
 static hipError_t launch_main(const Plan& p, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, const int variant) {
   LossArgs args = p.args;
   // the preloaded header (make_hdr): B, n_src, n_scales, prio_top and the tile counts packed
-  bool compact = args.B <= 0xffff && args.n_src <= 15 && args.n_scales <= 15 && args.prio_top <= 3;
+  // (sfm_loss_variant(3), tests: the header read from the struct, the path of counts beyond 16 bits)
+  bool compact = variant != 3 && args.B <= 0xffff && args.n_src <= 15 && args.n_scales <= 15 && args.prio_top <= 3;
   for (int k = 0; k < SFM_MAX_SCALES; ++k) compact = compact && args.tiles_of[k] >= 0 && args.tiles_of[k] <= 0xffff;
   unsigned h_bn = 0, h_t[4] = {0, 0, 0, 0}, h_prio = args.prio_tab;
   int h_items = args.items, h_simds = args.simds_per_xcd;
@@ -1341,7 +1342,7 @@ static int run(const SfmLossDesc* d, bool grad, bool loss, float gy, float* loss
   const int n_pose_blocks = grad ? d->B * d->n_src : 0;
   {
     const LossArgs& a = p.args;
-    bool compact = a.B <= 0xffff && a.n_src <= 15 && a.n_scales <= 15;
+    bool compact = variant != 3 && a.B <= 0xffff && a.n_src <= 15 && a.n_scales <= 15;
     for (int k = 0; k < SFM_MAX_SCALES; ++k) compact = compact && a.tiles_of[k] >= 0 && a.tiles_of[k] <= 0xffff;
     unsigned tw[4] = {0, 0, 0, 0};
     if (compact)
@@ -1384,7 +1385,7 @@ int sfm_loss_plan_info(const SfmLossDesc* desc, int grad, int loss, int* out, in
 }
 
 int sfm_loss_variant(int variant) {
-  if (variant < 0 || variant > 2) return sfm::fail(SFM_ERR_CONFIG, "sfm_loss_variant: %d not in [0, 2]", variant);
+  if (variant < 0 || variant > 3) return sfm::fail(SFM_ERR_CONFIG, "sfm_loss_variant: %d not in [0, 3]", variant);
   sfm::g_variant = variant;
   return SFM_OK;
 }

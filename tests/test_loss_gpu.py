@@ -701,6 +701,33 @@ def test_smooth_disparity_field_vs_oracle(ops, synth, dev, cfg_name, B, H, W):
     count_in_view_mismatches(ops, dev, d, ref, "hwc", what)
 
 
+@pytest.mark.parametrize("cfg_name", ["l1", "l1_smooth", "ssim_smooth", "edge_aware", "explain"])
+def test_header_read_from_the_struct_gives_the_same_bits(ops, synth, dev, cfg_name):
+    """The kernels take the header of their argument block (batch, counts, tile counts packed into 16-bit halves) as preloaded scalar
+    arguments; a batch or a tile count beyond 16 bits makes them read it from the struct instead.  No shape a test can afford reaches
+    that path, so sfm_loss_variant(3) forces it: all three entry points, every output bit for bit the default launch's."""
+    cfg = CONFIGS[cfg_name]
+    d = synth.make_inputs(B=3, H=48, W=136, n_src=2, n_scales=3, seed=17, with_masks=True)
+    outs = []
+    for forced in (False, True):
+        fl = _bind(ops, dev, d, cfg, layout="hwc")
+        hook = (lambda: ops.check(ops.lib.sfm_loss_variant(3))) if forced else (lambda: None)
+        hook()
+        l_fwd = to_np(fl.forward()).copy()
+        hook()
+        l_both = to_np(fl.forward_backward()).copy()
+        g_both = [to_np(t).copy() for t in fl.d_disps + fl.d_poses + (fl.d_masks or [])]
+        hook()
+        fl.backward(1.0)
+        g_bwd = [to_np(t).copy() for t in fl.d_disps + fl.d_poses + (fl.d_masks or [])]
+        outs.append((l_fwd, l_both, g_both, g_bwd))
+    (a_fwd, a_both, a_g, a_b), (b_fwd, b_both, b_g, b_b) = outs
+    np.testing.assert_array_equal(a_fwd, b_fwd)
+    np.testing.assert_array_equal(a_both, b_both)
+    for x, y in zip(a_g + a_b, b_g + b_b):
+        np.testing.assert_array_equal(x, y)
+
+
 def test_warped_pixels_at_256x832_on_seam_free_inputs(ops, synth, dev):
     """BASELINE cfg5 (B=8, 256x832, 4 sources) on seam-free inputs.  At U ~ 800 one ulp of a sampling position is 6e-5 px and two
     correct fp32 evaluations of it lie up to 3e-4 px apart: the product kernel is held to a flat 2e-4 of the range with at most
