@@ -533,6 +533,17 @@ __device__ __forceinline__ void loss_body(const Hdr& H, const LossArgs& A) {
     cyc_src += tp1 - tp0;
 #endif
   }
+  // the wave's four loss sums, reduced in LOCKSTEP (same adds in the same order per value as four wave_sum calls one after the other:
+  // bit-identical) and in front of the d_disp write-out, whose LDS reads and stores issue under the DPP chain's latency -- the last wave
+  // of a launch is alone on its SIMD when it gets here
+  if (LOSS) {
+    float v[4] = {acc_pix, acc_ssim, acc_sm, acc_exp};
+    wave_sums_lockstep(v);
+    if (lane == 63) {
+      float* o = A.part_loss + (size_t)item * 4;
+      o[0] = v[0] * S.inv_cnt; o[1] = v[1] * S.inv_cnt; o[2] = v[2]; o[3] = v[3] * S.c_exp;
+    }
+  }
   if (GRAD) {
     if (outl) {
       float* o = S.d_disp + (size_t)b * P;
@@ -556,16 +567,6 @@ __device__ __forceinline__ void loss_body(const Hdr& H, const LossArgs& A) {
       q[7] = ts3 - ts0;    // the whole wave in shader cycles (start-up and d_disp write-out = the rest)
     }
 #endif
-  }
-  if (LOSS) {
-    const float v0 = wave_sum(acc_pix) * S.inv_cnt;
-    const float v1 = wave_sum(acc_ssim) * S.inv_cnt;
-    const float v2 = wave_sum(acc_sm);
-    const float v3 = wave_sum(acc_exp) * S.c_exp;
-    if (lane == 0) {
-      float* o = A.part_loss + (size_t)item * 4;
-      o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3;
-    }
   }
 }
 
