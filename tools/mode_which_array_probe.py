@@ -117,6 +117,28 @@ if os.environ.get("PROBE_TOUCH"):      # the SAME arrays, same binding: read (a 
     step_fn = bind()
     print("%-40s step %.2f kernel %.2f" % (("same arrays, bound again",) + take(step_fn)), clock_note[0], flush=True)
     acc = 0.0
+    if os.environ.get("PROBE_TOUCH") == "families":      # one family at a time, smallest first: which read ends the slow level?
+        fl_last = keep[-1]
+        unrelated = torch.ones((64,), dtype=torch.float32, device=dev)          # (allocated now: a new small block)
+        torch.cuda.synchronize()
+        print("%-40s step %.2f kernel %.2f" % (("after ALLOCATING + filling 64 floats",) + take(step_fn)), flush=True)
+        if os.environ.get("PROBE_D2H"):       # the pieces of `float(x.sum())` one at a time: a reduction kernel; a device-to-host copy
+            r = unrelated.sum()
+            torch.cuda.synchronize()
+            print("%-40s step %.2f kernel %.2f" % (("after a sum KERNEL over them (no copy)",) + take(step_fn)), flush=True)
+            host = unrelated.cpu()
+            print("%-40s step %.2f kernel %.2f" % (("after COPYING them to the host",) + take(step_fn)), flush=True)
+            acc += float(r)
+            print("%-40s step %.2f kernel %.2f" % (("after float() of the 0-d result",) + take(step_fn)), flush=True)
+            sys.exit(0)
+        acc += float(unrelated.sum())
+        print("%-40s step %.2f kernel %.2f" % (("after summing those 64 floats",) + take(step_fn)), flush=True)
+        for label, arrs in (("K + poses", [cur["K"]] + cur["pose"]), ("workspace + outputs", [fl_last.ws] + fl_last.d_disps + fl_last.d_poses),
+                            ("disp", cur["disp"]), ("tgt", cur["tgt"]), ("src", cur["src"])):
+            for a in arrs:
+                acc += float(a.sum())
+            print("%-40s step %.2f kernel %.2f" % (("after READING %s" % label,) + take(step_fn)), flush=True)
+        sys.exit(0)
     for fam in ("tgt", "src", "disp"):
         for a in cur[fam]:
             acc += float(a.sum())
