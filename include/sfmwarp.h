@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SFM_ABI_VERSION 4
+#define SFM_ABI_VERSION 5
 
 #define SFM_OK 0
 #define SFM_ERR_NULL (-1)      /* a required pointer is NULL                       */
@@ -125,6 +125,25 @@ int sfm_sampler_interp_bwd(const float *x, const float *grid, const float *gy, f
 #define SFM_LAYOUT_PLANAR 0
 #define SFM_LAYOUT_HWC 1
 
+/* How the fused kernels evaluate the per-pixel projection of projective_inverse_warp (models/transform.py:94-133,189).  (ABI v5)
+ * Both take the pose -> projection products of proj_tgt_to_src and batch_inv in the reference's own roundings
+ * (R = (X . Y) . Z, K4 . T and adj(K) / det as separate multiplies, adds and correctly rounded quotients: transform.py:11-91,105).
+ *   SFM_PROJECTION_FAST             q = D (M . pix) + P[:,3] with M = P[:, :3] . K^-1 folded once per wavefront; the strict in-view
+ *                                   test of transform.py:129 on U = q0 / z directly and the sample taken at (U, V).  16 vector
+ *                                   instructions per pixel row.  GUARANTEES: the five loss scalars to 1e-4 relative; the warped pixels
+ *                                   within 1e-4 of the image range of the reference's up to 128 x 416 frames; at 256 x 832, where one
+ *                                   ulp of a sampling position is 6e-5 px, within 2e-4 with fewer than 0.01 % of the pixels beyond 1e-4.
+ *   SFM_PROJECTION_REFERENCE_ORDER  the reference's own chain per pixel: ray = K^-1 . pix, c = D ray, q = Pm . (c, 1), U = q0 / z,
+ *                                   xn = U / ((W-1)/2.) - 1, the strict test on xn, the sampler's position (xn + 1) (W-1) / 2 --
+ *                                   every multiply, add and quotient rounded where the reference rounds it (quotients as v_rcp +
+ *                                   residual correction: the IEEE result except in rare double-rounding cases).  45 vector
+ *                                   instructions per pixel row: the launch is about 10 % longer.  GUARANTEES: warped pixels within
+ *                                   1e-4 of the image range at ANY frame size, seams, large motion and samples behind the camera
+ *                                   included, and gradients that need no second opinion (d_pose within 1e-5 of its maximum).
+ * Not available together with d_src (SFM_ERR_CONFIG). */
+#define SFM_PROJECTION_FAST 0
+#define SFM_PROJECTION_REFERENCE_ORDER 1
+
 typedef struct SfmLossDesc {
   int32_t B;        /* samples held by this call (a batch shard)                              */
   int32_t norm_B;   /* batch size used in every mean: the GLOBAL batch when sharded, else B   */
@@ -153,6 +172,7 @@ typedef struct SfmLossDesc {
    * was computed on, curr_proj_img of models/base_model.py:90-94, i.e. what projective_inverse_warp returns for source i
    * at scale s -- exactly 0 where the sample is not in view (:96).  Planar in both image layouts. (ABI v4) */
   float *warped[SFM_MAX_SCALES]; /* (B,n_src,3,h,w) or NULL; overwritten                      */
+  int32_t projection;            /* SFM_PROJECTION_* (ABI v5); 0 = SFM_PROJECTION_FAST        */
 } SfmLossDesc;
 
 /* scratch needed by the three calls below for this descriptor (0 on a bad descriptor) */
@@ -177,14 +197,10 @@ int sfm_loss_profile_events(void *ev_start, void *ev_stop);
  * and tuning; nothing is launched. */
 int sfm_loss_plan_info(const SfmLossDesc *desc, int grad, int loss, int *out, int n_out);
 
-/* Development / test hook: the projection of the NEXT sfm_loss_* call of the calling thread (whatever becomes of that call), then
- * back to 0.  0 = the product (geometry built in the wave, fused roundings: DESIGN.md 3); 1 = the same per-pixel chain on the
- * geometry of the reference's own products and divisions (euler2mat, K4 . T, batch_inv: models/transform.py:11-91,105);
- * 2 = the reference's evaluation order per pixel as well (transform.py:105-108,122-131 and the sampler's position, :189).
- * 1 and 2 exist for sfm_loss_fwd_bwd with SSIM and smoothness in SFM_LAYOUT_HWC (the benchmarked launches); ignored elsewhere.
- * 3 = every entry point, same arithmetic: the kernels read the header of their argument block from the struct instead of taking it
- * as preloaded scalar arguments -- the path of a batch or a tile count beyond 16 bits, which no test could reach otherwise
- * (results are bit-identical to 0). */
+/* Development / test hook, consumed by the NEXT sfm_loss_* call of the calling thread (whatever becomes of that call), then back
+ * to 0.  3 = the kernels read the header of their argument block from the struct instead of taking it as preloaded scalar arguments
+ * -- the path of a batch or a tile count beyond 16 bits, which no test could reach otherwise (results are bit-identical to 0).
+ * (Rounds 4-5 selected the projection with values 1 and 2 here: that is SfmLossDesc.projection since ABI v5.) */
 int sfm_loss_variant(int variant);
 /* Diagnostics: the NEXT sfm_loss_* call of this thread makes every wavefront of its main kernel
  * write {start, end (100 MHz realtime counter), HW_ID, XCC_ID} as 4 x uint64 per work item into

@@ -16,8 +16,10 @@ import torch  # noqa: F401
 
 SFM_MAX_SCALES = 8
 SFM_MAX_SRC = 8
-SFM_ABI_VERSION = 4
+SFM_ABI_VERSION = 5
 SFM_LAYOUT_PLANAR, SFM_LAYOUT_HWC = 0, 1
+SFM_PROJECTION_FAST, SFM_PROJECTION_REFERENCE_ORDER = 0, 1
+PROJECTIONS = {None: SFM_PROJECTION_FAST, "fast": SFM_PROJECTION_FAST, "reference_order": SFM_PROJECTION_REFERENCE_ORDER}
 
 SMOOTH_NONE, SMOOTH_SECOND_ORDER, SMOOTH_EDGE_AWARE = 0, 1, 2
 SMOOTH_MODES = {None: SMOOTH_NONE, "none": SMOOTH_NONE, "second_order": SMOOTH_SECOND_ORDER,
@@ -40,6 +42,7 @@ class SfmLossDesc(C.Structure):
         ("d_src", _FP * SFM_MAX_SCALES),
         ("image_layout", C.c_int32),
         ("warped", _FP * SFM_MAX_SCALES),
+        ("projection", C.c_int32),
     ]
 
 

@@ -24,7 +24,7 @@ namespace sfm {
 #ifdef SFM_STAMPS   // diagnostic build only: cycle stamps around the stages of a row step (never in the product build)
 #define SFM_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 struct Stamps { unsigned long long a_fin, a_iss, b, c, steps; };   // quad passes: cycles waited for start-S, start-G, finish-S, finish-G; steps = loop cycles
-__device__ Stamps g_dummy_stamps;
+static __device__ Stamps g_dummy_stamps;
 #define SFM_STAMPS_ARG , Stamps& st
 #define SFM_STAMPS_PASS , st
 #else
@@ -36,7 +36,9 @@ __device__ Stamps g_dummy_stamps;
 struct SsimCtx {
   // uniform (SGPR)
   float M1[3], P3[3];
-  float Kinv[9], Pm[12];   // REF == 2 only (the reference's own evaluation order, see issue_row): batch_inv(K) and rows 0..2 of K4 . T
+  // REF only (SFM_PROJECTION_REFERENCE_ORDER, see ref_position): columns 1 and 2 of batch_inv(K), rows 0..2 of K4 . T, (W-1)/2 and
+  // (H-1)/2 with their reciprocals (all wave-uniform); mx[] then holds Kinv[j][0] x
+  float Ki1[3], Ki2[3], Pm[12], hw[2], rhw[2];
   int x0;               // column of lane 0 (uniform); the lane's column is x0 + lane
   float k_pix;   // dL/d(sum |e|)        = gy (1-alpha) / (norm_B 3 h w)   base_model.py:111,117
   float kq;      // -dL/d(sum ssim)      = -gy alpha / (norm_B 3 h w): 2 kappa of App. A.3   base_model.py:115,117,142
@@ -223,14 +225,51 @@ __device__ __forceinline__ void inv3_fast(const float* K, float* o) {
   o[8] = fmaf(a, e, -(b * d)) * r;
 }
 
+// batch_inv for one general 3x3 in the REFERENCE's roundings (models/transform.py:105; oracle: batch_inv3): cofactors and determinant
+// as separate multiplies and adds (nothing fused), every element the correctly rounded quotient adj / det -- v_rcp + one Newton
+// step for 1 / det, then one residual correction per element (the IEEE result except in rare double-rounding cases).
+__device__ __forceinline__ void inv3_exact(const float* K, float* o) {
+  float adj[9], det;
+  {
+#pragma clang fp contract(off)
+    const float a = K[0], b = K[1], c = K[2], d = K[3], e = K[4], f = K[5], g = K[6], h = K[7], i = K[8];
+    const float A = e * i - f * h, B = -(d * i - f * g), Cc = d * h - e * g;
+    det = (a * A + b * B) + c * Cc;
+    adj[0] = A; adj[1] = -(b * i - c * h); adj[2] = b * f - c * e;
+    adj[3] = B; adj[4] = a * i - c * g; adj[5] = -(a * f - c * d);
+    adj[6] = Cc; adj[7] = -(a * h - b * g); adj[8] = a * e - b * d;
+  }
+  const float r = rcp_refined(det);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) o[k] = div_r(adj[k], det, r);
+}
+// a0 b0 + a1 b1 + a2 b2, left to right, nothing fused: one element of F.batch_matmul as the oracle evaluates it (_bmm)
+__device__ __forceinline__ float dot3_unfused(const float a0, const float b0, const float a1, const float b1, const float a2, const float b2) {
+#pragma clang fp contract(off)
+  return (a0 * b0 + a1 * b1) + a2 * b2;
+}
+
 struct WaveGeom {       // lane 8g+k: row k of source g (per-lane registers, alive for the whole wave)
   float M0, M1, M2;     // M = (K R) K^-1:  q = D (M . (x,y,1)) + P3
   float P3;             // K . t
 };
+// with REF (SfmLossDesc.projection = SFM_PROJECTION_REFERENCE_ORDER) the passes evaluate the reference's own chain per pixel: they
+// take the rows of Pm = K4 . T and of K^-1 themselves
+struct WaveGeomRef {
+  float P0, P1, P2, P3; // row k of Pm[:3, :]                      (transform.py:86-88)
+  float Ki0, Ki1, Ki2;  // row k of batch_inv(K)                   (transform.py:105)
+};
 
 // pose[g]: pointer to the (B,6) pose array of source g (kernel arguments: wave-uniform, NULL beyond n_src)
-__device__ __forceinline__ WaveGeom build_wave_geom(const float* const (&pose)[SFM_MAX_SRC], const int n_src, const int b,
-                                                    const float* Kp /* K of this (sample, scale) */, const int lane) {
+// Since round 6 the products are the REFERENCE's (round-5 verdict, item 1a): R = (X . Y) . Z, K . [R | t] and P[:, :3] . K^-1 as
+// separate multiplies and adds in the oracle's order (_bmm: left to right, nothing fused), K^-1 as correctly rounded quotients
+// (inv3_exact) -- about 50 more vector instructions per WAVE than the fused form of rounds 4-5 (of ~8 500), once, in the shadow of the
+// first loads.  With the fused roundings the projection rows differed from the reference's in the last bits, which at U ~ 800 is
+// the difference between 20 and 355 warped pixels beyond 1e-4 (profiles/r05_reference_order_variants.txt, variant 1).
+template <bool REFG>
+__device__ __forceinline__ void build_wave_geom_any(const float* const (&pose)[SFM_MAX_SRC], const int n_src, const int b,
+                                                    const float* Kp /* K of this (sample, scale) */, const int lane, WaveGeom& g,
+                                                    WaveGeomRef& gr) {
   const float pi = 3.14159265358979323846f;
   const int grp = lane >> 3, sub = lane & 7, base = lane & ~7;
   // One batch of loads: the lane's pose component (sub 0..2 the angles, 3..5 the translation) of ITS source, its row of K, all of K.
@@ -258,22 +297,50 @@ __device__ __forceinline__ WaveGeom build_wave_geom(const float* const (&pose)[S
   const float sx = from_lane_v(sn, base), sy = from_lane_v(sn, base + 1), sz = from_lane_v(sn, base + 2);
   const float cx = from_lane_v(cs, base), cy = from_lane_v(cs, base + 1), cz = from_lane_v(cs, base + 2);
   const float tx = from_lane_v(pv, base + 3), ty = from_lane_v(pv, base + 4), tz = from_lane_v(pv, base + 5);
-  // X . Y = [[cy, 0, sy], [sx sy, cx, -sx cy], [-cx sy, sx, cx cy]] ;  R = (X . Y) . Z   (transform.py:27-39)
-  const float xy10 = sx * sy, xy20 = -(cx * sy);
-  const float R[9] = {cy * cz, -(cy * sz), sy,
-                      fmaf(xy10, cz, cx * sz), fmaf(-xy10, sz, cx * cz), -(sx * cy),
-                      fmaf(xy20, cz, sx * sz), fmaf(-xy20, sz, sx * cz), cx * cy};
+  // X . Y = [[cy, 0, sy], [sx sy, cx, -sx cy], [-cx sy, sx, cx cy]] ;  R = (X . Y) . Z   (transform.py:27-39).  The products with
+  // the zeros and ones of X, Y, Z are exact and adding their zeros changes nothing, so these closed forms ARE the general products'
+  // values when the remaining two-term sums are evaluated unfused, as here.
+  float R[9];
+  {
+#pragma clang fp contract(off)
+    const float xy10 = sx * sy, xy20 = -(cx * sy), xy12 = -(sx * cy), xy22 = cx * cy;
+    R[0] = cy * cz;               R[1] = cy * (-sz);             R[2] = sy;
+    R[3] = xy10 * cz + cx * sz;   R[4] = xy10 * (-sz) + cx * cz; R[5] = xy12;
+    R[6] = xy20 * cz + sx * sz;   R[7] = xy20 * (-sz) + sx * cz; R[8] = xy22;
+  }
   float Kinv[9];
-  inv3_fast(Ku.k, Kinv);
-  // lane 8g+k: row k of P = K . [R | t] (transform.py:56-58,86-88) and of M = P[:, :3] . K^-1
+  inv3_exact(Ku.k, Kinv);
+  // lane 8g+k: row k of P = K . [R | t] (transform.py:56-58,86-88; the fourth term of K4 . T is a product with 0 or the lone 1 . t)
   float P[3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) P[j] = fmaf(Kr.c[2], R[6 + j], fmaf(Kr.c[1], R[3 + j], Kr.c[0] * R[j]));
+  for (int j = 0; j < 3; ++j) P[j] = dot3_unfused(Kr.c[0], R[j], Kr.c[1], R[3 + j], Kr.c[2], R[6 + j]);
+  const float P3 = dot3_unfused(Kr.c[0], tx, Kr.c[1], ty, Kr.c[2], tz);
+  if constexpr (REFG) {
+    gr.P0 = P[0]; gr.P1 = P[1]; gr.P2 = P[2]; gr.P3 = P3;
+    const int k = min(sub, 2);
+    gr.Ki0 = (k == 0) ? Kinv[0] : (k == 1) ? Kinv[3] : Kinv[6];
+    gr.Ki1 = (k == 0) ? Kinv[1] : (k == 1) ? Kinv[4] : Kinv[7];
+    gr.Ki2 = (k == 0) ? Kinv[2] : (k == 1) ? Kinv[5] : Kinv[8];
+  } else {
+    // ... and of M = P[:, :3] . K^-1
+    g.P3 = P3;
+    g.M0 = dot3_unfused(P[0], Kinv[0], P[1], Kinv[3], P[2], Kinv[6]);
+    g.M1 = dot3_unfused(P[0], Kinv[1], P[1], Kinv[4], P[2], Kinv[7]);
+    g.M2 = dot3_unfused(P[0], Kinv[2], P[1], Kinv[5], P[2], Kinv[8]);
+  }
+}
+__device__ __forceinline__ WaveGeom build_wave_geom(const float* const (&pose)[SFM_MAX_SRC], const int n_src, const int b,
+                                                    const float* Kp, const int lane) {
   WaveGeom g;
-  g.P3 = fmaf(Kr.c[2], tz, fmaf(Kr.c[1], ty, Kr.c[0] * tx));
-  g.M0 = fmaf(P[2], Kinv[6], fmaf(P[1], Kinv[3], P[0] * Kinv[0]));
-  g.M1 = fmaf(P[2], Kinv[7], fmaf(P[1], Kinv[4], P[0] * Kinv[1]));
-  g.M2 = fmaf(P[2], Kinv[8], fmaf(P[1], Kinv[5], P[0] * Kinv[2]));
+  WaveGeomRef unused;
+  build_wave_geom_any<false>(pose, n_src, b, Kp, lane, g, unused);
+  return g;
+}
+__device__ __forceinline__ WaveGeomRef build_wave_geom_ref(const float* const (&pose)[SFM_MAX_SRC], const int n_src, const int b,
+                                                           const float* Kp, const int lane) {
+  WaveGeom unused;
+  WaveGeomRef g;
+  build_wave_geom_any<true>(pose, n_src, b, Kp, lane, unused, g);
   return g;
 }
 
@@ -330,52 +397,93 @@ struct __attribute__((packed, aligned(4))) Rgb2 {   // two horizontally adjacent
   float c[6];
 };
 
+// The sampling position of one pixel in the REFERENCE's own evaluation order (SfmLossDesc.projection =
+// SFM_PROJECTION_REFERENCE_ORDER), statement for statement what the oracle -- and the stand-alone warp operator's ref_project,
+// sfm_ops.hip -- evaluate, nothing fused (models/transform.py:105-108, 122-131, and the sampler's own position, :189):
+//   ray = K^-1 . (x, y, 1) ;  c = D ray ;  q = Pm . (c, 1) ;  z = q2 + 1e-10 ;  U = q0 / z ;  xn = U / ((W-1)/2.) - 1 ;
+//   in view iff -1 < xn < 1 and -1 < yn < 1 ;  the sampler samples at (xn + 1) (W-1) / 2 on the image padded by one pixel.
+// Every DIVISION (1 / disp, q / z, U / half) is v_rcp + residual correction(s): the correctly rounded quotient except in rare
+// double-rounding cases, at 3-4 instructions instead of the ~10 of the IEEE sequence; the x and y components of every step share
+// one packed instruction.  45 vector instructions per row step against the 16 of the product's chain (FAST).
+struct RefPos {
+  f2 UV;        // (q0, q1) / z: what the backward's dL/dq2 = -(gU U + gV V) / z takes
+  f2 fr, cell;  // bilinear fractions and top-left tap (as floats, un-padded) of the SAMPLER's position
+  float rz, D;
+  bool inview;  // transform.py:129, on xn and yn
+};
+// ... as the integer cell the planar gather and the dL/d(src) scatter take.  In view the sampler's position lies in (1, W] -- W itself
+// when (xn + 1) rounds up to 2 -- so its cell can be the LAST column / row with a zero fraction: folded onto the cell before it with
+// fraction 1 (the same value; no tap beyond the image is ever addressed).
+__device__ __forceinline__ Proj ref_proj_cell(const RefPos& rp, const int h, const int w) {
+  Proj p;
+  p.U = rp.UV.x; p.V = rp.UV.y; p.rz = rp.rz; p.inview = rp.inview;
+  int u0 = (int)rp.cell.x, v0 = (int)rp.cell.y;
+  p.fu = rp.fr.x; p.fv = rp.fr.y;
+  if (u0 > w - 2) { u0 = w - 2; p.fu = 1.f; }
+  if (v0 > h - 2) { v0 = h - 2; p.fv = 1.f; }
+  p.u0 = rp.inview ? u0 : 0;
+  p.v0 = rp.inview ? v0 : 0;
+  return p;
+}
+__device__ __forceinline__ RefPos ref_position(const SsimCtx& C, const float yf, const float D /* 1 / disp, correctly rounded */) {
+  RefPos o;
+  o.D = D;
+  f2 ray, q, kxp, Ki1p, Ki2p, Pc0, Pc1, Pc2, Pc3, hwp, rhwp, whm1;
+  kxp.x = C.mx[0]; kxp.y = C.mx[1]; Ki1p.x = C.Ki1[0]; Ki1p.y = C.Ki1[1]; Ki2p.x = C.Ki2[0]; Ki2p.y = C.Ki2[1];
+  Pc0.x = C.Pm[0]; Pc0.y = C.Pm[4]; Pc1.x = C.Pm[1]; Pc1.y = C.Pm[5]; Pc2.x = C.Pm[2]; Pc2.y = C.Pm[6]; Pc3.x = C.Pm[3]; Pc3.y = C.Pm[7];
+  hwp.x = C.hw[0]; hwp.y = C.hw[1]; rhwp.x = C.rhw[0]; rhwp.y = C.rhw[1]; whm1.x = C.sc.wm1; whm1.y = C.sc.hm1;
+  float q2;
+  {
+#pragma clang fp contract(off)
+    ray = (kxp + Ki1p * yf) + Ki2p;                                   // transform.py:105-106 (the third pixel coordinate is 1)
+    const float ray2 = (C.mx[2] + C.Ki1[2] * yf) + C.Ki2[2];
+    const f2 c = ray * o.D;                                           // :107
+    const float c2 = ray2 * o.D;
+    q = ((Pc0 * c.x + Pc1 * c.y) + Pc2 * c2) + Pc3;                   // :122 (the fourth camera coordinate is 1, :108)
+    q2 = ((C.Pm[8] * c.x + C.Pm[9] * c.y) + C.Pm[10] * c2) + C.Pm[11];
+  }
+  const float z = q2 + 1e-10f;                                        // :123
+  o.rz = rcp(z);
+  const f2 qr = q * o.rz;
+  o.UV = vfma(vfma(-qr, T_of<f2>(z), q), T_of<f2>(o.rz), qr);         // :124-125, the quotients
+  const f2 xr = o.UV * rhwp;
+  const f2 xn = vfma(vfma(-xr, hwp, o.UV), rhwp, xr) - 1.0f;          // ... / ((W-1)/2.) - 1
+  // -1 < xn < 1 exactly when 1 - xn^2 > 0 (one rounding of the exact value: the sign is right to the last bit; a NaN fails)
+  const f2 t = vfma(-xn, xn, T_of<f2>(1.0f));
+  o.inview = (t.x > 0.0f) & (t.y > 0.0f);                             // :129
+  f2 up;
+  {
+#pragma clang fp contract(off)
+    up = ((xn + 1.0f) * whm1) * 0.5f + 1.0f;                          // the sampler's position on the zero-padded image: in (1, W) in view
+  }
+  o.fr.x = __builtin_amdgcn_fractf(up.x); o.fr.y = __builtin_amdgcn_fractf(up.y);
+  o.cell = (up - o.fr) - 1.0f;                                        // floor(up) - 1: the top-left tap, un-padded
+  return o;
+}
+
 // HWC: the images are pixel-interleaved (SFM_LAYOUT_HWC): C.tp[0] / C.sp[0] are the (h,w,3) images of this sample /
 // (sample, source), and the three channels of a tap come with one load.
-// REF (experiment of round 5, SSIM gradient kernels in the pixel-interleaved layout only; picked by sfm_loss_variant):
-//   0  the product: q = D (M . pix) + P3 with M, P3 from the in-wave geometry, quotients from v_rcp + one residual correction,
-//      the in-view test on U, V directly
-//   1  the same per-pixel chain on the geometry of make_geom (exact euler2mat products, IEEE divisions, nothing fused)
-//   2  the reference's evaluation order per pixel as well (the stand-alone warp operator's ref_project, sfm_ops.hip):
-//      ray = K^-1 . pix, c = D ray, q = Pm . (c, 1), U = q0 / z (IEEE), xn = U / ((W-1)/2.) - 1, the strict test on xn, and the
-//      sampler's own position (xn + 1) (W-1) / 2 (transform.py:105-108,122-131,189) -- nothing fused
+// REF: 0 the product's chain (SFM_PROJECTION_FAST): q = D (M . pix) + P3, the in-view test on U, V directly, the sample at (U, V);
+//      1 the reference's evaluation order per pixel (SFM_PROJECTION_REFERENCE_ORDER, ref_position above).
 template <bool HWC, int REF = 0>
 __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const float disp, Pipe& ps) {
   const float yf = (float)r;
-  // depth = 1 / disp (base_model.py:60) from v_rcp_f32 alone (1 ulp): the quotients U = q0/z, V = q1/z below keep their residual
-  // correction (they decide the strict in-view test), the depth does not need one -- a last-bit change of D moves the sample by
-  // 1e-7 of its parallax
-  ps.D = rcp(disp);
   Proj p;
   f2 UV, fr, cell;
   float rz;
-  if constexpr (HWC && REF == 2) {
-#pragma clang fp contract(off)
-    const float Dr = 1.0f / disp;                                     // base_model.py:60, IEEE division
-    ps.D = Dr;
-    const float xf = (float)(C.x0 + C.lane);
-    float ray[3], c[3], q[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      ray[j] = (C.Kinv[j * 3 + 0] * xf + C.Kinv[j * 3 + 1] * yf) + C.Kinv[j * 3 + 2];
-      c[j] = Dr * ray[j];
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) q[k] = ((C.Pm[k * 4 + 0] * c[0] + C.Pm[k * 4 + 1] * c[1]) + C.Pm[k * 4 + 2] * c[2]) + C.Pm[k * 4 + 3];
-    const float z = q[2] + 1e-10f;
-    const float U = q[0] / z, V = q[1] / z;
-    const float half_w = (float)((double)C.sc.wm1 / 2.0), half_h = (float)((double)C.sc.hm1 / 2.0);
-    const float xn = U / half_w - 1.0f, yn = V / half_h - 1.0f;
-    p.inview = (xn > -1.0f) & (xn < 1.0f) & (yn > -1.0f) & (yn < 1.0f);
-    // the sampler's position on the zero-padded image (pad_taps, sfm_ops.hip): up in (1, W) for an in-view sample
-    const float up = (xn + 1.0f) * C.sc.wm1 * 0.5f + 1.0f, vp = (yn + 1.0f) * C.sc.hm1 * 0.5f + 1.0f;
-    const float fu = floorf(up), fv = floorf(vp);
-    fr.x = up - fu; fr.y = vp - fv;
-    cell.x = p.inview ? fu - 1.0f : 0.f; cell.y = p.inview ? fv - 1.0f : 0.f;   // the top-left tap, unpadded
-    UV.x = U; UV.y = V;                                               // (the backward's dL/dq2 = -(gU U + gV V) / z takes the quotients)
-    rz = 1.0f / z;
+  if constexpr (REF != 0) {
+    const RefPos rp = ref_position(C, yf, rcp_refined(disp));         // base_model.py:60: depth = 1 / disp
+    ps.D = rp.D; UV = rp.UV; fr = rp.fr; cell = rp.cell; rz = rp.rz; p.inview = rp.inview;
     p.u0 = p.v0 = 0;
+    if constexpr (!HWC) {
+      p = ref_proj_cell(rp, C.h, C.w);
+      fr.x = p.fu; fr.y = p.fv;
+    }
   } else if constexpr (HWC) {
+    // depth = 1 / disp (base_model.py:60) from v_rcp_f32 alone (1 ulp): the quotients U = q0/z, V = q1/z below keep their residual
+    // correction (they decide the strict in-view test), the depth does not need one -- a last-bit change of D moves the sample by
+    // 1e-7 of its parallax
+    ps.D = rcp(disp);
     // The projection of sfm_common.h's project(), with the x and y components of every step in ONE packed instruction (the same
     // IEEE operations per component: bit-identical values, two thirds of the instructions):
     //   a = M (x,y,1) ; q = D a + P[:,3] ; z = q2 + 1e-10 ; (U,V) = (q0,q1) / z ; in view iff U (W-1-U) > 0 and V (H-1-V) > 0
@@ -396,6 +504,7 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
     p.u0 = p.v0 = 0;   // (the pixel-interleaved gather forms its offset from the cell = UV - fr)
   } else {
     // (the planar gather needs the integer cell as well, and measured 4 % slower with the packed chain in front of it)
+    ps.D = rcp(disp);
     const float a0 = fmaf(C.M1[0], yf, C.mx[0]), a1 = fmaf(C.M1[1], yf, C.mx[1]), a2 = fmaf(C.M1[2], yf, C.mx[2]);
     p = project(a0, a1, a2, C.P3[0], C.P3[1], C.P3[2], ps.D, C.sc, C.h, C.w);
     UV.x = p.U; UV.y = p.V; fr.x = p.fu; fr.y = p.fv; rz = p.rz;
@@ -627,7 +736,7 @@ __device__ __forceinline__ void dsrc_finish(const SsimCtx& C, const PoseAcc& gpm
 
 // From dL/dI^ of one pixel (already contracted with dI^/du, dI^/dv and 1/z into gq = (gq0, gq1)) to its
 // share of d_depth (LDS tile), of the 12 sums of dL/dPm and, optionally, of dL/d(src).
-template <int DR /* rows of the dL/d(src) window; 0: the output is not produced */>
+template <int DR /* rows of the dL/d(src) window; 0: the output is not produced */, int REF = 0>
 __device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& s2, const int rc, const f2 gq,
                                                   const float* gI, float* gacc, const bool first, PoseAcc& gpm) {
   const int h = C.h, w = C.w;
@@ -656,8 +765,13 @@ __device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& 
   // (DSRC: the instantiations a launch with SfmLossDesc.d_src bound runs.  A run-time branch here -- rounds 1-4 -- costs the kernels
   //  of every OTHER launch registers: with the window code behind it the SSIM gradient kernels spill 32 VGPRs)
   if (DR != 0 && C.dsp != nullptr) {   // optional dL/d(src): scatter of dL/dI^ over the four taps, through the LDS window
-    const float a0 = fmaf(C.M1[0], yf, C.mx[0]), a1 = fmaf(C.M1[1], yf, C.mx[1]), a2 = fmaf(C.M1[2], yf, C.mx[2]);
-    const Proj p = project(a0, a1, a2, C.P3[0], C.P3[1], C.P3[2], s2.D, C.sc, h, w);
+    Proj p;
+    if constexpr (REF != 0) {
+      p = ref_proj_cell(ref_position(C, yf, s2.D), h, w);
+    } else {
+      const float a0 = fmaf(C.M1[0], yf, C.mx[0]), a1 = fmaf(C.M1[1], yf, C.mx[1]), a2 = fmaf(C.M1[2], yf, C.mx[2]);
+      p = project(a0, a1, a2, C.P3[0], C.P3[1], C.P3[2], s2.D, C.sc, h, w);
+    }
     dsrc_scatter<DR == 0 ? 4 : DR>(C, p, p.inview && C.outf != 0.f, gI, gpm);
   }
 }
@@ -797,7 +911,7 @@ __device__ __forceinline__ f2 contract_uv(const RowS& s, const f2 gp, const floa
 
 // Stage C at row rc (the row in s2; partials of the rows rc-1, rc, rc+1 in g2, g1, g0): dL/dI^ -> dL/d(u,v) -> dL/dq -> d_depth
 // tile and the sums of dL/dPm.
-template <bool LOSS, bool DSRC>
+template <bool LOSS, bool DSRC, int REF = 0>
 __device__ __forceinline__ void ssim_stage_c_row(const SsimCtx& C, const int rc, const RowS& s2, const RowG& g2, const RowG& g1,
                                                  const RowG& g0, float* gacc, const bool first, PoseAcc& gpm, float& acc_pix) {
   const float kpn = C.k_pix * s2.nm;
@@ -809,7 +923,7 @@ __device__ __forceinline__ void ssim_stage_c_row(const SsimCtx& C, const int rc,
   // and I^ - I is at hand (with the fused kernel stage B would form it a second time, one row earlier)
   if (LOSS) acc_pix = fmaf(vabs_sum(dp) + vabs_sum(ds), s2.nm * C.outf, acc_pix);
   const float gI[3] = {gp.x, gp.y, gs};
-  geometry_backward<DSRC ? 8 : 0>(C, s2, rc, contract_uv(s2, gp, gs), gI, gacc, first, gpm);
+  geometry_backward<DSRC ? 8 : 0, REF>(C, s2, rc, contract_uv(s2, gp, gs), gI, gacc, first, gpm);
 }
 
 // Which stages run on which step of a pass, as bit k of one 32-bit word per question (a pass has at most 32 steps): every
@@ -867,7 +981,7 @@ __device__ __forceinline__ void ssim_row_step(const SsimCtx& C, const StepMasks&
   // ---------------- C: gradients at row r-2 ----------------
   if (GRAD) {
     if (step_bit(M.c, k)) {
-      ssim_stage_c_row<LOSS, DSRC>(C, r - 2, s2, g2, g1, g0, gacc, first, gpm, acc_pix);
+      ssim_stage_c_row<LOSS, DSRC, REF>(C, r - 2, s2, g2, g1, g0, gacc, first, gpm, acc_pix);
     }
   }
   SFM_STAMP(t4);
@@ -921,7 +1035,7 @@ __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, 
 
 // Photometric pass WITHOUT SSIM for one (wave, source): L1 (+ explainability weighting, base_model.py:103-109).
 // Everything is per pixel, so there is no ring; the loads of row r+1 are in flight while row r is finished.
-template <bool GRAD, bool LOSS, bool EXPL, bool HWC, bool WARPED, bool DSRC = false>
+template <bool GRAD, bool LOSS, bool EXPL, bool HWC, bool WARPED, int REF = 0, bool DSRC = false>
 __device__ __forceinline__ void l1_source_pass(const SsimCtx& C, float* gacc, const bool first, float& acc_pix, float& acc_exp,
                                                float* gpm_out) {
   PoseAcc gpm;    // A_k, B_k, C_k of geometry_backward
@@ -930,14 +1044,14 @@ __device__ __forceinline__ void l1_source_pass(const SsimCtx& C, float* gacc, co
   ps.lg = 0.f;
   float disp_next = 1.f;
   const int rbeg = C.y0, rend = C.y1;    // rows of a chunk are always inside the image
-  issue_row<HWC>(C, rbeg, C.disp_first, ps);
+  issue_row<HWC, REF>(C, rbeg, C.disp_first, ps);
   if (rbeg + 1 < rend) disp_next = C.disp_second;
   for (int r = rbeg; r < rend; ++r) {
     RowS s0;
     finish_row<HWC>(C, ps, s0);
     if constexpr (WARPED) store_warped_row(C, r, s0);
     const float lg = ps.lg;
-    if (r + 1 < rend) issue_row<HWC>(C, r + 1, disp_next, ps);
+    if (r + 1 < rend) issue_row<HWC, REF>(C, r + 1, disp_next, ps);
     disp_next = ldf(C.dp, (unsigned)min(r + 2, C.h - 1) * (unsigned)C.w + C.xc);
     float sgm = 1.f;
     if (EXPL) {
@@ -955,7 +1069,7 @@ __device__ __forceinline__ void l1_source_pass(const SsimCtx& C, float* gacc, co
         // d/dlogit of (1-alpha) mean(err sigmoid) + exp_reg mean(softplus(-logit))
         if (C.outf != 0.f) stf_wt(C.dmp, (unsigned)r * (unsigned)C.w + C.xc, C.k_pix * e1 * sgm * (1.f - sgm) + C.k_exp * (sgm - 1.f));
       }
-      geometry_backward<DSRC ? 4 : 0>(C, s0, r, contract_uv(s0, gp, gs), gI, gacc, first, gpm);
+      geometry_backward<DSRC ? 4 : 0, REF>(C, s0, r, contract_uv(s0, gp, gs), gI, gacc, first, gpm);
     }
   }
   if (GRAD) {

@@ -94,11 +94,14 @@ class SFMLearnerLoss:
       gradients across iterations copies them, or passes cache_buffers=False).  A `backward()` on the loss of an EARLIER
       call, after the link has been called again, raises instead of handing out the later call's gradients.  The returned
       loss and the five reported scalars are per-call arrays: they keep their values.
+    projection (default "fast"): "reference_order" evaluates the per-pixel projection in the reference's own rounding sequence
+      (warped pixels within 1e-4 of the reference's at any frame size; the launch is about 10 % longer; include/sfmwarp.h).
     use_graph (default False): when a call repeats the previous call's arrays exactly (same addresses: static input buffers),
       the pyramid launch and the three launches of the loss are replayed from one HIP graph.
     """
 
-    def __init__(self, config, pretrained_model=None, smooth_mode="second_order", cache_buffers=True, use_graph=False):
+    def __init__(self, config, pretrained_model=None, smooth_mode="second_order", cache_buffers=True, use_graph=False,
+                 projection="fast"):
         # models/base_model.py:34-39
         self.n_sources = config['seq_len'] - 1
         self.smooth_reg = config['smooth_reg']
@@ -106,6 +109,8 @@ class SFMLearnerLoss:
         self.ssim_rate = parse_dict(config, 'ssim_rate', 0.0)
         # base_model.py:75-80: the second-order form is live, the edge-aware one is commented out there
         self.smooth_mode = smooth_mode
+        # "fast" or "reference_order": how the kernels evaluate transform.py:94-133 per pixel (include/sfmwarp.h, SFM_PROJECTION_*)
+        self.projection = projection
         self.xp = torch
         self.cache_buffers = cache_buffers
         self.use_graph = use_graph
@@ -122,7 +127,7 @@ class SFMLearnerLoss:
             st.pyr = None
             _build_pyramids(st, tgt, stacked, len(disps))
             st.fused = ops.FusedLoss(smooth_reg=self.smooth_reg or 0.0, exp_reg=self.exp_reg or 0.0,
-                                     ssim_rate=self.ssim_rate or 0.0, smooth_mode=self.smooth_mode)
+                                     ssim_rate=self.ssim_rate or 0.0, smooth_mode=self.smooth_mode, projection=self.projection)
             st.fused.bind(st.pyr[0], st.pyr[1], intrinsics, disps, poses, masks, norm_B=norm_batch, layout=st.layout)
             st.graph = st.graph_key = st.graph_stream = None
             st.calls = 0

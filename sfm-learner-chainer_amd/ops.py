@@ -279,9 +279,14 @@ class FusedLoss:
     descriptor + caller-owned workspace and outputs.  Re-usable across steps as long as the
     input tensors keep their addresses (call `bind` again otherwise)."""
 
-    def __init__(self, smooth_reg=0.0, exp_reg=0.0, ssim_rate=0.0, smooth_mode="second_order"):
+    def __init__(self, smooth_reg=0.0, exp_reg=0.0, ssim_rate=0.0, smooth_mode="second_order", projection="fast"):
+        """projection: "fast" (SFM_PROJECTION_FAST) or "reference_order" (SFM_PROJECTION_REFERENCE_ORDER: the per-pixel chain of
+        models/transform.py:105-108,122-131 in the reference's own rounding sequence; include/sfmwarp.h says what each guarantees)."""
         if smooth_mode not in _lib.SMOOTH_MODES:
             raise ValueError("smooth_mode must be one of %s" % sorted(k for k in _lib.SMOOTH_MODES if k))
+        if projection not in _lib.PROJECTIONS:
+            raise ValueError("projection must be one of %s" % sorted(k for k in _lib.PROJECTIONS if k))
+        self.projection = _lib.PROJECTIONS[projection]
         self.smooth_reg = float(smooth_reg or 0.0)
         self.exp_reg = float(exp_reg or 0.0)
         self.ssim_rate = float(ssim_rate or 0.0)
@@ -323,6 +328,7 @@ class FusedLoss:
         d.smooth_reg, d.exp_reg, d.ssim_rate, d.smooth_mode = self.smooth_reg, self.exp_reg, self.ssim_rate, self.smooth_mode
         d.intrinsics = intrinsics.data_ptr()
         d.image_layout = _lib.SFM_LAYOUT_HWC if hwc else _lib.SFM_LAYOUT_PLANAR
+        d.projection = self.projection
         d_disps, d_masks, d_srcs, warped = [], [], [], []
         for s in range(S):
             h, w = disps[s].shape[2:]
@@ -432,8 +438,7 @@ class FusedLoss:
     def forward_backward(self, out=None, variant=0):
         """`out`: optional (5,) float32 device tensor to receive the five scalars instead of `self.loss5`
         (lets a caller keep a log of the steps of a reporting interval and reduce it across ranks once).
-        `variant`: development hook (sfm_loss_variant): 1 = the projection on the reference's own geometry products, 2 = in the
-        reference's evaluation order per pixel as well; only the SSIM + smoothness launches in the hwc layout have them."""
+        `variant`: development hook (sfm_loss_variant): 3 = the kernels read their header from the argument struct."""
         self._zero_d_src()
         loss5 = self.loss5 if out is None else out
         if variant:

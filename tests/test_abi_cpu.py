@@ -30,11 +30,26 @@ def test_library_exports_every_declared_symbol():
 
 def test_descriptor_layout_matches_the_header():
     # 4 + 8 + 8 int32, 3 float, 1 int32, then 4*8 + 1 + 8 + 8 + 8 + 8 + 8 pointers, then image_layout (int32, padded to 8),
-    # then the 8 pointers of `warped` (ABI v4)
-    assert C.sizeof(_lib.SfmLossDesc) == 4 * (4 + 8 + 8 + 3 + 1) + 8 * (8 * 4 + 1 + 8 + 8 * 3 + 8) + 8 + 8 * 8
+    # then the 8 pointers of `warped` (ABI v4), then projection (int32, padded to 8; ABI v5)
+    assert C.sizeof(_lib.SfmLossDesc) == 4 * (4 + 8 + 8 + 3 + 1) + 8 * (8 * 4 + 1 + 8 + 8 * 3 + 8) + 8 + 8 * 8 + 8
     assert _lib.SfmLossDesc.tgt.offset % 8 == 0
-    assert _lib.SfmLossDesc.image_layout.offset == C.sizeof(_lib.SfmLossDesc) - 8 - 8 * 8
-    assert _lib.SfmLossDesc.warped.offset == C.sizeof(_lib.SfmLossDesc) - 8 * 8
+    assert _lib.SfmLossDesc.image_layout.offset == C.sizeof(_lib.SfmLossDesc) - 8 - 8 * 8 - 8
+    assert _lib.SfmLossDesc.warped.offset == C.sizeof(_lib.SfmLossDesc) - 8 * 8 - 8
+    assert _lib.SfmLossDesc.projection.offset == C.sizeof(_lib.SfmLossDesc) - 8
+
+
+def test_projection_field_is_validated_without_a_gpu():
+    """SfmLossDesc.projection (ABI v5): FAST and REFERENCE_ORDER size the same workspace; any other value, and REFERENCE_ORDER
+    together with d_src, are SFM_ERR_CONFIG from every entry point."""
+    d = _desc(ssim_rate=0.15, smooth_reg=0.1, smooth_mode=_lib.SMOOTH_SECOND_ORDER)
+    n = _lib.lib.sfm_loss_workspace_bytes(C.byref(d))
+    d.projection = _lib.SFM_PROJECTION_REFERENCE_ORDER
+    assert _lib.lib.sfm_loss_workspace_bytes(C.byref(d)) == n > 0
+    d.d_src[0] = d.d_src[1] = 0x1000
+    assert _lib.lib.sfm_loss_workspace_bytes(C.byref(d)) == 0
+    assert _lib.lib.sfm_loss_fwd(C.byref(d), None, None, 0, None) == _lib.ERR_CONFIG and "d_src" in _lib.last_error()
+    d = _desc(projection=2)
+    assert _lib.lib.sfm_loss_fwd(C.byref(d), None, None, 0, None) == _lib.ERR_CONFIG and "projection" in _lib.last_error()
 
 
 def _desc(**kw):

@@ -28,8 +28,8 @@ def _oracle(d, cfg, norm_B=None, want_d_src=False):
                       backward=True, want_d_src=want_d_src, keep_warped=True, norm_batch=norm_B, **cfg)
 
 
-def _bind(ops, dev, d, cfg, norm_B=None, want_d_src=False, layout="planar", want_warped=False):
-    fl = ops.FusedLoss(**cfg)
+def _bind(ops, dev, d, cfg, norm_B=None, want_d_src=False, layout="planar", want_warped=False, projection="fast"):
+    fl = ops.FusedLoss(projection=projection, **cfg)
     tgt, src = [to_dev(a, dev) for a in d["tgt_pyr"]], [to_dev(a, dev) for a in d["src_pyr"]]
     if layout == "hwc":      # the same values, pixel-interleaved (SFM_LAYOUT_HWC)
         tgt, src = [ops.to_hwc(a) for a in tgt], [ops.to_hwc(a) for a in src]
@@ -732,7 +732,12 @@ def test_warped_pixels_at_256x832_on_seam_free_inputs(ops, synth, dev):
     """BASELINE cfg5 (B=8, 256x832, 4 sources) on seam-free inputs.  At U ~ 800 one ulp of a sampling position is 6e-5 px and two
     correct fp32 evaluations of it lie up to 3e-4 px apart: the product kernel is held to a flat 2e-4 of the range with at most
     0.01 % of the pixels above 1e-4, next to the yardstick -- how far the fp32 ORACLE is from the fp64 one on the same inputs -- and
-    the kernel's reference-order variant (sfm_loss_variant(2): the oracle's own rounding sequence per pixel) to the flat 1e-4."""
+    the same launch with projection="reference_order" (SFM_PROJECTION_REFERENCE_ORDER: the oracle's own rounding sequence per pixel,
+    a mode a caller selects in the descriptor since ABI v5) to the FLAT 1e-4 with NO pixel above it, and its gradients by the usual
+    criteria.  (The mode follows the oracle's roundings up to sin / cos of the pose angles -- NumPy's float32 sin / cos differ
+    between CPUs -- so one source in a few has a projection that differs in the last bits; tools/diag_ref_pose.py: at this size that is
+    source 2, where the fp32 ORACLE is 3.4e-3 of the maximum from the fp64 one on d_pose of one sample and this mode 2e-4.  The fp64
+    second opinion is therefore offered here too; which rung decided is recorded.)"""
     cfg = CONFIGS["ssim_smooth"]
     B, H, W, n_src = 8, 256, 832, 4
     d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=4, seed=1, seam="shift")
@@ -754,32 +759,73 @@ def test_warped_pixels_at_256x832_on_seam_free_inputs(ops, synth, dev):
     o64 = max(float(np.abs(a - b).max(axis=2)[(a == 0).all(axis=2) == (b == 0).all(axis=2)].max()) for a, b in zip(ref["warped"], ref64["warped"]))
     parity_note("yardstick SEAM-FREE cfg5: the KERNEL is more than 1e-4 of the range from the fp64 oracle at %d of %d warped pixels (worst %.2e; the fp32 oracle's worst %.2e)" % (
         k64, n_px, w64, o64))
-    _check_losses(fl.forward_backward(variant=2), ref)
-    _check_warped(fl, ref, what + " [reference-order variant]", d, flat=True)
+    fr = _bind(ops, dev, d, cfg, layout="hwc", want_warped=True, projection="reference_order")
+    _check_losses(fr.forward_backward(), ref)
+    _check_warped(fr, ref, what + " [projection = reference_order]", d, flat=True, max_over_flat=0)
+    refb = O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], None, backward=True, keep_warped=True, **cfg)
+    ref64b = lambda: O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], None, backward=True, dtype=np.float64, **cfg)
+    _check_grads(fr, refb, n_src, what=what + " [projection = reference_order]", ref64=ref64b, **knife_widths(d, refb))
 
 
 @pytest.mark.parametrize("motion", [None, "behind", "large"])
-def test_reference_order_variant_meets_the_flat_tolerance_on_rolled_inputs(ops, synth, dev, motion):
-    """sfm_loss_variant(2) -- the fused kernel with the projection in the reference's own evaluation order (transform.py:105-108,
-    122-131,189; nothing fused, IEEE divisions) -- against the oracle on the ROLLED inputs, seam included: every warped pixel within
-    the FLAT 1e-4, no pixel zeroed differently away from the strict test, the loss and every gradient by the usual criteria.  What
-    separates the product kernel from the flat criterion on a contrast-2.0 seam is therefore the rounding sequence of the sampling
-    position, nothing else (profiles/r05_reference_order_variants.txt: +30 % kernel time, not the product)."""
+def test_reference_order_projection_meets_the_flat_tolerance_on_rolled_inputs(ops, synth, dev, motion):
+    """projection="reference_order" (SfmLossDesc.projection = SFM_PROJECTION_REFERENCE_ORDER) -- the fused kernel with the projection
+    in the reference's own evaluation order (transform.py:105-108,122-131,189; nothing fused, quotients as v_rcp + residual
+    correction) -- against the oracle on the ROLLED inputs, seam included: every warped pixel within the FLAT 1e-4, no pixel zeroed
+    differently away from the strict test, the loss and every gradient by the flat criteria (no fp64 second opinion is offered).
+    What separates the FAST projection from the flat criterion on a contrast-2.0 seam is therefore the rounding sequence of the
+    sampling position, nothing else (profiles/r06_reference_order.txt has the kernel times)."""
     cfg = CONFIGS["edge_aware"]
     kw = dict(B=4, H=128, W=416, n_src=2, n_scales=4)
     d = synth.make_inputs(seed=1, **kw) if motion is None else make_motion_inputs(synth, motion, seed=21, **kw)
     ref = _oracle(d, cfg)
-    ref64 = lambda: O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], None, backward=True, keep_warped=True,
-                               dtype=np.float64, **cfg)
-    what = "REFERENCE-ORDER VARIANT %s edge_aware B=4 128x416 hwc" % (motion or "default motion")
-    fl = _bind(ops, dev, d, cfg, layout="hwc", want_warped=True)
-    _check_losses(fl.forward_backward(variant=2), ref)
-    _check_warped(fl, ref, what, d, flat=True)
-    explain = lambda i, got: pose_explained_by_discontinuities(d, cfg, ref, i, got)
-    _check_grads(fl, ref, 2, what=what, ref64=ref64, explain=explain, **knife_widths(d, ref))
-    # ... and variant 1 (the reference's geometry products, the product's per-pixel chain) by the criteria of the product kernel
-    _check_losses(fl.forward_backward(variant=1), ref)
-    _check_warped(fl, ref, what.replace("REFERENCE-ORDER", "REFERENCE-GEOMETRY"), d)
+    what = "REFERENCE-ORDER PROJECTION %s edge_aware B=4 128x416 hwc" % (motion or "default motion")
+    fl = _bind(ops, dev, d, cfg, layout="hwc", want_warped=True, projection="reference_order")
+    _check_losses(fl.forward_backward(), ref)
+    _check_warped(fl, ref, what, d, flat=True, max_over_flat=0)
+    _check_grads(fl, ref, 2, what=what, **knife_widths(d, ref))
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+@pytest.mark.parametrize("shape", [(2, 32, 48, 2, 3), (3, 20, 130, 4, 2)])
+def test_reference_order_projection_every_mode_entry_point_and_layout(ops, synth, dev, name, shape):
+    """SFM_PROJECTION_REFERENCE_ORDER exists for every launch the FAST projection has (all loss modes, the three entry points, both
+    image layouts, with and without the warped output) except the ones that also produce d_src: each against the oracle by the
+    usual criteria, the warped pixels by the FLAT one, planar = hwc, fused = separate."""
+    B, H, W, n_src, n_scales = shape
+    cfg = CONFIGS[name]
+    d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=n_scales, seed=19, with_masks=True)
+    ref = _oracle(d, cfg)
+    outs = {}
+    for layout in ("planar", "hwc"):
+        fl = _bind(ops, dev, d, cfg, layout=layout, want_warped=True, projection="reference_order")
+        _check_losses(fl.forward(), ref)
+        _check_warped(fl, ref, "REFERENCE-ORDER PROJECTION %s %s [sfm_loss_fwd]" % (name, layout), d, flat=True, max_over_flat=0)
+        fl.backward(1.0)
+        _check_grads(fl, ref, n_src, check_mask=bool(cfg.get("exp_reg")), what="REFERENCE-ORDER PROJECTION %s %s" % (name, layout))
+        g_sep = [to_np(t).copy() for t in fl.d_disps + fl.d_poses + (fl.d_masks or [])]
+        l_fused = to_np(fl.forward_backward()).copy()
+        _check_losses(l_fused, ref)
+        _check_warped(fl, ref, "REFERENCE-ORDER PROJECTION %s %s [sfm_loss_fwd_bwd]" % (name, layout), d, flat=True, max_over_flat=0)
+        g_fused = [to_np(t).copy() for t in fl.d_disps + fl.d_poses + (fl.d_masks or [])]
+        for a, b in zip(g_sep, g_fused):
+            np.testing.assert_allclose(a, b, rtol=0, atol=2e-5 * max(np.abs(a).max(), 1e-30))
+        plain = _bind(ops, dev, d, cfg, layout=layout, projection="reference_order")      # the launch WITHOUT the warped output: same bits
+        np.testing.assert_array_equal(to_np(plain.forward_backward()), l_fused)
+        for a, b in zip([to_np(t) for t in plain.d_disps + plain.d_poses], g_fused):
+            np.testing.assert_array_equal(a, b)
+        outs[layout] = (l_fused, g_fused)
+    np.testing.assert_allclose(outs["hwc"][0], outs["planar"][0], rtol=2e-7, atol=0)
+    for a, b in zip(outs["planar"][1], outs["hwc"][1]):
+        np.testing.assert_allclose(b, a, rtol=0, atol=2e-5 * max(np.abs(a).max(), 1e-30))
+
+
+def test_reference_order_projection_is_refused_together_with_d_src(ops, synth, dev):
+    d = synth.make_inputs(B=1, H=24, W=40, n_src=2, n_scales=2, seed=3, with_masks=True)
+    with pytest.raises(ValueError, match="d_src"):
+        _bind(ops, dev, d, CONFIGS["ssim_smooth"], want_d_src=True, layout="hwc", projection="reference_order")
+    with pytest.raises(ValueError, match="projection"):
+        ops.FusedLoss(projection="exact")
 
 
 MOTIONS = {

@@ -24,7 +24,7 @@ def to_dev(a, dev):
 
 
 def to_np(t):
-    return t.detach().cpu().numpy()
+    return t if isinstance(t, np.ndarray) else t.detach().cpu().numpy()
 
 
 from oracle.parity import dilate  # noqa: E402,F401  (shared with __graft_entry__.smoke())

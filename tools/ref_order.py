@@ -1,15 +1,18 @@
 #!/usr/bin/env python3
-"""Round-5 experiment (verdict item 2c): the fused kernel's projection in the REFERENCE's evaluation order, measured.
+"""The two projections of the fused kernel (SfmLossDesc.projection, ABI v5) measured next to each other.
 
-    python tools/ref_order.py [--quick]     (GPU; writes gpurun_out/ref_order.txt)
+    python tools/ref_order.py [--quick]     (GPU; writes gpurun_out/ref_order.txt -> profiles/r06_reference_order.txt)
 
-For every case x {rolled, seam-free} inputs x variant (sfm_loss_variant: 0 = product, 1 = reference geometry products + the
-product's per-pixel chain, 2 = reference order per pixel as well) prints
+For every case x {rolled, seam-free} inputs x projection ("fast" = SFM_PROJECTION_FAST, the product's chain on the reference's
+geometry products; "reference_order" = SFM_PROJECTION_REFERENCE_ORDER, the reference's evaluation order per pixel as well) prints
   * the main kernel's time (HIP events on the dispatch, median of the timed steps; launch WITHOUT the warped output),
   * the warped pixels against the fp32 oracle's curr_proj_img (models/base_model.py:90-94): pixels above the FLAT 1e-4 of the
     range, the worst pixel, pixels zeroed differently (in-view flips) and how many of those the oracle itself places within
     8e-6 of the strict test, the share of pixels that are bit-identical to the oracle's,
-  * the five scalars' worst relative difference from the oracle's.
+  * the five scalars' worst relative difference from the oracle's,
+  * d_pose: worst element (of the array's maximum) against the fp32 oracle and against the fp64 oracle, next to the fp32 oracle's
+    own distance from the fp64 one.
+(Rounds 4-5 selected these with sfm_loss_variant(1 / 2); variant 1's geometry is the default of every kernel since round 6.)
 """
 import argparse
 import importlib
@@ -35,6 +38,7 @@ CASES = [
     ("cfg3 (2nd-order) B=4", 4, 128, 416, 2, dict(smooth_reg=0.1, ssim_rate=0.15), {}, None),
     ("cfg3_edge B=32", 32, 128, 416, 2, dict(smooth_reg=0.1, ssim_rate=0.15, smooth_mode="edge_aware"), {}, None),
     ("cfg5 (2 src) B=8 256x832", 8, 256, 832, 2, dict(smooth_reg=0.1, ssim_rate=0.15), {}, None),
+    ("cfg5 (4 src) B=8 256x832", 8, 256, 832, 4, dict(smooth_reg=0.1, ssim_rate=0.15), {}, None),
     ("behind the camera B=4", 4, 128, 416, 2, dict(smooth_reg=0.1, ssim_rate=0.15, smooth_mode="edge_aware"), {}, (-0.6, -0.3)),
     ("large motion B=4", 4, 128, 416, 2, dict(smooth_reg=0.1, ssim_rate=0.15, smooth_mode="edge_aware"), dict(rot_sigma=0.15, trans_sigma=0.25), None),
 ]
@@ -44,6 +48,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true", help="the B=4 cases only")
     ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--no-fp64", action="store_true", help="skip the fp64 oracle (d_pose yardstick)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     ev = bench.HipEvents()
@@ -65,27 +70,29 @@ def main():
                 for p in d["poses"]:
                     p[:, 5] = rng.uniform(tz[0], tz[1], size=p.shape[0]).astype(np.float32)
             t0 = time.time()
-            ref = O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], None, backward=False, keep_warped=True, **cfg)
+            ref = O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], None, backward=True, keep_warped=True, **cfg)
             t_or = time.time() - t0
-            binds = {}
-            for warped in (False, True):
-                binds[warped] = ops.FusedLoss(**cfg).bind([ops.to_hwc(t(a)) for a in d["tgt_pyr"]], [ops.to_hwc(t(a)) for a in d["src_pyr"]],
-                                                          t(d["intrinsics"]), [t(a) for a in d["disps"]], [t(a) for a in d["poses"]],
-                                                          layout="hwc", want_warped=warped)
-            say("== %s, %s inputs (%d warped px; oracle forward %.0f s)" % (name, "ROLLED (seam)" if seam == "roll" else "SEAM-FREE (shift)",
-                                                                          B * n_src * sum((H >> s) * (W >> s) for s in range(4)), t_or))
-            for variant in (0, 1, 2):
+            ref64 = None if args.no_fp64 else O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], None, backward=True,
+                                                         dtype=np.float64, **cfg)
+            say("== %s, %s inputs (%d warped px; fp32 oracle forward + backward %.0f s)" % (
+                name, "ROLLED (seam)" if seam == "roll" else "SEAM-FREE (shift)", B * n_src * sum((H >> s) * (W >> s) for s in range(4)), t_or))
+            for proj in ("fast", "reference_order"):
+                binds = {}
+                for warped in (False, True):
+                    binds[warped] = ops.FusedLoss(projection=proj, **cfg).bind(
+                        [ops.to_hwc(t(a)) for a in d["tgt_pyr"]], [ops.to_hwc(t(a)) for a in d["src_pyr"]], t(d["intrinsics"]),
+                        [t(a) for a in d["disps"]], [t(a) for a in d["poses"]], layout="hwc", want_warped=warped)
                 fl = binds[False]
                 for _ in range(8):
-                    fl.forward_backward(variant=variant)
+                    fl.forward_backward()
                 kt = []
                 for k in range(args.steps):
                     ops.lib.sfm_loss_profile_events(e0, e1)
-                    fl.forward_backward(variant=variant)
+                    fl.forward_backward()
                     torch.cuda.synchronize()
                     kt.append(ev.elapsed_ms(e0, e1) * 1e3)
                 fw = binds[True]
-                loss = fw.forward_backward(variant=variant).cpu().numpy()
+                loss = fw.forward_backward().cpu().numpy()
                 torch.cuda.synchronize()
                 n_px = n_over = n_flip = n_flip_near = n_same = 0
                 worst = 0.0
@@ -104,9 +111,17 @@ def main():
                     n_flip_near += int((mism & near).sum())
                     n_same += int((g == w).all(axis=2).sum())
                 lrel = max(abs(loss[k] - ref[nm]) / max(abs(ref[nm]), 1e-6) for k, nm in enumerate(KEYS))
-                say("   variant %d: main kernel %7.2f us (median of %d; min %.2f) | warped px above the flat 1e-4: %5d of %d, worst %.2e of the range | "
-                    "zeroed differently: %3d (%d within 8e-6 of the strict test) | bit-identical pixels %.2f %% | loss5 worst rel. diff %.1e" % (
-                        variant, float(np.median(kt)), len(kt), float(np.min(kt)), n_over, n_px, worst, n_flip, n_flip_near, 100.0 * n_same / n_px, lrel))
+                rel = lambda a, b: float(np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
+                p32 = max(rel(g.cpu().numpy(), w) for g, w in zip(fw.d_poses, ref["d_poses"]))
+                p64 = own = float("nan")
+                if ref64 is not None:
+                    p64 = max(rel(g.cpu().numpy(), w) for g, w in zip(fw.d_poses, ref64["d_poses"]))
+                    own = max(rel(a, b) for a, b in zip(ref["d_poses"], ref64["d_poses"]))
+                say("   %-15s: main kernel %7.2f us (median of %d; min %.2f) | warped px above the flat 1e-4: %5d of %d, worst %.2e of the range | "
+                    "zeroed differently: %3d (%d within 8e-6 of the strict test) | bit-identical pixels %.2f %% | loss5 worst rel. diff %.1e | "
+                    "d_pose worst element vs fp32 oracle %.2e, vs fp64 oracle %.2e (the fp32 oracle's own %.2e)" % (
+                        proj, float(np.median(kt)), len(kt), float(np.min(kt)), n_over, n_px, worst, n_flip, n_flip_near, 100.0 * n_same / n_px, lrel,
+                        p32, p64, own))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "ref_order.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
