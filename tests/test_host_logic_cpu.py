@@ -189,6 +189,23 @@ def test_augmentation_parameters_follow_the_reference_rng_order():
     np.testing.assert_allclose(Kms[:, 2, 0, 0], K2[:, 0, 0] / 4)
 
 
+def test_augmentation_host_side_matches_the_reference_run_golden():
+    """PINNED (round 6): augment.py's draws and intrinsics against tests/golden/intrinsics_aug.npz, produced by executing the
+    reference's own datasets/kitti/kitti_raw_transformed.py:17-93 (tests/golden/make_golden.py): scaled size, crop offsets, flip
+    decision, the intrinsics after augmentation and the multi-scale intrinsics, bit for bit."""
+    aug = importlib.import_module("sfm-learner-chainer_amd.augment")
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "intrinsics_aug.npz"))
+    for k in range(int(z["n_cases"])):
+        g = lambda name: z["c%d_%s" % (k, name)]
+        H, W = [int(v) for v in g("hw")]
+        p = aug.sample_params(np.random.RandomState(int(g("seed"))), 1, H, W)
+        assert (int(p[0, 2]), int(p[0, 3])) == tuple(int(v) for v in g("scaled_hw"))
+        assert (int(p[0, 4]), int(p[0, 5])) == tuple(int(v) for v in g("offset_yx")) and bool(p[0, 6]) == bool(g("flip"))
+        K = aug.augment_intrinsics(g("K_in")[None], p, W)
+        np.testing.assert_array_equal(K[0], g("K_out"))
+        np.testing.assert_array_equal(aug.get_multi_scale_intrinsics(K, g("K_multi").shape[0])[0], g("K_multi"))
+
+
 def test_rccl_binding_finds_the_library_torch_loaded():
     """rccl.py binds the librccl.so instance that torch has mapped (the one sharing torch's HIP runtime), declares the four entry
     points bench.py uses and can ask it for a unique id without a GPU; communicators and collectives need devices (GPU test:

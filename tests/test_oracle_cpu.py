@@ -29,7 +29,51 @@ def test_golden_fixture_set_is_complete():
     names = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLD, "*.npz")))
     assert names == ["euler_odom_util.npz", "interp_sampler_border.npz", "interp_sampler_c1.npz",
                      "interp_sampler_c5.npz", "interp_sampler_kitti_s3.npz", "interp_sampler_ragged.npz",
-                     "interp_sampler_small.npz"]
+                     "interp_sampler_small.npz", "intrinsics_aug.npz"]
+
+
+def _intrinsics_cases():
+    z = np.load(os.path.join(GOLD, "intrinsics_aug.npz"))
+    for k in range(int(z["n_cases"])):
+        yield k, {name[len("c%d_" % k):]: z[name] for name in z.files if name.startswith("c%d_" % k)}
+
+
+def _index_stack(n, c, h, w):
+    """what make_golden.py's stand-in for F.resize_images returns: the index of every element of the resized stack"""
+    f = np.arange(n, dtype=np.float64)[:, None, None, None]
+    y = np.arange(h, dtype=np.float64)[None, None, :, None]
+    x = np.arange(w, dtype=np.float64)[None, None, None, :]
+    return np.broadcast_to((f * 512 + y) * 2048 + x, (n, c, h, w)).astype(np.float32)
+
+
+def test_intrinsics_path_matches_the_reference_run_golden(monkeypatch):
+    """PINNED (round 6): the oracle's K path against tests/golden/intrinsics_aug.npz, produced by executing the reference's own
+    datasets/kitti/kitti_raw_transformed.py:17-93 on seeded np.random states (make_golden.py: make_intrinsics) -- the intrinsics
+    after scaling / cropping / flipping and the multi-scale intrinsics BIT-EXACT, and the crop + flip INDEXING on the same
+    index-valued stand-in for the resized stack."""
+    n = 0
+    for k, c in _intrinsics_cases():
+        H, W = [int(v) for v in c["hw"]]
+        S = int(c["n_src"])
+        # the draws, in the reference's order (:34, :50-51, :64)
+        rng = np.random.RandomState(int(c["seed"]))
+        sc = rng.uniform(1, 1.15, 2)
+        sh, sw = int(H * sc[1]), int(W * sc[0])
+        oy, ox = int(rng.randint(0, sh - H + 1)), int(rng.randint(0, sw - W + 1))
+        flip = bool(rng.rand() < 0.5)
+        assert (sh, sw) == tuple(int(v) for v in c["scaled_hw"]) and (oy, ox) == tuple(int(v) for v in c["offset_yx"]) and flip == bool(c["flip"])
+        monkeypatch.setattr(O, "resize_images", lambda imgs, hw, dtype=np.float32: _index_stack(imgs.shape[0], imgs.shape[1], hw[0], hw[1]))
+        t, s_, K = O.data_augmentation(np.zeros((3, H, W), np.float32), np.zeros((S, 3, H, W), np.float32), c["K_in"], sc[0], sc[1], oy, ox, flip)
+        np.testing.assert_array_equal(K, c["K_out"])
+        assert K.dtype == c["K_out"].dtype == np.float32
+        np.testing.assert_array_equal(O.get_multi_scale_intrinsics(K, c["K_multi"].shape[0]), c["K_multi"])
+        assert bool(c["tgt_channels_equal"])
+        np.testing.assert_array_equal(np.stack([t[0, 0], t[0, H // 2], t[0, H - 1]]).astype(np.int32), c["tgt_rows"])
+        np.testing.assert_array_equal(np.stack([t[0, :, 0], t[0, :, W // 2], t[0, :, W - 1]]).astype(np.int32), c["tgt_cols"])
+        np.testing.assert_array_equal(np.stack([[f[0, 0, 0], f[0, 0, W - 1], f[0, H - 1, 0], f[0, H - 1, W - 1]] for f in s_]).astype(np.int32),
+                                      c["src_corners"])
+        n += 1
+    assert n >= 8
 
 
 def test_interp_sampler_semantics_from_the_golden_border_case():
