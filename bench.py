@@ -364,6 +364,39 @@ def quick(torch, np, ev, runner, min_time=0.12, k=25):
             "step_roofline_frac": round((BYTES_FWD + BYTES_BWD) * runner.warped_px / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
+def interleaved(torch, np, runner, min_time=0.2, k=25):
+    """The headline step as a training loop presents it: another kernel runs between two steps.  Here the smallest such kernel, a
+    torch reduction over 64 unrelated floats (the launch that ends the slow level of a loop of nothing but this step,
+    profiles/r05_process_modes.txt), in front of EVERY step inside the timed blocks; `extra_kernel_ms` = what a block of those
+    reductions alone costs per launch (it is part of ms_per_step)."""
+    small = torch.arange(64, dtype=torch.float32, device=runner.dev)
+    sink = torch.zeros((), dtype=torch.float32, device=runner.dev)
+
+    def block(with_step):
+        t0 = time.perf_counter()
+        for _ in range(k):
+            torch.sum(small, out=sink)
+            if with_step:
+                runner.step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / k
+
+    for _ in range(3):
+        block(True)
+    torch.cuda.synchronize()
+    both, alone = [], []
+    t_all = time.perf_counter()
+    while time.perf_counter() - t_all < min_time or len(both) < 5:
+        both.append(block(True))
+    for _ in range(5):
+        alone.append(block(False))
+    ms, extra = float(np.median(both)) * 1e3, float(np.median(alone)) * 1e3
+    return {"workload": runner.desc, "ms_per_step": round(ms, 5), "extra_kernel_ms": round(extra, 5),
+            "value": round(runner.warped_px / (ms * 1e-3) / 1e6, 1),
+            "step_roofline_frac": round((BYTES_FWD + BYTES_BWD) * runner.warped_px / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "note": "a 64-float torch reduction launched before every step, inside the timed blocks (its own time is included)"}
+
+
 def link_path(torch, np, runner, min_time=0.12, k=25, use_graph=False):
     """The drop-in path a user of the reference calls: SFMLearnerLoss.__call__ from FULL-RESOLUTION frames (pyramid
     launch included) + loss.backward() (models/base_model.py:48-124), buffers cached across calls."""
@@ -570,6 +603,13 @@ def main():
         comm, comm_note = rccl.connect(rank, world, dev)
         if comm is None:
             sys.stderr.write("rank %d: no direct RCCL communicator (%s): the per-step collective goes through torch.distributed\n" % (rank, comm_note))
+    # how many ranks RCCL ITSELF counts (ncclCommCount; round-5 verdict item 5): on the line as config.rccl_ranks
+    rccl_ranks = None
+    if comm is not None:
+        rccl_ranks = comm.count()
+        if rccl_ranks != world or comm.user_rank() != rank:
+            sys.exit("rank %d: the RCCL communicator counts %d ranks and calls this one %d, the launcher said %d / %d" % (
+                rank, rccl_ranks, comm.user_rank(), world, rank))
     raw_stream = torch.cuda.current_stream(dev).cuda_stream
 
     def reduce_rows(t):
@@ -647,7 +687,24 @@ def main():
     input_warm = not args.no_input_warm
     global INPUT_WARM
     INPUT_WARM = input_warm
+    # Round 6 (round-5 verdict item 6 / advisor): the level BEFORE that read is measured and put on the line too -- about twenty blocks
+    # of the same K steps in the state the set-up left, `pre_warm_ms_per_step`: the figure that compares with the lines of rounds 1-4,
+    # which had no such read.  (No kernel events on these blocks.)
+    pre_warm = None
     if input_warm:
+        events.clear()
+        pw = []
+        t_pw = time.perf_counter()
+        while len(pw) < 20 and (time.perf_counter() - t_pw < 0.15 or len(pw) < 3):
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_steps(K, coll, False)
+            torch.cuda.synchronize()
+            pw.append((time.perf_counter() - t0) / K)
+        pre_warm = float(np.median(pw)) * 1e3
         warm_inputs(R)
         run_steps(min(args.warmup, 5), coll, False)
     blocks, k_main, k_second = [], [], []
@@ -714,6 +771,9 @@ def main():
         guarded("other_mode", lambda: quick(torch, np, ev, Runner(torch, np, ops, synth, dev, args.workload, args.layout,
                                                                     "separate" if args.mode == "fused" else "fused", args.batch)))
         guarded("graph_ms_per_step", lambda: graph_path(torch, np, R))
+        # the shape of a TRAINING loop (round-5 verdict item 6): the same step with an unrelated kernel -- a 64-float reduction, the
+        # launch that ends the slow level of profiles/r05_process_modes.txt -- in front of EVERY step, inside the timed blocks
+        guarded("cfg3_interleaved", lambda: interleaved(torch, np, R))
         guarded("link_ms_per_step", lambda: link_path(torch, np, R))
         for name in ("cfg3", "cfg3_edge", "cfg3_large_motion", "cfg3_smooth_disp", "cfg2", "cfg5", "cfg5_2src", "cfg5_2src_smooth_disp", "cfg1", "ref_b4"):
             if name != args.workload:
@@ -786,6 +846,7 @@ def main():
             "config": {"workload": R.desc, "per_gpu_batch": R.B, "global_batch": R.B * world, "H": R.H, "W": R.W, "n_src": R.n_src,
                        "n_scales": R.n_scales, "mode": args.mode, "image_layout": args.layout, "warped_px_per_gpu_step": R.warped_px,
                        "input_warm_read": input_warm,
+                       "rccl_ranks": rccl_ranks,
                        "collective": collective_line(coll, comm is not None, rehearse, comm_note) if use_dist else None,
                        "parallelism": ("batch-sharded x%d, no exchange on the data path; RCCL all-reduce of the 5 reported scalars: %s" % (
                            world, COLLECTIVE_NOTES[coll])) if use_dist else "single GPU, no collective"},
@@ -799,6 +860,9 @@ def main():
             "roofline_valu": roofline_valu,
             "roofline_valu_null_because": facts["stale"] if roofline_valu is None else None,
             "step_roofline_frac": round((BYTES_FWD + BYTES_BWD) * R.warped_px / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            # the same blocks BEFORE the one-off read of the inputs (config.input_warm_read): the protocol of rounds 1-4
+            "pre_warm_ms_per_step": round(pre_warm, 5) if pre_warm else None,
+            "pre_warm_step_roofline_frac": round((BYTES_FWD + BYTES_BWD) * R.warped_px / (pre_warm * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pre_warm else None,
             "csrc_sha16": csrc_sha16(),
             "loss5": [round(v, 6) for v in loss],
         }

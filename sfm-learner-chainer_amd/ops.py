@@ -213,17 +213,30 @@ def pyramid_pair_hwc(tgt, src, n_scales, out=None, per_pixel=False):
     n_src = src.shape[1] // 3
     if out is not None:
         yt, ys = out
-        if len(yt) != n_scales or tuple(yt[0].shape) != (N, 1, H, W, 3) or tuple(ys[0].shape) != (N, n_src, H, W, 3):
+        if len(yt) != n_scales or len(ys) != n_scales or tuple(yt[0].shape) != (N, 1, H, W, 3) or tuple(ys[0].shape) != (N, n_src, H, W, 3):
             raise TypeError("pyramid_pair_hwc: `out` does not match the inputs")
-        ptrs = getattr(out, "_ptrs", None)      # (the pointer arrays of buffers this function allocated: built once, a step is 15-60 us)
+        if yt[0].device != tgt.device or ys[0].device != tgt.device:
+            raise TypeError("pyramid_pair_hwc: `out` lives on %s, the inputs on %s" % (yt[0].device, tgt.device))
+        # (the pointer arrays of the buffers are built once -- a step is 15-60 us -- and are only reused while `out` still holds the
+        #  very arrays they were built from: round-5 advisor finding, a caller that swapped an element used to be written through a
+        #  stale pointer)
+        key = tuple(t.data_ptr() for t in yt) + tuple(t.data_ptr() for t in ys)
+        cached = getattr(out, "_ptrs", None)
+        ptrs = cached[1] if cached is not None and cached[0] == key else None
+        if ptrs is None:
+            for s in range(n_scales):
+                if tuple(yt[s].shape) != (N, 1, H >> s, W >> s, 3) or tuple(ys[s].shape) != (N, n_src, H >> s, W >> s, 3) or \
+                        not yt[s].is_contiguous() or not ys[s].is_contiguous() or yt[s].dtype != torch.float32 or ys[s].dtype != torch.float32 or \
+                        yt[s].device != tgt.device or ys[s].device != tgt.device:
+                    raise TypeError("pyramid_pair_hwc: `out` scale %d does not match the inputs" % s)
     else:
-        yt = [torch.empty((N, 1, H >> s, W >> s, 3), dtype=torch.float32, device=tgt.device) for s in range(n_scales)]
-        ys = [torch.empty((N, n_src, H >> s, W >> s, 3), dtype=torch.float32, device=tgt.device) for s in range(n_scales)]
+        yt = tuple(torch.empty((N, 1, H >> s, W >> s, 3), dtype=torch.float32, device=tgt.device) for s in range(n_scales))
+        ys = tuple(torch.empty((N, n_src, H >> s, W >> s, 3), dtype=torch.float32, device=tgt.device) for s in range(n_scales))
         out, ptrs = _PyramidPair((yt, ys)), None
     if ptrs is None:
         ptrs = (_ptr_array(yt), _ptr_array(ys))
         if isinstance(out, _PyramidPair):
-            out._ptrs = ptrs
+            out._ptrs = (tuple(t.data_ptr() for t in yt) + tuple(t.data_ptr() for t in ys), ptrs)
     idx = tgt.device.index
     if torch.cuda.current_device() == idx:
         if per_pixel:
@@ -238,8 +251,8 @@ def pyramid_pair_hwc(tgt, src, n_scales, out=None, per_pixel=False):
 
 
 class _PyramidPair(tuple):
-    """(tgt pyramid, src pyramid) as `pyramid_pair_hwc` returns it; carries the ctypes pointer arrays of its buffers so that a caller
-    that hands it back as `out` does not pay for rebuilding them every step."""
+    """(tgt pyramid, src pyramid) as `pyramid_pair_hwc` returns it -- two TUPLES of arrays; carries the ctypes pointer arrays of its
+    buffers, keyed on their addresses, so that a caller that hands it back as `out` does not pay for rebuilding them every step."""
 
 
 def to_hwc(x):

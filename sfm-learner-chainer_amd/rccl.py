@@ -77,6 +77,8 @@ def lib():
         L.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.ncclCommDestroy.argtypes = [C.c_void_p]
         L.ncclCommAbort.argtypes = [C.c_void_p]
+        L.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.ncclCommUserRank.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -110,6 +112,19 @@ class Communicator:
         p = C.c_void_p(tensor.data_ptr())
         _check(self._L.ncclAllReduce(p, p, tensor.numel(), NCCL_FLOAT32, NCCL_SUM, self._comm, C.c_void_p(st)), "ncclAllReduce")
         return tensor
+
+    def count(self):
+        """How many ranks RCCL ITSELF counts in this communicator (ncclCommCount): bench.py puts it on its JSON line as
+        config.rccl_ranks and asserts that it is the world size -- a first N > 1 run that says what it ran on."""
+        n = C.c_int(-1)
+        _check(self._L.ncclCommCount(self._comm, C.byref(n)), "ncclCommCount")
+        return int(n.value)
+
+    def user_rank(self):
+        """This process's rank as RCCL has it (ncclCommUserRank)."""
+        r = C.c_int(-1)
+        _check(self._L.ncclCommUserRank(self._comm, C.byref(r)), "ncclCommUserRank")
+        return int(r.value)
 
     def destroy(self, abort=False):
         """`abort`: ncclCommAbort instead of ncclCommDestroy (a communicator whose peers will never use it: nothing to wait for)."""
@@ -158,25 +173,48 @@ def connect(rank, world, device, init_timeout_s=None, library=None):
         return None, note or "another rank could not bind RCCL or make the unique id"
     if world == 1 and L is None:
         return None, note
+    bad_id = None
     if world > 1:                                                   # 3. the id
         raw = _broadcast_bytes(_id_bytes(uid) if rank == 0 else bytes(NCCL_UNIQUE_ID_BYTES), device)
-        C.memmove(C.byref(uid), raw[:NCCL_UNIQUE_ID_BYTES].ljust(NCCL_UNIQUE_ID_BYTES, b"\0"), NCCL_UNIQUE_ID_BYTES)
+        if len(raw) != NCCL_UNIQUE_ID_BYTES:                        # (round-5 advisor finding: a short id used to be zero-padded and used)
+            bad_id = "the broadcast unique id has %d bytes, not %d" % (len(raw), NCCL_UNIQUE_ID_BYTES)
+        else:
+            C.memmove(C.byref(uid), raw, NCCL_UNIQUE_ID_BYTES)
     comm = C.c_void_p()
     state = {}
+    lock = threading.Lock()
 
     def _init():
         try:
             if device is not None and getattr(device, "type", "cpu") == "cuda":
                 torch.cuda.set_device(device)                       # (the device of a thread is its own)
-            state["rc"] = L.ncclCommInitRank(C.byref(comm), world, uid, rank)
+            rc = L.ncclCommInitRank(C.byref(comm), world, uid, rank)
+            with lock:
+                state["rc"] = rc
+                # (round-5 advisor finding) the caller gave up on this call: the communicator it finally produced belongs to nobody --
+                # abort it here instead of leaking it
+                if state.get("abandoned") and rc == 0 and comm:
+                    try:
+                        L.ncclCommAbort(comm)
+                    except Exception:    # noqa: BLE001
+                        pass
         except Exception as e:   # noqa: BLE001
             state["exc"] = e
 
-    th = threading.Thread(target=_init, name="ncclCommInitRank", daemon=True)   # 4. under a deadline
-    th.start()
-    th.join(init_timeout_s)
-    if th.is_alive():
-        note = "ncclCommInitRank did not return within %.0f s" % init_timeout_s
+    th = None
+    if bad_id is None:                                              # 4. under a deadline (a rank with a bad id votes 0 without calling)
+        th = threading.Thread(target=_init, name="ncclCommInitRank", daemon=True)
+        th.start()
+        th.join(init_timeout_s)
+    if bad_id is not None:
+        note = bad_id
+    elif th.is_alive():
+        with lock:
+            if "rc" not in state and "exc" not in state:
+                state["abandoned"] = True
+        note = "ncclCommInitRank did not return within %.0f s" % init_timeout_s if state.get("abandoned") else None
+    if note is not None:
+        pass
     elif "exc" in state:
         note = "%s: %s" % (type(state["exc"]).__name__, state["exc"])
     elif state.get("rc", -1) != 0:

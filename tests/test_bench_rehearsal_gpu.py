@@ -61,6 +61,9 @@ def test_drivers_launcher_form_runs_on_real_rccl_at_one_rank(dev):
                  "--master-port", str(_free_port()), bench] + common)
     assert plain["config"]["collective"] is None and "ncclAllReduce" in dist["config"]["collective"]
     assert dist["n_gpus"] == 1 and dist["scaling"] == "weak"
+    # what RCCL itself counts (ncclCommCount on the direct communicator): the line of a first N > 1 run says what it ran on
+    assert dist["config"]["rccl_ranks"] == 1 and plain["config"]["rccl_ranks"] is None
+    assert plain["pre_warm_ms_per_step"] > 0 and plain["config"]["input_warm_read"] is True
     for key in ("interval_variant", "per_step_torch_variant"):          # the other placements ran too, on the same communicator
         assert dist[key]["ms_per_step"] > 0
     np = __import__("numpy")

@@ -35,6 +35,16 @@ def test_bench_starts_its_ranks_itself_and_rank0_alone_reports():
     assert lines[0]["n_gpus"] == 2 and lines[0]["steps"] == 3 and lines[0]["sum_of_ranks"] == 3.0   # 1 + 2: the collective ran over both ranks
 
 
+def test_bench_starts_eight_ranks():
+    """BASELINE cfg4's size (round-5 verdict item 5): `python bench.py --gpus 8` composes the launcher command for eight ranks, they
+    rendezvous on 127.0.0.1, the per-step collective sums over all eight (1 + 2 + ... + 8), rank 0 alone reports."""
+    r = run(8)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    assert lines[0]["n_gpus"] == 8 and lines[0]["sum_of_ranks"] == 36.0
+
+
 def test_bench_under_the_drivers_launcher():
     r = run(2, launcher=True)
     assert r.returncode == 0, r.stderr[-2000:]
