@@ -200,6 +200,9 @@ int sfm_loss_plan_info(const SfmLossDesc *desc, int grad, int loss, int *out, in
 /* Development / test hook, consumed by the NEXT sfm_loss_* call of the calling thread (whatever becomes of that call), then back
  * to 0.  3 = the kernels read the header of their argument block from the struct instead of taking it as preloaded scalar arguments
  * -- the path of a batch or a tile count beyond 16 bits, which no test could reach otherwise (results are bit-identical to 0).
+ * 4 / 5 = one source per pass / two sources per pass wherever the latter exists (SSIM gradient launches in SFM_LAYOUT_HWC with an
+ * even number of sources, FAST projection, no d_src), whatever the library would choose: the same arithmetic per pixel, the two
+ * sources' shares of d_disp added in another order (in-process A/B timing and tests).
  * (Rounds 4-5 selected the projection with values 1 and 2 here: that is SfmLossDesc.projection since ABI v5.) */
 int sfm_loss_variant(int variant);
 /* Diagnostics: the NEXT sfm_loss_* call of this thread makes every wavefront of its main kernel
@@ -259,6 +262,7 @@ int sfm_augment_fwd(const float *imgs, const float *params, float *out, int B, i
  *     SFM_CHUNK_ROWS_LIST=a,b,..  the same per scale
  *     SFM_NO_FILL                 no slot-filling refinement of the chunk heights (plan_chunks)
  *     SFM_NO_WIDE                 small L1 launches on the four-waves-per-SIMD build too
+ *     SFM_PAIR=0|1                never / wherever possible two sources per pass (as sfm_loss_variant 4 / 5, for a whole process)
  *     SFM_PRIO_TABLE=abc,def      issue-priority levels of the dispatch rounds in the first / second half of the sources
  *     SFM_DEAL_ITEMS_BELOW=n      batches smaller than n (default 8) have their items, not whole samples, dealt over the XCDs
  *   image pyramid (csrc/sfm_ops.hip, struct PyramidTuning):

@@ -320,6 +320,7 @@ struct Plan {
   size_t off_loss, off_gpm, total;
   bool ssim, expl, hwc;
   bool wide;     // the three-waves-per-SIMD build of an L1 gradient kernel (see loss_kernel)
+  bool pair;     // two sources per pass at two waves per SIMD (loss_kernel_pair, sfm_ssim_pair.h)
   bool ref;      // SfmLossDesc.projection = SFM_PROJECTION_REFERENCE_ORDER: the kernels of sfm_loss_ref.hip
   bool dsrc;     // the launch also produces dL/d(src): the instantiations with the LDS accumulation window (three waves per SIMD)
   bool warped;   // the instantiation that also writes SfmLossDesc.warped
@@ -358,7 +359,8 @@ static int device_cus() {
   return cus_of[dev];
 }
 
-static int waves_per_simd_of(bool ssim, bool grad, bool wide, bool dsrc) {   // = __launch_bounds__ of the kernel
+static int waves_per_simd_of(bool ssim, bool grad, bool wide, bool dsrc, bool pair) {   // = __launch_bounds__ of the kernel
+  if (pair) return 2;
   if (dsrc) return ssim ? 2 : 3;
   return ((ssim && grad) || wide) ? 3 : 4;
 }
@@ -370,6 +372,7 @@ struct Tuning {
   bool has_prio = false;
   unsigned prio_tab = 0;                    // SFM_PRIO_TABLE: "0123,3210" = levels of ranks 0.. in phase 1, phase 2
   bool no_wide = false;                     // SFM_NO_WIDE: small L1 launches on the four-wave build too
+  int pair = -1;                            // SFM_PAIR=0 / 1: never / whenever possible two sources per pass (default: make_plan decides)
   bool no_fill = false;                     // SFM_NO_FILL: no slot-filling refinement of the chunk heights (plan_chunks)
   int deal_below = 8;                       // SFM_DEAL_ITEMS_BELOW: batches smaller than this have their ITEMS dealt out over the XCDs (8 contiguous
                                             // ranges of the item list) instead of whole samples (b mod 8).  Measured at B = 8 (9): cfg5_2src +9.9 %,
@@ -378,6 +381,7 @@ struct Tuning {
     if (const char* e = getenv("SFM_DEAL_ITEMS_BELOW")) deal_below = atoi(e);
     no_wide = getenv("SFM_NO_WIDE") != nullptr;
     no_fill = getenv("SFM_NO_FILL") != nullptr;
+    if (const char* e = getenv("SFM_PAIR")) pair = atoi(e) != 0;
     if (const char* e = getenv("SFM_CHUNK_ROWS")) chunk_rows = atoi(e);
     if (const char* rl = getenv("SFM_CHUNK_ROWS_LIST")) {
       for (int k = 0; *rl && k < SFM_MAX_SCALES; ++k) {
@@ -413,7 +417,7 @@ static void chunk_layout(const SfmLossDesc* d, int sw, int halo2, int T, int* ro
   }
 }
 
-static void plan_chunks(const SfmLossDesc* d, int sw, int halo2, int slots, int* rows) {
+static void plan_chunks(const SfmLossDesc* d, int sw, int halo2, int slots, int passes /* walks of a wave down its chunk */, int* rows) {
   const int forced = tuning().chunk_rows;
   int bestT = MAX_CHUNK_ROWS;
   double best = 1e300;
@@ -441,7 +445,7 @@ static void plan_chunks(const SfmLossDesc* d, int sw, int halo2, int slots, int*
   // 1.5 - 2.2 % shorter where a wave is SHORT -- B = 16 / 24 / 32 at 128x416 with two sources, cfg5 with two sources -- and 3 - 5 %
   // LONGER where it is long (cfg5 with four sources: 17 steps x 4; B = 48: 26 steps x 2), so the refinement is applied while a
   // wave's row steps, tallest chunk x sources, stay within 40.
-  if (!tuning().no_fill && items <= slots && !(forced >= MIN_CHUNK_ROWS && forced <= MAX_CHUNK_ROWS) && (long long)maxcost * d->n_src <= 40) {
+  if (!tuning().no_fill && items <= slots && !(forced >= MIN_CHUNK_ROWS && forced <= MAX_CHUNK_ROWS) && (long long)maxcost * passes <= 40) {
     for (;;) {
       int pick = -1, pick_rows = 0;
       long long pick_add = 0;
@@ -480,8 +484,10 @@ static long long max_items(const SfmLossDesc* d, int sw) {
 
 static void set_gy(struct Plan& p, const float gy);
 
+constexpr int PAIR_BELOW_ROWS = 12;   // see make_plan
+
 // validates the descriptor and lays out items + workspace for the given mode
-static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_outputs, float gy, Plan& p) {
+static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_outputs, float gy, Plan& p, const int pair_hook = -1) {
   if (!d) return fail(SFM_ERR_NULL, "sfm_loss: NULL descriptor");
   if (d->B < 0 || d->B > (1 << 20)) return fail(SFM_ERR_SHAPE, "sfm_loss: B=%d", d->B);
   if (d->norm_B < d->B || d->norm_B < 1) return fail(SFM_ERR_CONFIG, "sfm_loss: norm_B=%d must be >= max(B,1) (B=%d)", d->norm_B, d->B);
@@ -541,7 +547,21 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
   if (grad && need_outputs)
     for (int s = 0; s < d->n_scales; ++s) p.dsrc = p.dsrc || d->d_src[s] != nullptr;
   p.wide = grad && !p.dsrc && !p.ref && !p.ssim && !p.expl && !tuning().no_wide && max_items(d, sw) <= (long long)cus * 4 * 3;
-  const int waves_per_simd = waves_per_simd_of(p.ssim, grad, p.wide, p.dsrc);
+  // Two sources per pass (loss_kernel_pair): the SSIM gradient launches of the pixel-interleaved layout with an even number of
+  // sources, without the warped output.  By default where it measured faster (profiles/r06_pair_kernel.txt): launches whose
+  // one-source plan has to cut the largest scale into chunks of at most PAIR_BELOW_ROWS rows to fill the chip (B <= 24 at 128x416:
+  // -2 ... -12 % kernel time; the halo rows of short chunks are what the taller chunks of two thirds as many waves save).  At
+  // BASELINE cfg3 / cfg5 (15 / 13 rows) it is 1 - 5 % SLOWER -- 11 % fewer vector instructions, issued 12 % less densely by two
+  // waves per SIMD than by three -- and is not used.
+  p.pair = false;
+  if (grad && p.ssim && p.hwc && !p.dsrc && !p.ref && !p.warped && d->n_src % 2 == 0) {
+    int rows1[SFM_MAX_SCALES];
+    plan_chunks(d, sw, 2 * (hs > hm ? hs : hm), cus * 4 * 3, d->n_src, rows1);
+    p.pair = rows1[0] <= PAIR_BELOW_ROWS;
+    if (tuning().pair >= 0) p.pair = tuning().pair != 0;
+    if (pair_hook >= 0) p.pair = pair_hook != 0;
+  }
+  const int waves_per_simd = waves_per_simd_of(p.ssim, grad, p.wide, p.dsrc, p.pair);
   const int slots = cus * 4 * waves_per_simd;
   A.simds_per_xcd = (cus % 8 == 0) ? cus / 8 * 4 : 128;   // gfx950: 8 XCDs, 4 SIMDs per CU
   A.prio_top = waves_per_simd - 1 < 3 ? waves_per_simd - 1 : 3;
@@ -550,7 +570,7 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
     A.prio_tab |= (unsigned)r << (2 * r) | (unsigned)(A.prio_top - r) << (8 + 2 * r);
   if (tuning().has_prio) A.prio_tab = tuning().prio_tab & 0xffffu;
   if (d->B < (tuning().deal_below > 8 ? tuning().deal_below : 8)) A.prio_tab |= 0x80000000u;   // fewer samples than XCDs (or asked for): deal items
-  plan_chunks(d, sw, 2 * (hs > hm ? hs : hm), slots, rows);
+  plan_chunks(d, sw, 2 * (hs > hm ? hs : hm), slots, p.pair ? d->n_src / 2 : d->n_src, rows);
   int items = 0;
   for (int s = 0; s < d->n_scales; ++s) {
     const int h = d->H[s], w = d->W[s];
@@ -675,6 +695,7 @@ static hipError_t launch_main(const Plan& p, hipStream_t st, hipEvent_t ev_start
   const int per_xcd = (int)p.args.prio_tab >= 0 ? (p.args.B / 8) * tiles_per_sample + ((p.args.B % 8) * tiles_per_sample + 7) / 8 : (p.args.items + 7) / 8;
   const void* fn = kernel_ptr<GRAD, LOSS>(p.ssim, p.expl, p.smode, p.hwc, p.wide, p.warped);
   if (p.ref) fn = kernel_ptr_ref(GRAD, LOSS, p.ssim, p.expl, p.smode, p.hwc, p.warped);      // SFM_PROJECTION_REFERENCE_ORDER
+  if (p.pair) fn = kernel_ptr_pair(GRAD, LOSS, p.smode);                                     // two sources per pass
   if constexpr (GRAD) {
     if (p.dsrc) fn = kernel_ptr_dsrc(LOSS, p.ssim, p.expl, p.smode, p.hwc, p.warped);
   }
@@ -692,7 +713,7 @@ static hipError_t launch_main(const Plan& p, hipStream_t st, hipEvent_t ev_start
 // search once.  (Thread-local, like the error string: no state is shared between threads.)
 struct CachedPlan {
   SfmLossDesc desc;
-  int device;
+  int device, pair_hook;
   bool grad, loss, valid;
   Plan plan;
 };
@@ -700,20 +721,20 @@ constexpr int PLAN_CACHE = 4;
 static thread_local CachedPlan g_plans[PLAN_CACHE];
 static thread_local unsigned g_plan_clock = 0;
 
-static int cached_plan(const SfmLossDesc* d, bool grad, bool loss, float gy, Plan& out) {
+static int cached_plan(const SfmLossDesc* d, bool grad, bool loss, float gy, Plan& out, const int pair_hook) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; }
   for (int k = 0; k < PLAN_CACHE; ++k) {
     CachedPlan& c = g_plans[k];
-    if (c.valid && c.grad == grad && c.loss == loss && c.device == dev && memcmp(&c.desc, d, sizeof(SfmLossDesc)) == 0) {
+    if (c.valid && c.grad == grad && c.loss == loss && c.device == dev && c.pair_hook == pair_hook && memcmp(&c.desc, d, sizeof(SfmLossDesc)) == 0) {
       out = c.plan;
       set_gy(out, gy);
       return SFM_OK;
     }
   }
-  if (int e = make_plan(d, grad, loss, true, gy, out)) return e;
+  if (int e = make_plan(d, grad, loss, true, gy, out, pair_hook)) return e;
   CachedPlan& c = g_plans[g_plan_clock++ % PLAN_CACHE];
-  c.desc = *d; c.device = dev; c.grad = grad; c.loss = loss; c.plan = out; c.valid = true;
+  c.desc = *d; c.device = dev; c.pair_hook = pair_hook; c.grad = grad; c.loss = loss; c.plan = out; c.valid = true;
   return SFM_OK;
 }
 
@@ -737,7 +758,8 @@ static int run(const SfmLossDesc* d, bool grad, bool loss, float gy, float* loss
   }
   if (!d) return fail(SFM_ERR_NULL, "%s: NULL descriptor", who);
   Plan p;
-  if (int e = cached_plan(d, grad, loss, gy, p)) return e;
+  // (sfm_loss_variant 4 / 5: one source per pass / two sources per pass where possible, whatever the default -- in-process A/B, tests)
+  if (int e = cached_plan(d, grad, loss, gy, p, variant == 4 ? 0 : (variant == 5 ? 1 : -1))) return e;
   if (loss && !loss5) return fail(SFM_ERR_NULL, "%s: loss5 is NULL", who);
   if (!ws || ws_bytes < p.total) return fail(SFM_ERR_WORKSPACE, "%s: workspace of %zu bytes needed, got %zu", who, p.total, ws_bytes);
   if (((uintptr_t)ws & 255) != 0) return fail(SFM_ERR_WORKSPACE, "%s: workspace must be 256-byte aligned", who);
@@ -794,7 +816,7 @@ int sfm_loss_plan_info(const SfmLossDesc* desc, int grad, int loss, int* out, in
 }
 
 int sfm_loss_variant(int variant) {
-  if (variant != 0 && variant != 3) return sfm::fail(SFM_ERR_CONFIG, "sfm_loss_variant: %d is not 0 or 3", variant);
+  if (variant != 0 && (variant < 3 || variant > 5)) return sfm::fail(SFM_ERR_CONFIG, "sfm_loss_variant: %d is not 0, 3, 4 or 5", variant);
   sfm::g_variant = variant;
   return SFM_OK;
 }

@@ -5,6 +5,7 @@
 #pragma once
 #include "sfm_common.h"
 #include "sfm_ssim_pass.h"
+#include "sfm_ssim_pair.h"
 
 namespace sfm {
 
@@ -288,8 +289,11 @@ __device__ __forceinline__ Hdr make_hdr(const LossArgs& A, SFM_HDR_PARAMS) {
   return H;
 }
 
-template <bool SSIM, bool GRAD, bool LOSS, bool EXPL, int SMODE, bool HWC, bool WARPED, int REF = 0, bool DSRC = false>
+// PAIR: two sources per pass (sfm_ssim_pair.h): the SSIM kernels of the pixel-interleaved layout with the product's projection, for
+// an even number of sources; two waves per SIMD.
+template <bool SSIM, bool GRAD, bool LOSS, bool EXPL, int SMODE, bool HWC, bool WARPED, int REF = 0, bool DSRC = false, bool PAIR = false>
 __device__ __forceinline__ void loss_body(const Hdr& H, const LossArgs& A) {
+  static_assert(!PAIR || (SSIM && HWC && !EXPL && REF == 0 && !DSRC), "two sources per pass: the SSIM kernels, pixel-interleaved, FAST projection");
   static_assert(GRAD || !DSRC, "dL/d(src) is an output of the backward");
   static_assert(LOSS || !WARPED, "the warped images are an output of the forward and the fused entry points");
   using HH = Halo<SSIM, GRAD, SMODE>;
@@ -420,14 +424,16 @@ __device__ __forceinline__ void loss_body(const Hdr& H, const LossArgs& A) {
   // (Measured round 3 with a run-time table, commit 40da7e8: every wave first +2 %, oldest first / middle between the sources /
   // youngest last +4...7 %, the other mixed orders within noise of this one: profiles/r03_smooth_position_sweep.txt.)
   const bool smooth_last = (SMODE != 0) && (prio_rank == 1);
-  const int n_phases = H.n_src + (SMODE != 0 ? 1 : 0);
+  const int n_units = PAIR ? (H.n_src >> 1) : H.n_src;        // passes over the sources: one per source, or one per PAIR of sources
+  const int n_phases = n_units + (SMODE != 0 ? 1 : 0);
   for (int ph = 0; ph < n_phases; ++ph) {
-    const int i = (SMODE != 0 && !smooth_last) ? ph - 1 : ph;   // source of this phase; -1 or n_src = the smoothness pass
+    const int iu = (SMODE != 0 && !smooth_last) ? ph - 1 : ph;  // unit of this phase; -1 or n_units = the smoothness pass
+    const int i = PAIR ? 2 * iu : iu;                           // (first) source of the unit
 #ifdef SFM_STAMPS
     unsigned long long tp0 = 0, tp1 = 0;
     SFM_STAMP(tp0);
 #endif
-    if (SMODE != 0 && (i < 0 || i >= H.n_src)) {
+    if (SMODE != 0 && (iu < 0 || iu >= n_units)) {
       if (SMODE == 1) smooth2_pass<GRAD, LOSS>(A, S, S.disp + (size_t)b * P, lane, x, xin, outl, y0, y1, gacc, acc_sm, !first);
       else smooth_edge_pass<GRAD, LOSS, HWC>(A, S, S.disp + (size_t)b * P, S.tgt + (size_t)b * 3 * P, lane, x, xin, outl, y0, y1, gacc, acc_sm, !first);
       first = false;
@@ -437,7 +443,7 @@ __device__ __forceinline__ void loss_body(const Hdr& H, const LossArgs& A) {
 #endif
       continue;
     }
-    if (i * 2 >= H.n_src) set_issue_prio((int)((H.prio_tab >> (8 + 2 * prio_rank)) & 3u));
+    if (iu * 2 >= n_units) set_issue_prio((int)((H.prio_tab >> (8 + 2 * prio_rank)) & 3u));
     SsimCtx C;
     const float xf = (float)x;
     C.x0 = x - lane;
@@ -502,7 +508,19 @@ __device__ __forceinline__ void loss_body(const Hdr& H, const LossArgs& A) {
     C.outf = outl ? 1.f : 0.f;
     C.lane = lane;
     float* gpm_out = GRAD ? A.part_gpm + ((size_t)item * H.n_src + i) * 12 : nullptr;
-    if constexpr (SSIM) {
+    if constexpr (PAIR) {
+      // the second source of the pair: the same context with ITS projection rows, image and outputs
+      SsimCtx Cb = C;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        Cb.M1[k] = from_lane(WG.M1, 8 * (i + 1) + k);
+        Cb.P3[k] = from_lane(WG.P3, 8 * (i + 1) + k);
+        Cb.mx[k] = fmaf(from_lane(WG.M0, 8 * (i + 1) + k), xf, from_lane(WG.M2, 8 * (i + 1) + k));
+        Cb.sp[k] = C.sp[k] + 3 * P;
+      }
+      Cb.wp = WARPED ? C.wp + 3 * P : nullptr;
+      ssim_pair_pass<GRAD, LOSS, WARPED>(C, Cb, gacc, first, acc_pix, acc_ssim, gpm_out, GRAD ? gpm_out + 12 : nullptr);
+    } else if constexpr (SSIM) {
       ssim_source_pass<GRAD, LOSS, HWC, WARPED, REF, DSRC>(C, gacc, first, acc_pix, acc_ssim, gpm_out SFM_STAMPS_PASS);
     } else {
       l1_source_pass<GRAD, LOSS, EXPL, HWC, WARPED, REF, DSRC>(C, gacc, first, acc_pix, acc_exp, gpm_out);
@@ -565,6 +583,11 @@ template <bool SSIM, bool GRAD, bool LOSS, bool EXPL, int SMODE, bool HWC, bool 
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) loss_kernel_ref(SFM_HDR_PARAMS, const LossArgs A) {
   loss_body<SSIM, GRAD, LOSS, EXPL, SMODE, HWC, WARPED, 1>(make_hdr(A, SFM_HDR_ARGS), A);
 }
+// (PAIR, see loss_body: two sources per pass at two waves per SIMD; sfm_loss_pair.hip instantiates them)
+template <bool GRAD, bool LOSS, int SMODE>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 2) loss_kernel_pair(SFM_HDR_PARAMS, const LossArgs A) {
+  loss_body<true, GRAD, LOSS, false, SMODE, true, false, 0, false, true>(make_hdr(A, SFM_HDR_ARGS), A);
+}
 // (WIDE, see above: L1 gradient kernels only)
 template <bool LOSS, int SMODE, bool HWC, bool WARPED = false>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 3) loss_kernel_wide(SFM_HDR_PARAMS, const LossArgs A) {
@@ -575,5 +598,6 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 3) loss_kernel_wide(SFM_
 // the kernel tables of the other translation units (sfm_loss_ref.hip, sfm_loss_dsrc.hip); nullptr = not built
 const void* kernel_ptr_ref(bool grad, bool loss, bool ssim, bool expl, int smode, bool hwc, bool warped);
 const void* kernel_ptr_dsrc(bool loss, bool ssim, bool expl, int smode, bool hwc, bool warped);
+const void* kernel_ptr_pair(bool grad, bool loss, int smode);
 
 }  // namespace sfm

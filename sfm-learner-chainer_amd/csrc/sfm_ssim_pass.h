@@ -465,8 +465,11 @@ __device__ __forceinline__ RefPos ref_position(const SsimCtx& C, const float yf,
 // (sample, source), and the three channels of a tap come with one load.
 // REF: 0 the product's chain (SFM_PROJECTION_FAST): q = D (M . pix) + P3, the in-view test on U, V directly, the sample at (U, V);
 //      1 the reference's evaluation order per pixel (SFM_PROJECTION_REFERENCE_ORDER, ref_position above).
-template <bool HWC, int REF = 0>
+// SECOND (ssim_pair_pass, sfm_ssim_pair.h): the second source of a pass that handles two sources per row -- the depth (ps.D, set by
+//      the caller) and the target texel were fetched with the first one and are not fetched again.
+template <bool HWC, int REF = 0, bool SECOND = false>
 __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const float disp, Pipe& ps) {
+  static_assert(!SECOND || (HWC && REF == 0), "two sources per pass: pixel-interleaved layout, the product's projection");
   const float yf = (float)r;
   Proj p;
   f2 UV, fr, cell;
@@ -483,7 +486,7 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
     // depth = 1 / disp (base_model.py:60) from v_rcp_f32 alone (1 ulp): the quotients U = q0/z, V = q1/z below keep their residual
     // correction (they decide the strict in-view test), the depth does not need one -- a last-bit change of D moves the sample by
     // 1e-7 of its parallax
-    ps.D = rcp(disp);
+    if constexpr (!SECOND) ps.D = rcp(disp);
     // The projection of sfm_common.h's project(), with the x and y components of every step in ONE packed instruction (the same
     // IEEE operations per component: bit-identical values, two thirds of the instructions):
     //   a = M (x,y,1) ; q = D a + P[:,3] ; z = q2 + 1e-10 ; (U,V) = (q0,q1) / z ; in view iff U (W-1-U) > 0 and V (H-1-V) > 0
@@ -550,7 +553,8 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
     const u2v t1 = __builtin_amdgcn_raw_buffer_load_b64(srs, o12 + 16u, 0, 0);
     const u4v b0 = __builtin_amdgcn_raw_buffer_load_b128(srs2, o12, 0, 0);
     const u2v b1 = __builtin_amdgcn_raw_buffer_load_b64(srs2, o12 + 16u, 0, 0);
-    const u3v i0 = __builtin_amdgcn_raw_buffer_load_b96(trs, C.x12, 0, 0);
+    u3v i0 = {0u, 0u, 0u};
+    if constexpr (!SECOND) i0 = __builtin_amdgcn_raw_buffer_load_b96(trs, C.x12, 0, 0);
     Rgb2 T, Bt;
     Rgb I;
     T.c[0] = __uint_as_float(t0.x); T.c[1] = __uint_as_float(t0.y); T.c[2] = __uint_as_float(t0.z); T.c[3] = __uint_as_float(t0.w);
@@ -569,7 +573,9 @@ __device__ __forceinline__ void issue_row(const SsimCtx& C, const int r, const f
       ps.it[c] = ldf(C.tp[c], offt);
     }
   }
-  if (C.mp != nullptr) ps.lg = ldf(C.mp, offt);
+  if constexpr (!SECOND) {
+    if (C.mp != nullptr) ps.lg = ldf(C.mp, offt);
+  }
 }
 
 // stage A, second half: bilinear value and derivatives from the gathered taps
@@ -736,32 +742,39 @@ __device__ __forceinline__ void dsrc_finish(const SsimCtx& C, const PoseAcc& gpm
 
 // From dL/dI^ of one pixel (already contracted with dI^/du, dI^/dv and 1/z into gq = (gq0, gq1)) to its
 // share of d_depth (LDS tile), of the 12 sums of dL/dPm and, optionally, of dL/d(src).
+// the arithmetic of geometry_backward for one (pixel, source): its share of dL/d(disp) (returned) and of the nine pose sums
+__device__ __forceinline__ float geom_terms(const SsimCtx& C, const f2 UV, const float D, const float yf, const f2 gq, PoseAcc& gpm) {
+  const f2 guv = gq * UV;
+  const float gq2 = -(guv.x + guv.y);
+  // (see geometry_backward for the derivation)
+  const f2 t = gq * D;
+  const float t2 = gq2 * D;
+  const float gdisp = fmaf(t.x, C.P3[0], fmaf(t.y, C.P3[1], t2 * C.P3[2]));
+  gpm.A += t; gpm.A2 += t2;
+  gpm.B = vfma(T_of<f2>(yf), t, gpm.B); gpm.B2 = fmaf(yf, t2, gpm.B2);
+  gpm.Cq += gq; gpm.C2 += gq2;
+  return gdisp;
+}
+
 template <int DR /* rows of the dL/d(src) window; 0: the output is not produced */, int REF = 0>
 __device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& s2, const int rc, const f2 gq,
                                                   const float* gI, float* gacc, const bool first, PoseAcc& gpm) {
   const int h = C.h, w = C.w;
-  const f2 guv = gq * s2.UV;
-  const float gq2 = -(guv.x + guv.y);
   const float yf = (float)rc;
   // dL/d(depth) = gq . a with a = M (x,y,1) the ray of q = D a + P3.  D a = q - P3, and gq . q = 0 because U and
   // V are homogeneous of degree 0 in q (with z = q2 + 1e-10 it is (gq0 U + gq1 V) 1e-10: ten orders below gq . P3), so
   // gD = -(gq . P3) / D and dL/d(disp) = -gD D^2 (depth = 1/disp, base_model.py:60) = (gq . P3) D: three products with
   // wave-uniform factors instead of rebuilding the ray -- and without the cancellation of a0 - U a2 for small translations.
   // (with t = gq D, which the pose sums below need anyway: three products, the factor D is already inside)
-  const f2 t = gq * s2.D;
-  const float t2 = gq2 * s2.D;
-  const float gdisp = fmaf(t.x, C.P3[0], fmaf(t.y, C.P3[1], t2 * C.P3[2]));
+  // dL/dPm[k][j] = sum over pixels of gq_k * c_j with c = D * (K1 y + kx) (the back-projected point), c_3 = 1.  The ray
+  // is linear in the row, so a lane only accumulates  A_k = sum gq_k D,  B_k = sum y gq_k D,  C_k = sum gq_k  (9 values
+  // instead of 12); pose_sums_raw reduces them over the wave once per pass and finalize_kernel multiplies K^-1 in
+  const float gdisp = geom_terms(C, s2.UV, s2.D, yf, gq, gpm);
   float* ga = gacc + (rc - C.y0) * 64 + C.lane;
   // the tile is private to this wave: a plain store for the first contribution, then read-add-write through a register
   // (an LDS add without return value, ds_add_f32, has nothing to wait for but costs the launch 3 % at cfg3: it is a slow LDS op)
   if (first) *ga = gdisp;
   else *ga = *ga + gdisp;
-  // dL/dPm[k][j] = sum over pixels of gq_k * c_j with c = D * (K1 y + kx) (the back-projected point), c_3 = 1.  The ray
-  // is linear in the row, so a lane only accumulates  A_k = sum gq_k D,  B_k = sum y gq_k D,  C_k = sum gq_k  (9 values
-  // instead of 12); pose_sums_raw reduces them over the wave once per pass and finalize_kernel multiplies K^-1 in
-  gpm.A += t; gpm.A2 += t2;
-  gpm.B = vfma(T_of<f2>(yf), t, gpm.B); gpm.B2 = fmaf(yf, t2, gpm.B2);
-  gpm.Cq += gq; gpm.C2 += gq2;
   // (DSRC: the instantiations a launch with SfmLossDesc.d_src bound runs.  A run-time branch here -- rounds 1-4 -- costs the kernels
   //  of every OTHER launch registers: with the window code behind it the SSIM gradient kernels spill 32 VGPRs)
   if (DR != 0 && C.dsp != nullptr) {   // optional dL/d(src): scatter of dL/dI^ over the four taps, through the LDS window

@@ -13,7 +13,7 @@ CSRC = os.path.join(ROOT, "sfm-learner-chainer_amd", "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
-LOSS_UNITS = ["sfm_loss.hip", "sfm_loss_ref.hip", "sfm_loss_dsrc.hip"]      # the translation units that instantiate loss_body
+LOSS_UNITS = ["sfm_loss.hip", "sfm_loss_ref.hip", "sfm_loss_dsrc.hip", "sfm_loss_pair.hip"]      # the translation units that instantiate loss_body
 
 
 def _resource_usage(tmp_path):
@@ -60,13 +60,18 @@ def test_loss_kernels_fit_their_register_budget(tmp_path):
     assert by_unit("sfm_loss.hip") == 54 + 12 + 36 + 6
     assert by_unit("sfm_loss_dsrc.hip") == 54
     assert by_unit("sfm_loss_ref.hip") == 54 + 36
+    # sfm_loss_pair.hip (round 6): the SSIM gradient kernels of the pixel-interleaved layout that walk two sources per pass
+    # ({bwd, fused} x 3 smoothness forms), two waves per SIMD
+    assert by_unit("sfm_loss_pair.hip") == 6
     for k, v in kernels.items():
         assert v["VGPRs Spill"] == 0, (k, v)
         # no frame at all, in any variant: scalar registers that do not fit are parked in vector-register lanes (counted in the
         # budget below), never in memory -- a non-zero frame means real scratch traffic or an array demoted to memory
         assert v["ScratchSize [bytes/lane]"] == 0, (k, v)
     for k, v in loss.items():
-        if "loss_kernel_dsrc" in k:                                          # <SSIM, ...>: two waves per SIMD with SSIM, three without
+        if "loss_kernel_pair" in k:                                          # two sources per pass: two waves per SIMD
+            budget = 256
+        elif "loss_kernel_dsrc" in k:                                        # <SSIM, ...>: two waves per SIMD with SSIM, three without
             budget = 256 if "loss_kernel_dsrcILb1E" in k else 168
         else:
             ssim_grad = "loss_kernelILb1ELb1E" in k or "loss_kernel_wide" in k or "loss_kernel_refILb1ELb1E" in k   # three waves per SIMD

@@ -820,6 +820,42 @@ def test_reference_order_projection_every_mode_entry_point_and_layout(ops, synth
         np.testing.assert_allclose(b, a, rtol=0, atol=2e-5 * max(np.abs(a).max(), 1e-30))
 
 
+@pytest.mark.parametrize("cfg_name", ["ssim_smooth", "ssim_only", "edge_aware"])
+@pytest.mark.parametrize("shape", [(2, 32, 48, 2, 3), (3, 20, 130, 4, 2), (4, 128, 416, 2, 4), (1, 37, 70, 6, 1)])
+def test_two_sources_per_pass_gives_the_one_source_results(ops, synth, dev, cfg_name, shape):
+    """loss_kernel_pair (sfm_ssim_pair.h, round 6): SSIM gradient launches of an even number of sources can walk TWO sources per pass
+    at two waves per SIMD (the library picks that form where it is faster: small batches; profiles/r06_pair_kernel.txt).  Per pixel
+    it is the one-source kernels' arithmetic; what differs is the chunking (fewer, taller chunks: another summation order of the
+    per-wave partials) and the order in which the sources' shares of d_disp are added.  sfm_loss_variant(5) / (4) select either form
+    for one call: same loss to 2e-7, same gradients to 2e-5 of their maximum -- and the pair form against the oracle by the usual
+    criteria."""
+    B, H, W, n_src, n_scales = shape
+    cfg = CONFIGS[cfg_name]
+    d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=n_scales, seed=23)
+    ref = _oracle(d, cfg)
+    fl = _bind(ops, dev, d, cfg, layout="hwc")
+    outs = {}
+    for variant in (4, 5):
+        loss = to_np(fl.forward_backward(variant=variant)).copy()
+        outs[variant] = (loss, [to_np(t).copy() for t in fl.d_disps + fl.d_poses])
+        ops.check(ops.lib.sfm_loss_variant(variant))
+        fl.backward(1.0)                                        # sfm_loss_bwd has the pair form too
+        for a, b in zip(outs[variant][1], [to_np(t) for t in fl.d_disps + fl.d_poses]):
+            np.testing.assert_allclose(b, a, rtol=0, atol=2e-5 * max(np.abs(a).max(), 1e-30))
+    np.testing.assert_allclose(outs[5][0], outs[4][0], rtol=2e-7, atol=0)
+    for a, b in zip(outs[4][1], outs[5][1]):
+        np.testing.assert_allclose(b, a, rtol=0, atol=2e-5 * max(np.abs(a).max(), 1e-30))
+    what = "TWO SOURCES PER PASS %s B=%d %dx%d %d src" % (cfg_name, B, H, W, n_src)
+    _check_losses(fl.forward_backward(variant=5), ref)
+    _check_grads(fl, ref, n_src, what=what, **knife_widths(d, ref))
+    # the form is really another kernel with another plan: fewer work items (host-side query; variant hooks do not reach it, the
+    # environment does -- so only the default is asserted: small launches take the pair form)
+    import ctypes as C
+    out = (C.c_int * (1 + 4 * n_scales))()
+    ops.check(ops.lib.sfm_loss_plan_info(C.byref(fl.desc), 1, 1, out, len(out)))
+    assert out[0] > 0
+
+
 def test_reference_order_projection_is_refused_together_with_d_src(ops, synth, dev):
     d = synth.make_inputs(B=1, H=24, W=40, n_src=2, n_scales=2, seed=3, with_masks=True)
     with pytest.raises(ValueError, match="d_src"):
@@ -887,12 +923,22 @@ def test_large_motion_vs_oracle(ops, synth, dev, motion, cfg_name, B, H, W, n_sr
         assert oov > (0.15 if motion == "medium" else 0.5)
     ref64 = lambda: O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], d["masks"], backward=True,
                                keep_warped=True, dtype=np.float64, **cfg)
-    explain = lambda i, got: pose_explained_by_discontinuities(d, cfg, ref, i, got)
+    # (behind the camera the samples near z = 0 carry percents of a sample's d_pose each, and which cell / side of the in-view test
+    #  such a sample lands in is decided by the last bit of its position: up to THREE named pixels per sample there, two elsewhere.
+    #  Round 6: with the in-wave geometry on the reference's roundings the FAST projection takes another branch than the fp32 oracle
+    #  at two pixels of sample 1 -- tools/diag_motion_pose.py: the REFERENCE_ORDER projection follows the oracle to 1e-6 on the same
+    #  input, which is what the second half of this test holds it to.)
+    explain = lambda i, got: pose_explained_by_discontinuities(d, cfg, ref, i, got, max_jumps=3 if motion == "behind" else 2)
     fl = _bind(ops, dev, d, cfg, layout=layout, want_warped=True)
     _check_losses(fl.forward_backward(), ref)
     _check_warped(fl, ref, what, d)
     _check_grads(fl, ref, n_src, what=what, ref64=ref64, explain=explain, check_mask=bool(cfg.get("exp_reg")), **knife_widths(d, ref))
     count_in_view_mismatches(ops, dev, d, ref, layout, what)
+    # ... and SFM_PROJECTION_REFERENCE_ORDER on the same inputs: the flat criteria, no second opinion, no named pixels
+    fr = _bind(ops, dev, d, cfg, layout=layout, want_warped=True, projection="reference_order")
+    _check_losses(fr.forward_backward(), ref)
+    _check_warped(fr, ref, what + " [projection = reference_order]", d, flat=True)
+    _check_grads(fr, ref, n_src, what=what + " [projection = reference_order]", check_mask=bool(cfg.get("exp_reg")), **knife_widths(d, ref))
 
 
 @pytest.mark.parametrize("cfg_name", ["edge_aware", "l1_smooth", "explain"])
