@@ -234,6 +234,17 @@ int sfm_pyramid_variant(int variant);
 int sfm_pyramid_pair_hwc_fwd(const float *tgt, const float *src, float *const *y_tgt, float *const *y_src, int N, int n_src,
                              int H, int W, int n_scales, void *stream);
 
+/* One step of SFMLearner.__call__ from the FULL-RESOLUTION frames in one call (models/base_model.py:48-124; ABI v5): the loop head
+ * :69-72 -- sfm_pyramid_pair_hwc_fwd of tgt_full (B,3,H,W) and src_full (B,3*n_src,H,W) into the buffers desc->tgt[s] /
+ * desc->src[s], which the descriptor must bind as SFM_LAYOUT_HWC with H[s] = H[0] >> s, W[s] = W[0] >> s -- followed by
+ * sfm_loss_fwd (sfm_step_fwd) or sfm_loss_fwd_bwd (sfm_step_fwd_bwd) on the same stream.  Exactly the two calls it replaces, same
+ * results bit for bit; it exists for callers whose step is host-bound (the reference trains at B = 4, experiments/sfm_learner_v1.yml:43:
+ * 25 us of GPU work per step): one trip through the FFI, one argument conversion, one plan look-up. */
+int sfm_step_fwd(const float *tgt_full, const float *src_full, const SfmLossDesc *desc, float *loss5, void *ws, size_t ws_bytes,
+                 void *stream);
+int sfm_step_fwd_bwd(const float *tgt_full, const float *src_full, const SfmLossDesc *desc, float *loss5, void *ws, size_t ws_bytes,
+                     void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * DispNet's output activation for all scales in one launch, models/disp_net.py:7-8 and
  * :104,:110,:116,:122:  disp = 10 * sigmoid(x) + 0.01.  numel[s] = elements of scale s.

@@ -67,6 +67,8 @@ SYMBOLS = {
     "sfm_loss_fwd": (_I, [C.POINTER(SfmLossDesc), _FP, _V, _Z, _V]),
     "sfm_loss_bwd": (_I, [C.POINTER(SfmLossDesc), C.c_float, _V, _Z, _V]),
     "sfm_loss_fwd_bwd": (_I, [C.POINTER(SfmLossDesc), _FP, _V, _Z, _V]),
+    "sfm_step_fwd": (_I, [_FP, _FP, C.POINTER(SfmLossDesc), _FP, _V, _Z, _V]),
+    "sfm_step_fwd_bwd": (_I, [_FP, _FP, C.POINTER(SfmLossDesc), _FP, _V, _Z, _V]),
     "sfm_loss_plan_info": (_I, [C.POINTER(SfmLossDesc), _I, _I, C.POINTER(C.c_int), _I]),
     "sfm_loss_profile_events": (_I, [_V, _V]),
     "sfm_loss_debug_trace": (_I, [_V]),

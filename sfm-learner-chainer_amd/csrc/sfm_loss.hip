@@ -844,4 +844,32 @@ int sfm_loss_fwd_bwd(const SfmLossDesc* desc, float* loss5, void* ws, size_t ws_
   return sfm::run(desc, true, true, 1.f, loss5, ws, ws_bytes, stream, "sfm_loss_fwd_bwd");
 }
 
+// One step of SFMLearner.__call__ from the full-resolution frames (models/base_model.py:48-124) in ONE call: the loop head :69-72 --
+// both pyramids, pixel-interleaved, into the buffers the descriptor binds as tgt[] / src[] -- then the fused loss.
+static int step_from_frames(const float* tgt_full, const float* src_full, const SfmLossDesc* d, bool grad, float* loss5, void* ws,
+                            size_t ws_bytes, void* stream, const char* who) {
+  if (!d) return sfm::fail(SFM_ERR_NULL, "%s: NULL descriptor", who);
+  if (d->image_layout != SFM_LAYOUT_HWC)
+    return sfm::fail(SFM_ERR_CONFIG, "%s: the descriptor must bind pixel-interleaved pyramid buffers (SFM_LAYOUT_HWC): they are what this call writes", who);
+  if (d->n_scales < 1 || d->n_scales > SFM_MAX_SCALES) return sfm::fail(SFM_ERR_SHAPE, "%s: n_scales=%d", who, d->n_scales);
+  for (int s = 1; s < d->n_scales; ++s)
+    if (d->H[s] != d->H[0] >> s || d->W[s] != d->W[0] >> s)
+      return sfm::fail(SFM_ERR_SHAPE, "%s: scale %d is %dx%d, the pyramid of a %dx%d frame has %dx%d there (base_model.py:70)", who, s, d->H[s],
+                       d->W[s], d->H[0], d->W[0], d->H[0] >> s, d->W[0] >> s);
+  // (the descriptor's pyramid pointers are inputs of the loss and outputs of this call: the caller owns the buffers either way)
+  if (int e = sfm_pyramid_pair_hwc_fwd(tgt_full, src_full, (float* const*)d->tgt, (float* const*)d->src, d->B, d->n_src, d->H[0], d->W[0],
+                                       d->n_scales, stream))
+    return e;
+  return sfm::run(d, grad, true, 1.f, loss5, ws, ws_bytes, stream, who);
+}
+
+int sfm_step_fwd(const float* tgt_full, const float* src_full, const SfmLossDesc* desc, float* loss5, void* ws, size_t ws_bytes, void* stream) {
+  return step_from_frames(tgt_full, src_full, desc, false, loss5, ws, ws_bytes, stream, "sfm_step_fwd");
+}
+
+int sfm_step_fwd_bwd(const float* tgt_full, const float* src_full, const SfmLossDesc* desc, float* loss5, void* ws, size_t ws_bytes,
+                     void* stream) {
+  return step_from_frames(tgt_full, src_full, desc, true, loss5, ws, ws_bytes, stream, "sfm_step_fwd_bwd");
+}
+
 }  // extern "C"

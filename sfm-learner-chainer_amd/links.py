@@ -25,8 +25,11 @@ class _FusedLossFunction(Function):
     With backprop enabled the forward launch already produces every gradient
     (sfm_loss_fwd_bwd); backward only hands them out, scaled by the upstream gradient."""
 
-    def __init__(self, fused, S, n, with_masks, need_grad, run=None, state=None):
+    def __init__(self, fused, S, n, with_masks, need_grad, run=None, state=None, frames=None):
         self.fused, self.S, self.n, self.with_masks, self.need_grad, self.run = fused, S, n, with_masks, need_grad, run
+        # (tgt, stacked sources) at full resolution: pyramids + loss in ONE call through the C ABI (sfm_step_fwd_bwd); None: the
+        # pyramids of this call have been built already (planar layout, HIP-graph replay)
+        self.frames = frames
         # the call of the link this node belongs to: the gradient arrays of a cached FusedLoss are valid for its latest call only
         self.state, self.generation = state, (state.calls if state is not None else 0)
 
@@ -37,7 +40,10 @@ class _FusedLossFunction(Function):
             loss5 = self.run().clone()         # pyramid + fused launch of this call, replayed from a HIP graph (fixed output)
         else:
             out = torch.empty((5,), dtype=torch.float32, device=self.fused.device)
-            loss5 = self.fused.forward_backward(out=out) if self.need_grad else self.fused.forward(out=out)
+            if self.frames is not None:
+                loss5 = self.fused.step_from_frames(self.frames[0], self.frames[1], grad=self.need_grad, out=out)
+            else:
+                loss5 = self.fused.forward_backward(out=out) if self.need_grad else self.fused.forward(out=out)
         self.loss5 = loss5
         return loss5[0:1].reshape(()),
 
@@ -59,6 +65,12 @@ class _FusedLossFunction(Function):
 class _Cached:
     """What one link keeps between calls for one set of shapes."""
     __slots__ = ("fused", "pyr", "layout", "graph", "graph_key", "graph_stream", "calls")
+
+
+class _Repeat:
+    """The arguments of the link's previous call, for the fast path of `SFMLearnerLoss.__call__`: a call that passes the very same
+    objects, holding the very same arrays at the same addresses, has nothing to validate, reshape or re-bind."""
+    __slots__ = ("objs", "tensors", "ptrs", "st", "tgt", "stacked", "inputs", "n_scales", "n_sources", "do_exp", "norm_batch")
 
 
 # SFM_LAYOUT_HWC forms the byte offset of a gather inside one image exactly in fp32 (include/sfmwarp.h): an image of a scale
@@ -115,6 +127,7 @@ class SFMLearnerLoss:
         self.cache_buffers = cache_buffers
         self.use_graph = use_graph
         self._cache = {}
+        self._repeat = None
 
     def _state(self, tgt, stacked, intrinsics, disps, poses, masks, norm_batch):
         """The bound FusedLoss + pyramid buffers for these shapes (built on first use)."""
@@ -153,6 +166,25 @@ class SFMLearnerLoss:
            Return:
                loss (Variable).
         """
+        # Fast path (round 6; the reference trains at B = 4, where a step is 25 us of GPU work and the host side of this call decides
+        # the step time): the previous call's objects again, holding the same arrays at the same addresses -- static input buffers --
+        # are neither validated nor re-bound a second time.
+        rp = self._repeat
+        if rp is not None and norm_batch == rp.norm_batch:
+            cur = [tgt_img, src_imgs, intrinsics]
+            cur += pred_disps
+            cur += pred_poses
+            if rp.do_exp and pred_maskes is not None:
+                cur += pred_maskes
+            same = len(cur) == len(rp.objs)
+            if same:
+                for a, b, t, p in zip(cur, rp.objs, rp.tensors, rp.ptrs):
+                    d = a.data if type(a) is Variable else a
+                    if a is not b or d is not t or d.data_ptr() != p:
+                        same = False
+                        break
+            if same:
+                return self._finish(rp.st, rp.inputs, rp.n_scales, rp.n_sources, rp.do_exp, None, (rp.tgt, rp.stacked))
         tgt = ops._dev(as_array(tgt_img), "tgt_img", 4)
         src = as_array(src_imgs)
         batchsize, n_sources, _, H, W = src.shape                              # :57
@@ -168,16 +200,40 @@ class SFMLearnerLoss:
         inputs = list(pred_disps) + list(pred_poses) + (list(pred_maskes) if do_exp else [])
         need_grad = config.enable_backprop and any(isinstance(v, Variable) and v.requires_grad for v in inputs)
         st, fresh = self._state(tgt, stacked_src_imgs, K, disps, poses, masks, norm_batch)
-        fused = st.fused
         run = None
         if self.use_graph and self.cache_buffers:
             run = self._graph_step(st, tgt, stacked_src_imgs, n_scales, need_grad, fresh)
-        if run is None and not fresh:
-            _build_pyramids(st, tgt, stacked_src_imgs, n_scales)                # :69-72
+        frames = None
+        if run is None:
+            if st.layout == "hwc":
+                frames = (tgt, stacked_src_imgs)          # pyramids + loss in one call (sfm_step_fwd_bwd)
+            elif not fresh:
+                _build_pyramids(st, tgt, stacked_src_imgs, n_scales)                # :69-72
+        self._repeat = None
+        if self.cache_buffers and frames is not None and not self.use_graph:
+            rp = _Repeat()
+            rp.objs = [tgt_img, src_imgs, intrinsics] + list(pred_disps) + list(pred_poses) + (list(pred_maskes) if do_exp else [])
+            rp.tensors = [as_array(o) for o in rp.objs]
+            rp.ptrs = [t.data_ptr() for t in rp.tensors]
+            # (the arrays the kernels read are the validated, contiguous ones the descriptor is bound to; an input that had to be
+            #  copied -- non-contiguous -- is not what is bound and cannot repeat)
+            keep = st.fused._keep
+            bound = [keep[2]] + list(keep[3]) + list(keep[4]) + (list(keep[5]) if keep[5] is not None else [])
+            if tgt is rp.tensors[0] and len(bound) == len(rp.tensors) - 2 and all(a is b for a, b in zip(rp.tensors[2:], bound)) \
+                    and stacked_src_imgs.data_ptr() == rp.ptrs[1]:
+                rp.st, rp.tgt, rp.stacked, rp.inputs = st, tgt, stacked_src_imgs, inputs
+                rp.n_scales, rp.n_sources, rp.do_exp, rp.norm_batch = n_scales, n_sources, do_exp, norm_batch
+                self._repeat = rp
+        return self._finish(st, inputs, n_scales, n_sources, do_exp, run, frames, need_grad)
+
+    def _finish(self, st, inputs, n_scales, n_sources, do_exp, run, frames, need_grad=None):
+        """The Function node of this call and the five reported scalars (models/base_model.py:117-124)."""
+        if need_grad is None:
+            need_grad = config.enable_backprop and any(isinstance(v, Variable) and v.requires_grad for v in inputs)
         st.calls += 1
-        node = _FusedLossFunction(fused, n_scales, n_sources, do_exp, need_grad, run, st if self.cache_buffers else None)
+        node = _FusedLossFunction(st.fused, n_scales, n_sources, do_exp, need_grad, run, st if self.cache_buffers else None, frames)
         total_loss = node(*inputs)
-        l5 = node.loss5
+        l5 = node.loss5.unbind(0)
         report({'total_loss': l5[0]}, self)                                    # :119-123
         report({'pixel_loss': l5[1]}, self)
         report({'smooth_loss': l5[2]}, self)

@@ -437,6 +437,23 @@ class FusedLoss:
             with torch.cuda.device(self.device):
                 check(fn(self._desc_ref, *mid, self._ws_arg, self._ws_bytes, _stream(idx)))
 
+    def step_from_frames(self, tgt_full, src_full, grad=True, out=None):
+        """One step from the FULL-RESOLUTION frames in one call through the C ABI (sfm_step_fwd_bwd / sfm_step_fwd): both pyramids
+        are written into the pixel-interleaved buffers this instance was bound to (layout="hwc"), then the fused loss runs.
+        tgt_full (B,3,H,W), src_full (B,3*n_src,H,W): float32, contiguous, on the bound device -- the CALLER vouches for that
+        (links.SFMLearnerLoss validates once per set of arrays); nothing is checked here but what the library checks itself."""
+        self._zero_d_src()
+        loss5 = self.loss5 if out is None else out
+        fn = lib.sfm_step_fwd_bwd if grad else lib.sfm_step_fwd
+        l5 = self._loss5_arg if out is None else C.c_void_p(out.data_ptr())
+        idx = self.device.index
+        if torch.cuda.current_device() == idx:
+            check(fn(tgt_full.data_ptr(), src_full.data_ptr(), self._desc_ref, l5, self._ws_arg, self._ws_bytes, _stream(idx)))
+        else:
+            with torch.cuda.device(self.device):
+                check(fn(tgt_full.data_ptr(), src_full.data_ptr(), self._desc_ref, l5, self._ws_arg, self._ws_bytes, _stream(idx)))
+        return loss5
+
     def forward(self, out=None):
         """`out`: as for forward_backward."""
         loss5 = self.loss5 if out is None else out
