@@ -404,6 +404,7 @@ static const Tuning& tuning() { static const Tuning t; return t; }
 
 // chunk height per scale for a target height T: equal chunks, never more than T rows
 static void chunk_layout(const SfmLossDesc* d, int sw, int halo2, int T, int* rows, long long* items, long long* work, int* maxcost) {
+  // (T: at most this many rows per chunk)
   *items = 0; *work = 0; *maxcost = 0;
   for (int s = 0; s < d->n_scales; ++s) {
     const int h = d->H[s], strips = (d->W[s] + sw - 1) / sw;
@@ -417,11 +418,12 @@ static void chunk_layout(const SfmLossDesc* d, int sw, int halo2, int T, int* ro
   }
 }
 
-static void plan_chunks(const SfmLossDesc* d, int sw, int halo2, int slots, int passes /* walks of a wave down its chunk */, int* rows) {
+static void plan_chunks(const SfmLossDesc* d, int sw, int halo2, int slots, int passes /* walks of a wave down its chunk */, int* rows,
+                        const int max_rows = MAX_CHUNK_ROWS) {
   const int forced = tuning().chunk_rows;
-  int bestT = MAX_CHUNK_ROWS;
+  int bestT = max_rows;
   double best = 1e300;
-  for (int T = MIN_CHUNK_ROWS; T <= MAX_CHUNK_ROWS; ++T) {
+  for (int T = MIN_CHUNK_ROWS; T <= max_rows; ++T) {
     if (forced >= MIN_CHUNK_ROWS && forced <= MAX_CHUNK_ROWS && T != forced) continue;
     long long items, work;
     int maxcost, r[SFM_MAX_SCALES];
@@ -467,7 +469,7 @@ static void plan_chunks(const SfmLossDesc* d, int sw, int halo2, int slots, int 
   }
   for (int k = 0; k < d->n_scales; ++k) {
     const int v = tuning().rows_list[k];
-    if (v >= MIN_CHUNK_ROWS && v <= MAX_CHUNK_ROWS) rows[k] = v;
+    if (v >= MIN_CHUNK_ROWS && v <= max_rows) rows[k] = v;
   }
 }
 
@@ -570,7 +572,7 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
     A.prio_tab |= (unsigned)r << (2 * r) | (unsigned)(A.prio_top - r) << (8 + 2 * r);
   if (tuning().has_prio) A.prio_tab = tuning().prio_tab & 0xffffu;
   if (d->B < (tuning().deal_below > 8 ? tuning().deal_below : 8)) A.prio_tab |= 0x80000000u;   // fewer samples than XCDs (or asked for): deal items
-  plan_chunks(d, sw, 2 * (hs > hm ? hs : hm), slots, p.pair ? d->n_src / 2 : d->n_src, rows);
+  plan_chunks(d, sw, 2 * (hs > hm ? hs : hm), slots, p.pair ? d->n_src / 2 : d->n_src, rows, p.dsrc ? DSRC_MAX_CHUNK_ROWS : MAX_CHUNK_ROWS);
   int items = 0;
   for (int s = 0; s < d->n_scales; ++s) {
     const int h = d->H[s], w = d->W[s];
@@ -703,7 +705,7 @@ static hipError_t launch_main(const Plan& p, hipStream_t st, hipEvent_t ev_start
   // timestamps of THIS dispatch (what rocprofv3's kernel trace reports), and no marker packets are put between the
   // launches of a step (hipEventRecord on either side of the kernel costs the step several microseconds).
   // dynamic LDS: the accumulation window of the optional dL/d(src) output (sfm_ssim_pass.h, dsrc_scatter), only when it is bound
-  const size_t smem = (GRAD && p.dsrc) ? dsrc_tile_floats(p.ssim ? 8 : 4) * sizeof(float) : 0;
+  const size_t smem = (GRAD && p.dsrc) ? dsrc_tile_floats(p.ssim ? DSRC_ROWS_SSIM : DSRC_ROWS_L1) * sizeof(float) : 0;
   if (ev_start && ev_stop) return hipExtLaunchKernel(fn, dim3(8 * per_xcd), dim3(64 * WAVES_PER_BLOCK), kargs, smem, st, ev_start, ev_stop, 0);
   return hipLaunchKernel(fn, dim3(8 * per_xcd), dim3(64 * WAVES_PER_BLOCK), kargs, smem, st);
 }

@@ -297,9 +297,11 @@ __device__ __forceinline__ void loss_body(const Hdr& H, const LossArgs& A) {
   static_assert(GRAD || !DSRC, "dL/d(src) is an output of the backward");
   static_assert(LOSS || !WARPED, "the warped images are an output of the forward and the fused entry points");
   using HH = Halo<SSIM, GRAD, SMODE>;
-  __shared__ float gacc_all[GRAD ? WAVES_PER_BLOCK * MAX_CHUNK_ROWS * 64 : 64];
+  // (a launch that produces d_src cuts its chunks at DSRC_MAX_CHUNK_ROWS: the LDS its d_disp tile leaves goes to the d_src window)
+  constexpr int TILE_ROWS = DSRC ? DSRC_MAX_CHUNK_ROWS : MAX_CHUNK_ROWS;
+  __shared__ float gacc_all[GRAD ? WAVES_PER_BLOCK * TILE_ROWS * 64 : 64];
   const int wave = threadIdx.x >> 6;
-  float* gacc = gacc_all + (GRAD ? wave * MAX_CHUNK_ROWS * 64 : 0);
+  float* gacc = gacc_all + (GRAD ? wave * TILE_ROWS * 64 : 0);
 
   // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  XCD x is given the samples
   // b = x (mod 8) at ALL scales, largest scale first: every XCD gets the same mix of work, and all planes of
@@ -394,10 +396,9 @@ __device__ __forceinline__ void loss_body(const Hdr& H, const LossArgs& A) {
   float acc_pix = 0.f, acc_ssim = 0.f, acc_sm = 0.f, acc_exp = 0.f;
   bool first = true;
   // the LDS window of the optional dL/d(src) (dynamic LDS: allocated by the launch only when the descriptor binds d_src)
-  extern __shared__ float dsrc_tile[];
+  extern __shared__ __attribute__((aligned(16))) float dsrc_tile[];
   if (DSRC && S.d_src) {
-#pragma unroll
-    for (int k = 0; k < dsrc_tile_floats(SSIM ? 8 : 4) / 64; ++k) dsrc_tile[k * 64 + lane] = 0.f;
+    for (int k = lane; k < dsrc_tile_floats(SSIM ? DSRC_ROWS_SSIM : DSRC_ROWS_L1); k += 64) dsrc_tile[k] = 0.f;
   }
   // the disparities every source pass of this wave starts from (see ssim_source_pass / l1_source_pass): loaded once, now
   float disp_first, disp_second;

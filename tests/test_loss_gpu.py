@@ -953,11 +953,12 @@ def test_large_motion_vs_oracle(ops, synth, dev, motion, cfg_name, B, H, W, n_sr
 @pytest.mark.parametrize("motion", [None, "medium", "large", "behind"])
 def test_d_src_through_the_lds_window(ops, synth, dev, motion, cfg_name):
     """The optional dL/d(src) output (north_star: the backward "scatters dL/d(depth, pose, src_img)") at the BASELINE frame size:
-    the kernels accumulate it in a wave-private LDS window of 4 source rows x 128 columns that slides with the wave and reaches
-    memory once per source row (csrc/sfm_ssim_pass.h, dsrc_scatter); taps outside the window go to memory directly.  Default motion
-    keeps every tap inside the window; `medium` / `large` / `behind` (wide and mirrored footprints, most of the frame out of view)
-    exercise the direct path and windows that jump.  d_src element-wise against the oracle outside the scatter footprints of
-    knife-edge pixels, loss and the other gradients by the usual criteria (the launch runs another instantiation of the kernel)."""
+    the kernels accumulate it in a wave-private LDS window of 12 (SSIM kernels) or 6 source rows x 76 columns of 16-byte texels
+    (r, g, b, tag) that is re-centred on the mean tap row of every output row and reaches memory once per source row that leaves it
+    (csrc/sfm_ssim_pass.h, dsrc_scatter); taps outside the window go to memory directly.  Default motion keeps most taps inside the
+    window; `medium` / `large` / `behind` (wide and mirrored footprints, most of the frame out of view) exercise the direct path and
+    windows that jump in both directions.  d_src element-wise against the oracle outside the scatter footprints of knife-edge
+    pixels, loss and the other gradients by the usual criteria (the launch runs another instantiation of the kernel)."""
     cfg = CONFIGS[cfg_name]
     kw = dict(B=4, H=128, W=416, n_src=2, n_scales=4, with_masks=True)      # (the inputs of test_large_motion_vs_oracle)
     d = synth.make_inputs(seed=21, **kw) if motion is None else make_motion_inputs(synth, motion, seed=21, **kw)
@@ -978,6 +979,30 @@ def test_d_src_through_the_lds_window(ops, synth, dev, motion, cfg_name):
     fl._zero_d_src = keep
     for a, t, w in zip(first, fl.d_srcs, ref["d_srcs"]):
         np.testing.assert_allclose(to_np(t), 2.0 * a, rtol=0, atol=2e-5 * max(float(np.abs(w).max()), 1e-30))
+
+
+@pytest.mark.parametrize("cfg_name", ["edge_aware", "l1_smooth"])
+def test_d_src_under_heavy_minification(ops, synth, dev, cfg_name):
+    """Round-5 advisor finding: the window's read-add-write is guarded by a tag per texel against several lanes of ONE instruction
+    landing on one texel.  Here the source is sampled with a minification of 3 - 10 (the camera pulled back by 3 along z, depths
+    0.1 - 2: U = cx + (x - cx) D / (D + tz)): runs of 3 - 10 neighbouring lanes share a texel in every tap instruction, the loop
+    around the tag goes round as many times, and d_src must still be the oracle's sum."""
+    cfg = CONFIGS[cfg_name]
+    d = synth.make_inputs(B=2, H=64, W=208, n_src=2, n_scales=3, seed=31, rot_sigma=0.002, trans_sigma=0.005)
+    for p in d["poses"]:
+        p[:, 5] = np.float32(3.0)
+    ref = _oracle(d, cfg, want_d_src=True)
+    with np.errstate(invalid="ignore"):
+        du = np.abs(np.diff(ref["uv"][0][:, :, 0], axis=-1))
+    shared = float((du[np.isfinite(du)] < 0.34).mean())
+    assert shared > 0.5, "the case is meant to put three or more neighbouring lanes on one source column (share with |dU/dx| < 1/3: %.2f)" % shared
+    fl = _bind(ops, dev, d, cfg, want_d_src=True, layout="hwc")
+    _check_losses(fl.forward_backward(), ref)
+    what = "D_SRC MINIFICATION %s B=2 64x208 hwc" % cfg_name
+    ref64 = lambda: O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], None, backward=True, want_d_src=True,
+                               dtype=np.float64, **cfg)
+    _check_grads(fl, ref, 2, check_src=True, what=what, ref64=ref64, **knife_widths(d, ref))
+    parity_note("d_src %s: %.0f %% of neighbouring output pixels less than a third of a source column apart" % (what, 100 * shared))
 
 
 @pytest.mark.parametrize("motion", ["medium", "behind"])
