@@ -43,7 +43,7 @@ PKG = "sfm-learner-chainer_amd"
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_FWD, BYTES_BWD = 28, 32   # algorithmic bytes per warped pixel, SURVEY.md 8(d)
 N_SIMD = 1024                   # 256 CUs x 4 SIMDs
-PROFILE_TAGS = ("r05", "r04", "r03")         # profiles/<tag>_summary.json, _issue_model.json, _wave_stage_stamps.txt: what roofline_valu is built from
+PROFILE_TAGS = ("r06", "r05", "r04", "r03")         # profiles/<tag>_summary.json, _issue_model.json, _wave_stage_stamps.txt: what roofline_valu is built from
 GRAD_BUFFER_FLOATS = 36489060 + 3393892   # DispNet + PoseNet parameters: the ~160 MB all-reduce probe
 
 COLLECTIVE_NOTES = {
@@ -375,7 +375,7 @@ def interleaved(torch, np, runner, min_time=0.2, k=25):
     def block(with_step):
         t0 = time.perf_counter()
         for _ in range(k):
-            torch.sum(small, out=sink)
+            torch.sum(small, dim=0, out=sink)
             if with_step:
                 runner.step()
         torch.cuda.synchronize()

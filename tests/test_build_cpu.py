@@ -84,10 +84,10 @@ def test_loss_kernels_fit_their_register_budget(tmp_path):
 
 @pytest.mark.timeout(600)
 def test_committed_issue_model_is_the_one_of_these_sources():
-    """bench.py's `roofline_valu` prices the counted vector instructions with profiles/r05_issue_model.json: the file must be the
+    """bench.py's `roofline_valu` prices the counted vector instructions with profiles/r06_issue_model.json: the file must be the
     model of the kernels as they are in the tree (tools/issue_model.py --check recompiles and compares)."""
     import sys
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "issue_model.py"), "r05", "--check"], capture_output=True, text=True, timeout=580)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "issue_model.py"), "r06", "--check"], capture_output=True, text=True, timeout=580)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])

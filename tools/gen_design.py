@@ -10,7 +10,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 BLOCKS = {"parity_table": "parity_table_design.md", "warped_table": "warped_table_design.md", "perf_table": "perf_table.md"}
 path = os.path.join(ROOT, "DESIGN.md")
 text = open(path).read()

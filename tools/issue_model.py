@@ -21,7 +21,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHECK = "--check" in sys.argv          # recompute from the sources and compare with the committed JSON instead of writing it
 _args = [a for a in sys.argv[1:] if not a.startswith("--")]
-tag = _args[0] if _args else "r05"
+tag = _args[0] if _args else "r06"
 CSRC = os.path.join(ROOT, "sfm-learner-chainer_amd", "csrc")
 
 # instruction -> row of the op-cost table whose measured cost it takes

@@ -11,7 +11,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 raw_root = os.path.join(ROOT, "gpurun_out", "profiles_raw", tag)
 out = os.path.join(ROOT, "profiles")
 os.makedirs(out, exist_ok=True)
