@@ -92,6 +92,18 @@ for key, label in (("graph_ms_per_step", "the headline step replayed from a HIP 
     if isinstance(b.get(key), (int, float)):
         extra.append("| %s | %.4f | - | - | - | - |" % (label, b[key]))
 out += extra
+# round 6: the level BEFORE bench.py's one-off read of the inputs (the protocol of rounds 1-4), and the step with an unrelated kernel
+# in front of every launch (the shape of a training loop)
+frac = lambda ms: 60.0 * px / (ms * 1e-3) / 8e12
+for line, lab in ((b, "default run"), (drv, "the driver's arguments")):
+    if line and line.get("pre_warm_ms_per_step"):
+        out.append("| headline BEFORE the input warm read (%s) | %.4f | %.0f | - | - | %.3f |" % (
+            lab, line["pre_warm_ms_per_step"], px / (line["pre_warm_ms_per_step"] * 1e-3) / 1e6, frac(line["pre_warm_ms_per_step"])))
+il = b.get("cfg3_interleaved")
+if isinstance(il, dict) and "ms_per_step" in il:
+    net = il["ms_per_step"] - il["extra_kernel_ms"]
+    out.append("| headline with a 64-float reduction kernel in front of EVERY step (`cfg3_interleaved`; the reduction alone: %.4f ms) | %.4f | %.0f | - | - | %.3f (%.3f net of the reduction) |" % (
+        il["extra_kernel_ms"], il["ms_per_step"], il["value"], il["step_roofline_frac"], frac(net)))
 f = fin_us("cfg3_edge_hwc_fused")
 tail = "\n\n(`finalize_kernel` by rocprof: %s us at the headline.  bench line: `csrc_sha16` %s; roofline.traffic %s; cpu_baseline %s %s on %s core(s).)\n" % (
     ("%.2f" % f) if f else "n/a", b.get("csrc_sha16"), b["roofline"].get("traffic"), b.get("cpu_baseline", {}).get("value"), b.get("cpu_baseline", {}).get("unit"),
