@@ -694,8 +694,9 @@ def main():
     if input_warm:
         events.clear()
         pw = []
-        t_pw = time.perf_counter()
-        while len(pw) < 20 and (time.perf_counter() - t_pw < 0.15 or len(pw) < 3):
+        # (the SAME number of blocks on every rank -- they hold collectives -- so it follows from K alone, never from a clock: about
+        #  1000 steps, between 3 and 20 blocks)
+        for _ in range(min(20, max(3, 1000 // K))):
             torch.cuda.synchronize()
             if use_dist:
                 dist.barrier()
