@@ -167,7 +167,9 @@ def test_random_shapes_and_modes(ops, synth, dev, B, H, W, n_src, n_scales, cfg_
     parity_note("sweep case B=%d %dx%d n_src=%d scales=%d %s: input re-drawn %d times; %d pixels on the (-1,1) test, reach %.1e of the loss" % (
         B, H, W, n_src, n_scales, cfg_name, attempt, flips, flip_reach))
     layout = "hwc" if seed % 2 else "planar"                                   # both image layouts take part in the sweep
-    fl = _bind(ops, dev, d, cfg, layout=layout)
+    # (SFM_SWEEP_PROJECTION=reference_order runs the same sweep with SfmLossDesc.projection = SFM_PROJECTION_REFERENCE_ORDER: a soak of
+    #  that mode over shapes, batch sizes, source counts, loss modes and layouts)
+    fl = _bind(ops, dev, d, cfg, layout=layout, projection=os.environ.get("SFM_SWEEP_PROJECTION", "fast"))
     plain = dict(d, masks=None)
     count_in_view_mismatches(ops, dev, plain, ref, layout, "sweep %s %dx%d" % (cfg_name, H, W))
     counted = sum(c * 3.0 / (B * ref["margin"][s_].shape[-2] * ref["margin"][s_].shape[-1])
