@@ -318,11 +318,13 @@ __global__ void __launch_bounds__(64 * FINALIZE_WAVES) finalize_kernel(const flo
 struct Plan {
   LossArgs args;
   size_t off_loss, off_gpm, total;
+  size_t off_rec[SFM_MAX_SCALES];   // with d_src bound: the record of dL/dI^ of the scale (B, 3 n_src, h, w) that the second launch reads
+  DsrcArgs dsrc_args;               // ... and that launch (dsrc_scatter_kernel, sfm_loss_dsrc.hip)
   bool ssim, expl, hwc;
   bool wide;     // the three-waves-per-SIMD build of an L1 gradient kernel (see loss_kernel)
   bool pair;     // two sources per pass at two waves per SIMD (loss_kernel_pair, sfm_ssim_pair.h)
   bool ref;      // SfmLossDesc.projection = SFM_PROJECTION_REFERENCE_ORDER: the kernels of sfm_loss_ref.hip
-  bool dsrc;     // the launch also produces dL/d(src): the instantiations with the LDS accumulation window (three waves per SIMD)
+  bool dsrc;     // the call also produces dL/d(src): the instantiations that record dL/dI^, and the second launch
   bool warped;   // the instantiation that also writes SfmLossDesc.warped
   int smode;
 };
@@ -361,7 +363,7 @@ static int device_cus() {
 
 static int waves_per_simd_of(bool ssim, bool grad, bool wide, bool dsrc, bool pair) {   // = __launch_bounds__ of the kernel
   if (pair) return 2;
-  if (dsrc) return ssim ? 2 : 3;
+  (void)dsrc;    // (the kernels that record dL/dI^ for dL/d(src) run at the occupancy of the others)
   return ((ssim && grad) || wide) ? 3 : 4;
 }
 
@@ -485,6 +487,7 @@ static long long max_items(const SfmLossDesc* d, int sw) {
 }
 
 static void set_gy(struct Plan& p, const float gy);
+static void plan_dsrc(const SfmLossDesc* d, const int cus, struct Plan& p);
 
 constexpr int PAIR_BELOW_ROWS = 12;   // see make_plan
 
@@ -572,7 +575,7 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
     A.prio_tab |= (unsigned)r << (2 * r) | (unsigned)(A.prio_top - r) << (8 + 2 * r);
   if (tuning().has_prio) A.prio_tab = tuning().prio_tab & 0xffffu;
   if (d->B < (tuning().deal_below > 8 ? tuning().deal_below : 8)) A.prio_tab |= 0x80000000u;   // fewer samples than XCDs (or asked for): deal items
-  plan_chunks(d, sw, 2 * (hs > hm ? hs : hm), slots, p.pair ? d->n_src / 2 : d->n_src, rows, p.dsrc ? DSRC_MAX_CHUNK_ROWS : MAX_CHUNK_ROWS);
+  plan_chunks(d, sw, 2 * (hs > hm ? hs : hm), slots, p.pair ? d->n_src / 2 : d->n_src, rows);
   int items = 0;
   for (int s = 0; s < d->n_scales; ++s) {
     const int h = d->H[s], w = d->W[s];
@@ -625,7 +628,59 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
   p.off_loss = 0;
   p.off_gpm = align_up(p.off_loss + cap * 4 * sizeof(float), 256);
   p.total = align_up(p.off_gpm + cap * d->n_src * 12 * sizeof(float), 256);
+  // dL/d(src): the record of dL/dI^ per scale that binds d_src (whatever the entry point: the workspace is sized from the descriptor)
+  plan_dsrc(d, cus, p);
   return SFM_OK;
+}
+
+// The second launch of a call with d_src bound: bands, window and workgroups (DsrcArgs), and the place of the records in the workspace.
+static void plan_dsrc(const SfmLossDesc* d, const int cus, Plan& p) {
+  DsrcArgs& D = p.dsrc_args;
+  memset(&D, 0, sizeof(D));
+  D.B = d->B; D.n_src = d->n_src; D.n_scales = d->n_scales;
+  D.intrinsics = d->intrinsics;
+  for (int i = 0; i < d->n_src; ++i) D.pose[i] = d->pose[i];
+  // bands of at most max_segs 64-lane segments: as wide as possible (fewer overlapping windows) while the largest scale still gives
+  // half the CUs a workgroup
+  int max_segs = DSRC_MAX_SEGS;
+  int lds_bytes = DSRC_LDS_BYTES;
+  D.margin = DSRC_MARGIN;
+  if (const char* e = getenv("SFM_DSRC_SEGS")) max_segs = atoi(e) >= 2 ? 2 : 1;        // (development)
+  if (const char* e = getenv("SFM_DSRC_LDS_KB")) lds_bytes = atoi(e) * 1024 < lds_bytes ? atoi(e) * 1024 : lds_bytes;
+  if (const char* e = getenv("SFM_DSRC_MARGIN")) D.margin = atoi(e);
+  int s0 = -1;
+  for (int s = 0; s < d->n_scales; ++s)
+    if (d->d_src[s] && s0 < 0) s0 = s;
+  if (s0 >= 0)
+    while (max_segs > 1 && (long long)d->B * d->n_src * ((d->W[s0] + 64 * max_segs - 1) / (64 * max_segs)) < cus / 2) max_segs >>= 1;
+  int wgs = 0, widest = 0;
+  for (int s = 0; s < d->n_scales; ++s) {
+    p.off_rec[s] = 0;
+    DsrcScale& S = D.sc[s];
+    S.wg_begin = wgs;
+    if (!d->d_src[s]) continue;
+    const int h = d->H[s], w = d->W[s];
+    p.off_rec[s] = p.total;
+    p.total = align_up(p.total + (size_t)d->B * d->n_src * 3 * h * w * sizeof(float), 256);
+    S.disp = d->disp[s];
+    S.d_src = d->d_src[s];
+    S.h = h; S.w = w;
+    S.bands = (w + 64 * max_segs - 1) / (64 * max_segs);
+    S.band_w = (w + S.bands - 1) / S.bands;
+    const int segs = (S.band_w + 63) / 64;
+    S.seg_shift = segs > 1 ? 1 : 0;
+    wgs += d->B * d->n_src * S.bands;
+    if (S.band_w > widest) widest = S.band_w;
+  }
+  D.wgs = wgs;
+  D.win_cols = widest + 2 * D.margin;
+  if (D.win_cols < 16) D.win_cols = 16;
+  // as many rows as the LDS holds, at most 64
+  int rows = 64;
+  while (rows > 8 && dsrc_lds_bytes(rows, D.win_cols) > (size_t)lds_bytes) --rows;
+  D.win_rows = rows;
+  D.nq = (D.win_cols + 63) / 64;
+  D.nq_inv16 = (65536 + D.nq - 1) / D.nq;
 }
 
 static void set_gy(Plan& p, const float gy) {
@@ -643,6 +698,12 @@ static void bind_workspace(Plan& p, void* ws) {
   char* base = (char*)ws;
   p.args.part_loss = (float*)(base + p.off_loss);
   p.args.part_gpm = (float*)(base + p.off_gpm);
+  if (p.dsrc)
+    for (int s = 0; s < p.args.n_scales; ++s)
+      if (p.dsrc_args.sc[s].d_src) {
+        p.args.sc[s].d_src = (float*)(base + p.off_rec[s]);       // the main launch writes the record ...
+        p.dsrc_args.sc[s].rec = (const float*)(base + p.off_rec[s]);   // ... the second launch reads it
+      }
 }
 
 template <bool GRAD, bool LOSS>
@@ -704,8 +765,7 @@ static hipError_t launch_main(const Plan& p, hipStream_t st, hipEvent_t ev_start
   // With profiling events the kernel is launched through hipExtLaunchKernel: the events then carry the begin / end
   // timestamps of THIS dispatch (what rocprofv3's kernel trace reports), and no marker packets are put between the
   // launches of a step (hipEventRecord on either side of the kernel costs the step several microseconds).
-  // dynamic LDS: the accumulation window of the optional dL/d(src) output (sfm_ssim_pass.h, dsrc_scatter), only when it is bound
-  const size_t smem = (GRAD && p.dsrc) ? dsrc_tile_floats(p.ssim ? DSRC_ROWS_SSIM : DSRC_ROWS_L1) * sizeof(float) : 0;
+  const size_t smem = 0;
   if (ev_start && ev_stop) return hipExtLaunchKernel(fn, dim3(8 * per_xcd), dim3(64 * WAVES_PER_BLOCK), kargs, smem, st, ev_start, ev_stop, 0);
   return hipLaunchKernel(fn, dim3(8 * per_xcd), dim3(64 * WAVES_PER_BLOCK), kargs, smem, st);
 }
@@ -772,6 +832,10 @@ static int run(const SfmLossDesc* d, bool grad, bool loss, float gy, float* loss
   else if (grad) le = launch_main<true, false>(p, st, ev_start, ev_stop, variant);
   else le = launch_main<false, true>(p, st, ev_start, ev_stop, variant);
   if (le != hipSuccess) return fail((int)le, "%s: launch of the main kernel: %s", who, hipGetErrorString(le));
+  if (grad && p.dsrc) {      // dL/d(src) from the record the main launch has just written
+    le = launch_dsrc_scatter(p.dsrc_args, st);
+    if (le != hipSuccess) return fail((int)le, "%s: launch of the d_src kernel: %s", who, hipGetErrorString(le));
+  }
   const int n_pose_blocks = grad ? d->B * d->n_src : 0;
   {
     const LossArgs& a = p.args;

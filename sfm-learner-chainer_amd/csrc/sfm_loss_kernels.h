@@ -20,7 +20,7 @@ struct ScaleArgs {
   const float* mlog;
   float* d_disp;
   float* d_mask;
-  float* d_src;
+  float* d_src;                // with d_src bound: the RECORD of dL/dI^ (B, 3 n_src, h, w) in the workspace that dsrc_scatter_kernel reads
   float* warped;               // optional output (B,n_src,3,h,w): the warped sources, base_model.py:90-94
   int h, w, strips, chunks, tiles, item_begin, chunk_rows;
   float inv_cnt;               // 1 / (norm_B * 3 * h * w)                 base_model.py:111,115
@@ -297,8 +297,7 @@ __device__ __forceinline__ void loss_body(const Hdr& H, const LossArgs& A) {
   static_assert(GRAD || !DSRC, "dL/d(src) is an output of the backward");
   static_assert(LOSS || !WARPED, "the warped images are an output of the forward and the fused entry points");
   using HH = Halo<SSIM, GRAD, SMODE>;
-  // (a launch that produces d_src cuts its chunks at DSRC_MAX_CHUNK_ROWS: the LDS its d_disp tile leaves goes to the d_src window)
-  constexpr int TILE_ROWS = DSRC ? DSRC_MAX_CHUNK_ROWS : MAX_CHUNK_ROWS;
+  constexpr int TILE_ROWS = MAX_CHUNK_ROWS;
   __shared__ float gacc_all[GRAD ? WAVES_PER_BLOCK * TILE_ROWS * 64 : 64];
   const int wave = threadIdx.x >> 6;
   float* gacc = gacc_all + (GRAD ? wave * TILE_ROWS * 64 : 0);
@@ -395,11 +394,6 @@ __device__ __forceinline__ void loss_body(const Hdr& H, const LossArgs& A) {
 
   float acc_pix = 0.f, acc_ssim = 0.f, acc_sm = 0.f, acc_exp = 0.f;
   bool first = true;
-  // the LDS window of the optional dL/d(src) (dynamic LDS: allocated by the launch only when the descriptor binds d_src)
-  extern __shared__ __attribute__((aligned(16))) float dsrc_tile[];
-  if (DSRC && S.d_src) {
-    for (int k = lane; k < dsrc_tile_floats(SSIM ? DSRC_ROWS_SSIM : DSRC_ROWS_L1); k += 64) dsrc_tile[k] = 0.f;
-  }
   // the disparities every source pass of this wave starts from (see ssim_source_pass / l1_source_pass): loaded once, now
   float disp_first, disp_second;
   {
@@ -489,7 +483,6 @@ __device__ __forceinline__ void loss_body(const Hdr& H, const LossArgs& A) {
     C.h = h; C.w = w; C.y0 = y0p; C.y1 = y1p;
     C.dp = S.disp + (size_t)b * P;
     C.dsp = (DSRC && S.d_src) ? S.d_src + ((size_t)b * H.n_src + i) * 3 * P : nullptr;
-    C.dtile = dsrc_tile;
     C.wp = WARPED ? S.warped + ((size_t)b * H.n_src + i) * 3 * P : nullptr;
     C.mp = EXPL ? S.mlog + ((size_t)b * H.n_src + i) * P : nullptr;
     C.dmp = (EXPL && GRAD) ? S.d_mask + ((size_t)b * H.n_src + i) * P : nullptr;
@@ -573,10 +566,10 @@ template <bool SSIM, bool GRAD, bool LOSS, bool EXPL, int SMODE, bool HWC, bool 
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) loss_kernel(SFM_HDR_PARAMS, const LossArgs A) {
   loss_body<SSIM, GRAD, LOSS, EXPL, SMODE, HWC, WARPED>(make_hdr(A, SFM_HDR_ARGS), A);
 }
-// (DSRC, see loss_body: the gradient kernels of a launch that also wants dL/d(src).  Three waves per SIMD; the SSIM ones two: at
-//  three they would spill 22-34 registers to scratch)
+// (DSRC, see loss_body: the gradient kernels of a launch that also wants dL/d(src): the same kernels plus three stores per pixel row
+//  and source, the record of dL/dI^ that dsrc_scatter_kernel turns into d_src)
 template <bool SSIM, bool LOSS, bool EXPL, int SMODE, bool HWC, bool WARPED = false>
-__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, SSIM ? 2 : 3) loss_kernel_dsrc(SFM_HDR_PARAMS, const LossArgs A) {
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, SSIM ? 3 : 4) loss_kernel_dsrc(SFM_HDR_PARAMS, const LossArgs A) {
   loss_body<SSIM, true, LOSS, EXPL, SMODE, HWC, WARPED, 0, true>(make_hdr(A, SFM_HDR_ARGS), A);
 }
 // (REF, see loss_body: every launch of a descriptor with projection = SFM_PROJECTION_REFERENCE_ORDER; sfm_loss_ref.hip instantiates them)
@@ -600,5 +593,44 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 3) loss_kernel_wide(SFM_
 const void* kernel_ptr_ref(bool grad, bool loss, bool ssim, bool expl, int smode, bool hwc, bool warped);
 const void* kernel_ptr_dsrc(bool loss, bool ssim, bool expl, int smode, bool hwc, bool warped);
 const void* kernel_ptr_pair(bool grad, bool loss, int smode);
+
+// ------------------------------------------------------------------------------------------
+// The second launch of a call with SfmLossDesc.d_src bound (sfm_loss_dsrc.hip): dL/d(src) from the record of dL/dI^.
+// One workgroup per (scale, sample, source, band of columns) walks down ITS band of the target image, DSRC_WAVES pixel rows of 64
+// lanes at a time, re-projects the pixels (the projection of the main launch: same inputs, same instructions, same
+// cells and fractions) and adds the four taps of every in-view sample into a window of the source image held in LDS as DOUBLES
+// (ds_add_f64: 3 - 4 ticks per wave instruction and CU, against 100+ for ds_add_f32: profiles/r06_lds_atomic_cost.txt): win_rows source
+// rows x win_cols columns x 3 channels that follow the mean tap row of the band.  A row that leaves the window is added to d_src once
+// (float atomics: bands and windows of other workgroups overlap it) and cleared; taps outside the window go to memory directly.
+// ------------------------------------------------------------------------------------------
+constexpr int DSRC_WAVES = 8;             // wavefronts per workgroup that sample and add: one pixel row of 64 lanes each per step
+constexpr int DSRC_FLUSH_WAVES = 4;       // ... and that only flush
+constexpr int DSRC_MAX_SEGS = 2;          // a band is at most this many 64-lane segments wide
+constexpr int DSRC_MARGIN = 12;           // window columns on either side of the band (on top of the mean horizontal shift, which the window follows)
+constexpr int DSRC_LDS_BYTES = 156 * 1024;  // of the CU's 160 KiB: one workgroup per CU
+__host__ __device__ constexpr size_t dsrc_lds_bytes(const int rows, const int cols) {      // window, 12 ints of statistics, a first column per row
+  return (size_t)rows * cols * 3 * sizeof(double) + (12 + (size_t)rows) * sizeof(int); 
+}
+struct DsrcScale {
+  const float* rec;    // (B, 3 n_src, h, w): dL/dI^ of every warped pixel, written by the main launch
+  const float* disp;   // (B, 1, h, w)
+  float* d_src;        // (B, 3 n_src, h, w), accumulated into
+  int h, w;
+  int bands, band_w;   // column bands per image, target columns per band
+  int seg_shift;       // log2 of the 64-lane segments per band row (1 or 2 of them): DSRC_WAVES >> seg_shift rows per step
+  int wg_begin;        // first workgroup of the scale (largest scale first)
+};
+struct DsrcArgs {
+  DsrcScale sc[SFM_MAX_SCALES];
+  const float* pose[SFM_MAX_SRC];
+  const float* intrinsics;
+  int B, n_src, n_scales;
+  int win_rows, win_cols;   // the LDS window: source rows (ring) x columns
+  int margin;               // window columns on either side of the band
+  int nq, nq_inv16;         // 64-column pieces of a window row, and ceil(2^16 / nq)
+  int wgs;                  // workgroups
+  unsigned long long* counters;   // development (SFM_DSRC_COUNT): samples with taps outside the window; normally nullptr
+};
+hipError_t launch_dsrc_scatter(const DsrcArgs& a, hipStream_t st);
 
 }  // namespace sfm

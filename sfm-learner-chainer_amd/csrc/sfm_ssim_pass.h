@@ -46,8 +46,7 @@ struct SsimCtx {
   const float* tp[3];   // target planes of this sample
   const float* sp[3];   // source planes of this (sample, source)
   const float* dp;      // disparity plane
-  float* dsp;           // d_src planes of this (sample, source) or nullptr
-  float* dtile;         // with dsp: this wave's LDS accumulation window for dL/d(src) (rows x DSRC_COLS texels of (r, g, b, tag), see dsrc_scatter)
+  float* dsp;           // the three planes of this (sample, source) in the RECORD of dL/dI^ a launch with d_src bound keeps, or nullptr
   float* wp;            // planes of the optional warped-image output of this (sample, source), or nullptr   base_model.py:90-94
   const float* mp;      // explainability logits of this (sample, source) or nullptr     base_model.py:104
   float* dmp;           // their gradient plane or nullptr
@@ -631,140 +630,19 @@ __device__ __forceinline__ void store_warped_row(const SsimCtx& C, const int r, 
 struct PoseAcc {
   f2 A, B, Cq;         // sum gq D, sum y gq D, sum gq   (components 0, 1)
   float A2, B2, C2;    // ... component 2
-  int dvb, dcb;        // optional dL/d(src): first source row / column of the LDS accumulation window (wave-uniform; dsrc_scatter)
 };
-constexpr int DSRC_UNSET = 0x7fffffff;
 __device__ __forceinline__ void zero(PoseAcc& a) {
   a.A = a.B = a.Cq = T_of<f2>(0.f); a.A2 = a.B2 = a.C2 = 0.f;
-  a.dvb = DSRC_UNSET; a.dcb = 0;
 }
 
 // ------------------------------------------------------------------------------------------
 // Optional dL/d(src) (SfmLossDesc.d_src; the reference discards it in training, models/base_model.py:71-72 `.data`): the scatter of
-// dL/dI^ over the four taps of every sample, SURVEY.md App. A.3.  Straight to memory that is 12 global float atomics per warped pixel
-// and the cfg3 step takes 1.26 ms instead of 0.057 (round 5, profiles/r05_d_src.txt: what costs is the number of 64-byte atomic
-// requests, and a wave instruction whose lanes land in different source rows is up to 64 of them).  The wave therefore accumulates in
-// LDS where it can: a window of DR source rows x DSRC_COLS columns that follows the taps of the wave's current output row down the
-// source image.  A row that leaves the window is added to memory ONCE -- one dense 256-byte atomic per 64 texels and channel -- and
-// cleared; taps outside the window go to memory directly: the result is the same sum either way.
-//
-// Round 6 (round-5 verdict item 3).  The window of round 5 held 39 % of the scale-0 taps of synth's rough disparity field (4.36 M
-// inside, 6.83 M ABOVE it, none below: profiles/r05_d_src.txt) although +-3 rows around the mean tap row hold 56 %: it only ever
-// moved DOWN, so every upward jitter of the mean tap row left it too low for good.  Now
-//   * it is re-centred on the mean tap row of every output row, in BOTH directions (one row of hysteresis against jitter): what
-//     leaves it at either end is flushed;
-//   * a texel is ONE 16-byte LDS word (r, g, b, tag): a tap is a 4-byte tag write, a 16-byte read that brings the tag back WITH the
-//     sums, and a 16-byte write -- three LDS operations instead of eight (tag write / read + three read-add-writes), all of them
-//     volatile: the protocol's order is the program's order (round-5 advisor finding);
-//   * 12 rows x 76 columns (14.3 KB) next to a d_disp tile of 16 rows (launches with d_src cut their chunks at 16 rows) in the SSIM
-//     kernels, 6 rows in the others: +-5.5 rows hold 75 % of the scale-0 taps, nearly all at the smaller scales.
+// dL/dI^ over the four taps of every sample, SURVEY.md App. A.3.  The main launch does NOT scatter: it RECORDS dL/dI^ of every warped
+// pixel (three coalesced stores per pixel row into the workspace, geometry_backward below) and a second launch, dsrc_scatter_kernel
+// (sfm_loss_dsrc.hip), re-projects the pixels and sums their taps in an LDS window per workgroup.  History of the scatter inside this
+// kernel -- straight to memory 1.26 ms per cfg3 step (round 4), an LDS window per wave 0.51 (round 5) and 0.42 (round 6, first
+// form: the window costs the kernel a wave per SIMD and half its chunk height) -- in profiles/r06_d_src.txt.
 // ------------------------------------------------------------------------------------------
-constexpr int DSRC_COLS = 76;
-constexpr int DSRC_ROWS_SSIM = 12, DSRC_ROWS_L1 = 6;      // window rows: SSIM kernels (two waves per SIMD: 20 KB of LDS per wave) / the others (three)
-constexpr int DSRC_MAX_CHUNK_ROWS = 16;                   // chunk height of a launch that produces d_src (its d_disp tile: 4 KB)
-__host__ __device__ constexpr int dsrc_tile_floats(const int dr) { return dr * 4 * DSRC_COLS; }
-
-struct __attribute__((aligned(16))) DsrcTexel { float r, g, b; int tag; };
-
-// rows [v0, v1) of the window (at most DR of them) -> memory, and cleared
-template <int DR>
-__device__ __forceinline__ void dsrc_flush(const SsimCtx& C, const int v0, const int v1, const int cb) {
-  volatile DsrcTexel* win = reinterpret_cast<volatile DsrcTexel*>(C.dtile);
-  for (int v = v0; v < v1; ++v) {
-    // (a window placed around the first taps can reach above or below the image: those rows never received anything -- taps are
-    //  taken in view only -- and have no slot of their own)
-    if ((unsigned)v >= (unsigned)C.h) continue;
-    volatile DsrcTexel* row = win + ((unsigned)v % (unsigned)DR) * DSRC_COLS;
-#pragma unroll
-    for (int j = 0; j < (DSRC_COLS + 63) / 64; ++j) {
-      const int col = j * 64 + C.lane;
-      if (col < DSRC_COLS) {
-        const float r = row[col].r, g = row[col].g, bl = row[col].b;
-        row[col].r = 0.f; row[col].g = 0.f; row[col].b = 0.f;
-        // (a column outside the image never received anything either; the test keeps every address inside the plane whatever the sums hold)
-        if ((unsigned)(cb + col) < (unsigned)C.w) {
-          float* o = C.dsp + (unsigned)(v * C.w + cb + col);
-          if (r != 0.f) atomicAdd(o, r);
-          if (g != 0.f) atomicAdd(o + C.P, g);
-          if (bl != 0.f) atomicAdd(o + 2 * C.P, bl);
-        }
-      }
-    }
-  }
-}
-
-// A tap of every lane into the window.  ds_add_f32 would be the obvious instruction and is unusable: 564 cycles per wave
-// instruction per SIMD on gfx950 (profiles/r05_op_cost_microbench.txt).  Plain read-add-write instead, made safe against two lanes
-// of the SAME instruction landing on one texel (minification, folds) by the texel's tag word: every pending lane writes its lane
-// id, reads the texel back -- tag and sums in one 16-byte read -- and the lane whose id survived writes the sums (and its id) back;
-// the others go round again (wave-uniform loop; one trip unless lanes collide).  LDS operations of a wave execute in order, the
-// window is private to the wave, and every access is volatile: nothing is cached in registers or moved across the protocol.
-__device__ __forceinline__ void dsrc_add(const SsimCtx& C, bool pend, const int slot /* window row * DSRC_COLS + column */, const float* val) {
-  typedef float f4v __attribute__((ext_vector_type(4)));
-  volatile DsrcTexel* t = reinterpret_cast<volatile DsrcTexel*>(C.dtile) + slot;
-  volatile f4v* tv = reinterpret_cast<volatile f4v*>(t);
-  while (__builtin_amdgcn_ballot_w64(pend) != 0) {
-    if (pend) t->tag = C.lane;
-    if (pend) {
-      const f4v cur = *tv;
-      if (__float_as_int(cur.w) == C.lane) {
-        f4v nxt;
-        nxt.x = cur.x + val[0]; nxt.y = cur.y + val[1]; nxt.z = cur.z + val[2]; nxt.w = cur.w;
-        *tv = nxt;
-        pend = false;
-      }
-    }
-  }
-}
-// (Measured and not kept, round 6: the two taps of a footprint column in ONE protocol round -- tags lane * 2 + tap -- made the cfg3
-//  step no shorter, 419 us against 421, and the smooth-field one longer, 314 against 284: the protocol's latency is not what this
-//  path waits for.  profiles/r06_d_src.txt.)
-
-template <int DR>
-__device__ __forceinline__ void dsrc_scatter(const SsimCtx& C, const Proj& p, const bool act, const float* gI, PoseAcc& gpm) {
-  const unsigned long long m = __builtin_amdgcn_ballot_w64(act);
-  if (m == 0) return;                                      // (wave-uniform) no sample of this row is in view
-  const int cnt = __builtin_popcountll(m);
-  const float vsum = wave_sum(act ? (float)p.v0 : 0.f);
-  const int vmid = (int)(vsum / (float)cnt);               // v0 >= 0 in view: truncation is floor
-  const int want = vmid - DR / 2 + 1;                      // the window centred on the taps (v0, v0 + 1) of the mean sample
-  if (gpm.dvb == DSRC_UNSET) {                             // first such row of the pass: place the window around its taps
-    const float usum = wave_sum(act ? (float)p.u0 : 0.f);
-    gpm.dcb = (int)(usum / (float)cnt) - DSRC_COLS / 2 + 1;
-    gpm.dvb = want;
-  }
-  // follow the mean tap row in both directions, one row of hysteresis upwards (the mean advances by about one source row per
-  // output row and jitters by one or two: a window that only ever moved down ended up below most of its taps)
-  int nvb = gpm.dvb;
-  if (want > gpm.dvb) nvb = want;
-  else if (want < gpm.dvb - 1) nvb = want + 1;
-  if (nvb > gpm.dvb) {
-    dsrc_flush<DR>(C, gpm.dvb, min(nvb, gpm.dvb + DR), gpm.dcb);
-    gpm.dvb = nvb;
-  } else if (nvb < gpm.dvb) {
-    dsrc_flush<DR>(C, max(nvb + DR, gpm.dvb), gpm.dvb + DR, gpm.dcb);
-    gpm.dvb = nvb;
-  }
-  const float w00 = (1.f - p.fu) * (1.f - p.fv), w01 = p.fu * (1.f - p.fv), w10 = (1.f - p.fu) * p.fv, w11 = p.fu * p.fv;
-  const float wt[4] = {w00, w01, w10, w11};
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int v = p.v0 + (k >> 1), u = p.u0 + (k & 1);
-    const bool inside = act && (unsigned)(v - gpm.dvb) < (unsigned)DR && (unsigned)(u - gpm.dcb) < (unsigned)DSRC_COLS;
-    const float val[3] = {gI[0] * wt[k], gI[1] * wt[k], gI[2] * wt[k]};
-    dsrc_add(C, inside, (int)((unsigned)max(v, 0) % (unsigned)DR) * DSRC_COLS + (u - gpm.dcb), val);
-    if (act && !inside) {                                  // outside the window (above, below or beside it): straight to memory
-      float* ds = C.dsp + (unsigned)(v * C.w + u);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) atomicAdd(ds + c * C.P, val[c]);
-    }
-  }
-}
-// end of a pass: what is left in the window
-template <int DR>
-__device__ __forceinline__ void dsrc_finish(const SsimCtx& C, const PoseAcc& gpm) {
-  if (C.dsp != nullptr && gpm.dvb != DSRC_UNSET) dsrc_flush<DR>(C, gpm.dvb, gpm.dvb + DR, gpm.dcb);
-}
 
 // From dL/dI^ of one pixel (already contracted with dI^/du, dI^/dv and 1/z into gq = (gq0, gq1)) to its
 // share of d_depth (LDS tile), of the 12 sums of dL/dPm and, optionally, of dL/d(src).
@@ -782,7 +660,7 @@ __device__ __forceinline__ float geom_terms(const SsimCtx& C, const f2 UV, const
   return gdisp;
 }
 
-template <int DR /* rows of the dL/d(src) window; 0: the output is not produced */, int REF = 0>
+template <bool DSRC /* the launch also produces dL/d(src) */, int REF = 0>
 __device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& s2, const int rc, const f2 gq,
                                                   const float* gI, float* gacc, const bool first, PoseAcc& gpm) {
   const int h = C.h, w = C.w;
@@ -801,18 +679,15 @@ __device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& 
   // (an LDS add without return value, ds_add_f32, has nothing to wait for but costs the launch 3 % at cfg3: it is a slow LDS op)
   if (first) *ga = gdisp;
   else *ga = *ga + gdisp;
-  // (DSRC: the instantiations a launch with SfmLossDesc.d_src bound runs.  A run-time branch here -- rounds 1-4 -- costs the kernels
-  //  of every OTHER launch registers: with the window code behind it the SSIM gradient kernels spill 32 VGPRs)
-  if (DR != 0 && C.dsp != nullptr) {   // optional dL/d(src): scatter of dL/dI^ over the four taps, through the LDS window
-    Proj p;
-    if constexpr (REF != 0) {
-      p = ref_proj_cell(ref_position(C, yf, s2.D), h, w);
-    } else {
-      const float a0 = fmaf(C.M1[0], yf, C.mx[0]), a1 = fmaf(C.M1[1], yf, C.mx[1]), a2 = fmaf(C.M1[2], yf, C.mx[2]);
-      p = project(a0, a1, a2, C.P3[0], C.P3[1], C.P3[2], s2.D, C.sc, h, w);
-    }
-    dsrc_scatter<DR == 0 ? DSRC_ROWS_L1 : DR>(C, p, p.inview && C.outf != 0.f, gI, gpm);
+  // (DSRC: the instantiations a launch with SfmLossDesc.d_src bound runs: they record dL/dI^ of the pixel for dsrc_scatter_kernel,
+  //  which applies the in-view test itself.  Instantiations of their own so that no other launch carries the branch.)
+  if (DSRC && C.dsp != nullptr && C.outb) {
+    const unsigned o = (unsigned)rc * (unsigned)w + (unsigned)(C.x0 + C.lane);
+    C.dsp[o] = gI[0];
+    C.dsp[o + (unsigned)C.P] = gI[1];
+    C.dsp[o + 2u * (unsigned)C.P] = gI[2];
   }
+  (void)h;
 }
 
 // The pose sums of this (wave, source) from the 9 per-lane accumulators of geometry_backward.  dL/dPm[k][j] = sum over pixels of
@@ -962,7 +837,7 @@ __device__ __forceinline__ void ssim_stage_c_row(const SsimCtx& C, const int rc,
   // and I^ - I is at hand (with the fused kernel stage B would form it a second time, one row earlier)
   if (LOSS) acc_pix = fmaf(vabs_sum(dp) + vabs_sum(ds), s2.nm * C.outf, acc_pix);
   const float gI[3] = {gp.x, gp.y, gs};
-  geometry_backward<DSRC ? DSRC_ROWS_SSIM : 0, REF>(C, s2, rc, contract_uv(s2, gp, gs), gI, gacc, first, gpm);
+  geometry_backward<DSRC, REF>(C, s2, rc, contract_uv(s2, gp, gs), gI, gacc, first, gpm);
 }
 
 // Which stages run on which step of a pass, as bit k of one 32-bit word per question (a pass has at most 32 steps): every
@@ -1067,7 +942,6 @@ __device__ __forceinline__ void ssim_source_pass(const SsimCtx& C, float* gacc, 
       ssim_row_step<GRAD, LOSS, HWC, WARPED, REF, DSRC>(C, M, k + 2, r + 2, ps, disp_next, S2, S1, S0, G2, G1, G0, gacc, first, acc_pix, acc_ssim, gpm SFM_STAMPS_PASS);
   }
   if (GRAD) {
-    if (DSRC) dsrc_finish<DSRC_ROWS_SSIM>(C, gpm);
     pose_sums_raw(C, gpm, gpm_out);
   }
 }
@@ -1108,11 +982,10 @@ __device__ __forceinline__ void l1_source_pass(const SsimCtx& C, float* gacc, co
         // d/dlogit of (1-alpha) mean(err sigmoid) + exp_reg mean(softplus(-logit))
         if (C.outf != 0.f) stf_wt(C.dmp, (unsigned)r * (unsigned)C.w + C.xc, C.k_pix * e1 * sgm * (1.f - sgm) + C.k_exp * (sgm - 1.f));
       }
-      geometry_backward<DSRC ? DSRC_ROWS_L1 : 0, REF>(C, s0, r, contract_uv(s0, gp, gs), gI, gacc, first, gpm);
+      geometry_backward<DSRC, REF>(C, s0, r, contract_uv(s0, gp, gs), gI, gacc, first, gpm);
     }
   }
   if (GRAD) {
-    if (DSRC) dsrc_finish<DSRC_ROWS_L1>(C, gpm);
     pose_sums_raw(C, gpm, gpm_out);
   }
 }
