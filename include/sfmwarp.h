@@ -140,7 +140,7 @@ int sfm_sampler_interp_bwd(const float *x, const float *grid, const float *gy, f
  *                                   instructions per pixel row: the launch is about 10 % longer.  GUARANTEES: warped pixels within
  *                                   1e-4 of the image range at ANY frame size, seams, large motion and samples behind the camera
  *                                   included, and gradients that need no second opinion (d_pose within 1e-5 of its maximum).
- * Not available together with d_src (SFM_ERR_CONFIG). */
+ * Both produce d_src (a second launch re-projects the pixels by the same chain). */
 #define SFM_PROJECTION_FAST 0
 #define SFM_PROJECTION_REFERENCE_ORDER 1
 
@@ -166,6 +166,10 @@ typedef struct SfmLossDesc {
   float *d_disp[SFM_MAX_SCALES]; /* (B,1,h,w)     overwritten                                 */
   float *d_pose[SFM_MAX_SRC];    /* (B,6)         overwritten                                 */
   float *d_mask[SFM_MAX_SCALES]; /* (B,n_src,h,w) overwritten; required iff exp_reg != 0      */
+  /* optional: dL/d(curr_src_imgs) (the reference computes it -- the sampler's gx, models/transform.py:189 -- and drops it,
+   * base_model.py:71-72 `.data`).  Any subset of the scales may bind it.  Binding it adds a second kernel launch to
+   * sfm_loss_bwd / sfm_loss_fwd_bwd (the pixels re-projected, their taps summed in on-chip memory) and, per bound scale,
+   * B*3*n_src*h*w floats to sfm_loss_workspace_bytes (dL/d(warped pixel), recorded by the first launch). */
   float *d_src[SFM_MAX_SCALES];  /* (B,3*n_src,h,w) or NULL; ACCUMULATED (atomics)            */
   int32_t image_layout;          /* SFM_LAYOUT_* of tgt[] and src[]                           */
   /* optional output of sfm_loss_fwd and sfm_loss_fwd_bwd (ignored by sfm_loss_bwd): the warped source images the loss

@@ -510,9 +510,6 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
   if (d->projection != SFM_PROJECTION_FAST && d->projection != SFM_PROJECTION_REFERENCE_ORDER)
     return fail(SFM_ERR_CONFIG, "sfm_loss: projection=%d", d->projection);
   p.ref = d->projection == SFM_PROJECTION_REFERENCE_ORDER;
-  if (p.ref)      // (whatever the entry point: a descriptor is either valid for all three or for none)
-    for (int s = 0; s < d->n_scales && s < SFM_MAX_SCALES; ++s)
-      if (d->d_src[s]) return fail(SFM_ERR_CONFIG, "sfm_loss: d_src is not produced with projection = SFM_PROJECTION_REFERENCE_ORDER (bind one or the other)");
   p.expl = d->exp_reg > 0.f;                       // base_model.py:86,103
   p.ssim = !p.expl && d->ssim_rate > 0.f;          // base_model.py:110-112
   p.smode = d->smooth_reg > 0.f ? d->smooth_mode : SFM_SMOOTH_NONE;   // base_model.py:75
@@ -639,6 +636,7 @@ static void plan_dsrc(const SfmLossDesc* d, const int cus, Plan& p) {
   memset(&D, 0, sizeof(D));
   D.B = d->B; D.n_src = d->n_src; D.n_scales = d->n_scales;
   D.intrinsics = d->intrinsics;
+  D.ref = d->projection == SFM_PROJECTION_REFERENCE_ORDER;
   for (int i = 0; i < d->n_src; ++i) D.pose[i] = d->pose[i];
   // bands of at most max_segs 64-lane segments: as wide as possible (fewer overlapping windows) while the largest scale still gives
   // half the CUs a workgroup
@@ -760,7 +758,7 @@ static hipError_t launch_main(const Plan& p, hipStream_t st, hipEvent_t ev_start
   if (p.ref) fn = kernel_ptr_ref(GRAD, LOSS, p.ssim, p.expl, p.smode, p.hwc, p.warped);      // SFM_PROJECTION_REFERENCE_ORDER
   if (p.pair) fn = kernel_ptr_pair(GRAD, LOSS, p.smode);                                     // two sources per pass
   if constexpr (GRAD) {
-    if (p.dsrc) fn = kernel_ptr_dsrc(LOSS, p.ssim, p.expl, p.smode, p.hwc, p.warped);
+    if (p.dsrc && !p.ref) fn = kernel_ptr_dsrc(LOSS, p.ssim, p.expl, p.smode, p.hwc, p.warped);      // (the REF kernels record dL/dI^ themselves)
   }
   // With profiling events the kernel is launched through hipExtLaunchKernel: the events then carry the begin / end
   // timestamps of THIS dispatch (what rocprofv3's kernel trace reports), and no marker packets are put between the

@@ -103,13 +103,14 @@ __device__ __forceinline__ void dsrc_flush_rows(double* win, const int* cbs, con
 }
 
 // NW wavefronts that sample and add, NF that flush (and nothing else)
-template <int NW, int NF>
+template <int NW, int NF, bool REF>
 __global__ void __launch_bounds__(64 * (NW + NF)) dsrc_scatter_kernel(const DsrcArgs A) {
   extern __shared__ __attribute__((aligned(16))) double dsrc_win[];
   const int DR = A.win_rows, WC = A.win_cols, PL = DR * WC;
   // behind the window: stats[3][4] = (sum of v0 - y and of u0 - x over the in-view samples of a step, their number, -), then cbs[DR]
   int* hdr = reinterpret_cast<int*>(dsrc_win + (size_t)PL * 3);
-  int* cbs = hdr + 12;
+  int* ctl = hdr + 12;      // ctl[3][2]: (vb, sb) of a step, written during the step before it
+  int* cbs = hdr + 20;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool flusher = wave >= NW;
   int s = 0;
@@ -133,32 +134,54 @@ __global__ void __launch_bounds__(64 * (NW + NF)) dsrc_scatter_kernel(const Dsrc
   const float* dpl = S.disp + (size_t)b * P;
   const unsigned xc = (unsigned)min(x, w - 1);
 
-  // the projection rows of (sample, scale, source): what loss_body hands its passes (FAST projection)
-  const WaveGeom WG = build_wave_geom(A.pose, A.n_src, b, A.intrinsics + (size_t)(b * A.n_scales + s) * 9, lane);
+  // the projection rows of (sample, scale, source): what loss_body hands its passes, for either projection
+  WaveGeom WG;
+  WaveGeomRef WGR;
+  build_wave_geom_any<REF>(A.pose, A.n_src, b, A.intrinsics + (size_t)(b * A.n_scales + s) * 9, lane, WG, WGR);
   const float xf = (float)x;
-  float M1[3], P3[3], mx[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    M1[k] = from_lane(WG.M1, 8 * i + k);
-    P3[k] = from_lane(WG.P3, 8 * i + k);
-    mx[k] = fmaf(from_lane(WG.M0, 8 * i + k), xf, from_lane(WG.M2, 8 * i + k));
-  }
   const ScaleConst sc = make_scale_const(h, w);
+  SsimCtx C;       // (only the fields the projection reads are ever set or used)
+  C.sc = sc;
+  if constexpr (REF) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      C.Pm[k * 4 + 0] = from_lane(WGR.P0, 8 * i + k);
+      C.Pm[k * 4 + 1] = from_lane(WGR.P1, 8 * i + k);
+      C.Pm[k * 4 + 2] = from_lane(WGR.P2, 8 * i + k);
+      C.Pm[k * 4 + 3] = from_lane(WGR.P3, 8 * i + k);
+      C.Ki1[k] = from_lane(WGR.Ki1, k);
+      C.Ki2[k] = from_lane(WGR.Ki2, k);
+      C.mx[k] = from_lane(WGR.Ki0, k) * xf;
+    }
+    C.hw[0] = 0.5f * sc.wm1; C.hw[1] = 0.5f * sc.hm1;
+    C.rhw[0] = uniform(rcp_refined(C.hw[0])); C.rhw[1] = uniform(rcp_refined(C.hw[1]));
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      C.M1[k] = from_lane(WG.M1, 8 * i + k);
+      C.P3[k] = from_lane(WG.P3, 8 * i + k);
+      C.mx[k] = fmaf(from_lane(WG.M0, 8 * i + k), xf, from_lane(WG.M2, 8 * i + k));
+    }
+  }
 
   for (int k = tid; k < PL * 3; k += 64 * (NW + NF)) dsrc_win[k] = 0.0;
-  if (tid < 12) hdr[tid] = 0;
+  if (tid < 20) hdr[tid] = 0;
   __syncthreads();
 
   const int SL = max(2, min(2 * G, DR / 3)) & ~1;      // slack rows; the window moves by at most SL / 2 rows between two steps
   const int DA = DR - SL;
   const int steps = (h + G - 1) / G;
 
-  // the sample of (row r, this lane): cell, fractions, in view
+  // the sample of (row r, this lane): cell, fractions, in view -- the instructions of the main launch (issue_row / geometry_backward)
   auto sample = [&](const int r, const float disp) -> Proj {
     const float yf = (float)r;
-    const float D = rcp(disp);                                                         // base_model.py:60, as issue_row
-    const float a0 = fmaf(M1[0], yf, mx[0]), a1 = fmaf(M1[1], yf, mx[1]), a2 = fmaf(M1[2], yf, mx[2]);
-    return project(a0, a1, a2, P3[0], P3[1], P3[2], D, sc, h, w);
+    if constexpr (REF) {
+      return ref_proj_cell(ref_position(C, yf, rcp_refined(disp)), h, w);
+    } else {
+      const float D = rcp(disp);                                                         // base_model.py:60, as issue_row
+      const float a0 = fmaf(C.M1[0], yf, C.mx[0]), a1 = fmaf(C.M1[1], yf, C.mx[1]), a2 = fmaf(C.M1[2], yf, C.mx[2]);
+      return project(a0, a1, a2, C.P3[0], C.P3[1], C.P3[2], D, sc, h, w);
+    }
   };
   auto clampd = [](const int d) -> float { return (float)max(min(d, 2047), -2048); };
   // mean of a step's statistic, rounded down (the same instructions in every wavefront: the same value)
@@ -175,7 +198,7 @@ __global__ void __launch_bounds__(64 * (NW + NF)) dsrc_scatter_kernel(const Dsrc
   }
 
   // placement: the first step's own samples (a pass without adds)
-  int vb = 0, sb = 0;
+  int vb = 0, sb = 0, d_cur = 0;
   {
     const Proj p = sample(rsub, dsp);
     const bool act = xvalid && rsub < h && p.inview;
@@ -192,6 +215,7 @@ __global__ void __launch_bounds__(64 * (NW + NF)) dsrc_scatter_kernel(const Dsrc
     __syncthreads();
     const int n = __builtin_amdgcn_readfirstlane(hdr[10]);
     const int cb0 = xb - A.margin + (n > 0 ? mean_of(__builtin_amdgcn_readfirstlane(hdr[9]), n) : 0);
+    if (n > 0) vb = mean_of(__builtin_amdgcn_readfirstlane(hdr[8]), n) + (G + 1) / 2 - DA / 2;      // the window of step 0: around its own taps
     if (tid < DR) cbs[tid] = cb0;
     // (visible to everyone behind the barrier that ends step 0: no slot is read before -- see below -- except by step 0 itself)
     __syncthreads();
@@ -207,38 +231,49 @@ __global__ void __launch_bounds__(64 * (NW + NF)) dsrc_scatter_kernel(const Dsrc
       n0 = nvalid ? rec[o] : 0.f; n1 = nvalid ? rec[o + P] : 0.f; n2 = nvalid ? rec[o + 2 * P] : 0.f;
       ndsp = dpl[o];
     }
-    // where the window goes: the mean tap row of the step before (complete: the barrier that ended it), G rows further down
-    {
+    if (flusher) {
+      // the rows the move INTO this step's window (d_cur, decided a step ago) pushed out of its active part: to memory, now
+      if (d_cur > 0) {                         // rows vb - d .. vb - 1 left at the top
+        int sf = sb - d_cur;
+        sf += sf < 0 ? DR : 0;
+        dsrc_flush_rows<NF>(dsrc_win, cbs, DR, WC, A.nq, A.nq_inv16, sf, vb - d_cur, d_cur, dst, h, w, P, wave - NW, lane);
+      } else if (d_cur < 0) {                  // rows vb + DA .. vb + DA - d - 1 left at the bottom
+        int sf = sb + DA;
+        sf -= sf >= DR ? DR : 0;
+        dsrc_flush_rows<NF>(dsrc_win, cbs, DR, WC, A.nq, A.nq_inv16, sf, vb + DA, -d_cur, dst, h, w, P, wave - NW, lane);
+      }
+      // where the window goes NEXT: towards the mean tap row of the step before this one (complete: the barrier that ended it), two
+      // steps of G rows further down.  Decided here, one step ahead and by the wavefronts that flush, so that the others find it ready.
       const int* st = hdr + 4 * ((g + 2) % 3);
       const int n = __builtin_amdgcn_readfirstlane(st[2]);
-      int want = vb, cbn = 0;
-      if (n > 0) {
-        want = g * G + mean_of(__builtin_amdgcn_readfirstlane(st[0]), n) + (G + 1) / 2 - DA / 2;
-        cbn = xb - A.margin + mean_of(__builtin_amdgcn_readfirstlane(st[1]), n);
+      int d_next = 0, cbn = 0;
+      if (n > 0 && g + 1 < steps) {      // (after the last step the window stays: every wavefront flushes it from where it is)
+        const int want = (g + 1) * G + mean_of(__builtin_amdgcn_readfirstlane(st[0]), n) + (G + 1) / 2 - DA / 2;
+        d_next = max(min(want - vb, SL / 2), -(SL / 2));
       }
-      int d = 0;
-      if (g == 0) {
-        vb = want;                             // nothing in the window yet
-      } else {
-        d = max(min(want - vb, SL / 2), -(SL / 2));
-        if (d > 0) {                           // rows vb .. vb + d - 1 leave at the top
-          if (flusher) dsrc_flush_rows<NF>(dsrc_win, cbs, DR, WC, A.nq, A.nq_inv16, sb, vb, d, dst, h, w, P, wave - NW, lane);
-          vb += d; sb += d; sb -= sb >= DR ? DR : 0;
-        } else if (d < 0) {                    // rows vb + DA + d .. vb + DA - 1 leave at the bottom
-          int sf = sb + DA + d;
-          sf -= sf >= DR ? DR : 0;
-          if (flusher) dsrc_flush_rows<NF>(dsrc_win, cbs, DR, WC, A.nq, A.nq_inv16, sf, vb + DA + d, -d, dst, h, w, P, wave - NW, lane);
-          vb += d; sb += d; sb += sb < 0 ? DR : 0;
+      if (n > 0) cbn = xb - A.margin + mean_of(__builtin_amdgcn_readfirstlane(st[1]), n);
+      int sbn = sb + d_next;
+      sbn -= sbn >= DR ? DR : 0;
+      sbn += sbn < 0 ? DR : 0;
+      if (wave == NW + NF - 1) {
+        // the first column of the slack slots: the slots of the ring behind the active ones, except those being flushed right now
+        // (d_cur > 0: the last d_cur of them; d_cur < 0: the first -d_cur) -- clear, read by nobody during this step; the rows that
+        // enter the window with the next move (at most SL / 2 of them, at either end) are among them
+        if (n > 0 && lane < SL && (d_cur > 0 ? lane < SL - d_cur : lane >= -d_cur)) {
+          int slot = sb + DA + lane;
+          slot -= slot >= DR ? DR : 0;
+          cbs[slot] = cbn;
+        }
+        if (lane == 0) {
+          int* c = ctl + 2 * ((g + 1) % 3);
+          c[0] = vb + d_next; c[1] = sbn;
+          int* z = hdr + 4 * ((g + 1) % 3); z[0] = 0; z[1] = 0; z[2] = 0;     // the stats of the NEXT step: nobody reads or adds there now
         }
       }
-      // the first column of the slack slots: the slots of the ring behind the active ones, except those being flushed right now
-      // (d > 0: the last d of them; d < 0: the first -d) -- clear, read by nobody during this step
-      if (n > 0 && wave == NW + NF - 1 && lane < SL && (d > 0 ? lane < SL - d : lane >= -d)) {
-        int slot = sb + DA + lane;
-        slot -= slot >= DR ? DR : 0;
-        cbs[slot] = cbn;
-      }
-      if (tid == 0) { int* z = hdr + 4 * ((g + 1) % 3); z[0] = 0; z[1] = 0; z[2] = 0; }     // the stats of the NEXT step: nobody reads or adds there now
+      vb += d_next; sb = sbn; d_cur = d_next;      // (the window of the next step; this wavefront has nothing else to do in this one)
+    } else if (g > 0) {
+      const int* c = ctl + 2 * (g % 3);
+      vb = __builtin_amdgcn_readfirstlane(c[0]); sb = __builtin_amdgcn_readfirstlane(c[1]);
     }
     const Proj p = sample(r, dsp);
     const bool act = xvalid && r < h && p.inview;
@@ -312,14 +347,14 @@ __global__ void __launch_bounds__(64 * (NW + NF)) dsrc_scatter_kernel(const Dsrc
 hipError_t launch_dsrc_scatter(const DsrcArgs& a, hipStream_t st) {
   if (a.wgs <= 0) return hipSuccess;
   const size_t smem = dsrc_lds_bytes(a.win_rows, a.win_cols);
-  const void* fn = (const void*)&dsrc_scatter_kernel<DSRC_WAVES, DSRC_FLUSH_WAVES>;
-  static bool attr_set[64];      // per device; a benign race sets the same value twice
+  const void* fn = a.ref ? (const void*)&dsrc_scatter_kernel<DSRC_WAVES, DSRC_FLUSH_WAVES, true> : (const void*)&dsrc_scatter_kernel<DSRC_WAVES, DSRC_FLUSH_WAVES, false>;
+  static bool attr_set[64][2];      // per device; a benign race sets the same value twice
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); dev = -1; }
-  if (dev < 0 || !attr_set[dev]) {
+  if (dev < 0 || !attr_set[dev][a.ref != 0]) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, DSRC_LDS_BYTES);
     if (e != hipSuccess) return e;
-    if (dev >= 0) attr_set[dev] = true;
+    if (dev >= 0) attr_set[dev][a.ref != 0] = true;
   }
   DsrcArgs args = a;
   void* kargs[] = {&args};

@@ -575,7 +575,8 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, SSIM ? 3 : 4) loss_kerne
 // (REF, see loss_body: every launch of a descriptor with projection = SFM_PROJECTION_REFERENCE_ORDER; sfm_loss_ref.hip instantiates them)
 template <bool SSIM, bool GRAD, bool LOSS, bool EXPL, int SMODE, bool HWC, bool WARPED = false>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, (SSIM && GRAD) ? 3 : 4) loss_kernel_ref(SFM_HDR_PARAMS, const LossArgs A) {
-  loss_body<SSIM, GRAD, LOSS, EXPL, SMODE, HWC, WARPED, 1>(make_hdr(A, SFM_HDR_ARGS), A);
+  // (DSRC = GRAD: these kernels record dL/dI^ whenever the descriptor binds d_src -- a run-time test of one pointer and three stores)
+  loss_body<SSIM, GRAD, LOSS, EXPL, SMODE, HWC, WARPED, 1, GRAD>(make_hdr(A, SFM_HDR_ARGS), A);
 }
 // (PAIR, see loss_body: two sources per pass at two waves per SIMD; sfm_loss_pair.hip instantiates them)
 template <bool GRAD, bool LOSS, int SMODE>
@@ -606,10 +607,10 @@ const void* kernel_ptr_pair(bool grad, bool loss, int smode);
 constexpr int DSRC_WAVES = 8;             // wavefronts per workgroup that sample and add: one pixel row of 64 lanes each per step
 constexpr int DSRC_FLUSH_WAVES = 4;       // ... and that only flush
 constexpr int DSRC_MAX_SEGS = 2;          // a band is at most this many 64-lane segments wide
-constexpr int DSRC_MARGIN = 12;           // window columns on either side of the band (on top of the mean horizontal shift, which the window follows)
+constexpr int DSRC_MARGIN = 16;           // window columns on either side of the band (on top of the mean horizontal shift, which the window follows)
 constexpr int DSRC_LDS_BYTES = 156 * 1024;  // of the CU's 160 KiB: one workgroup per CU
-__host__ __device__ constexpr size_t dsrc_lds_bytes(const int rows, const int cols) {      // window, 12 ints of statistics, a first column per row
-  return (size_t)rows * cols * 3 * sizeof(double) + (12 + (size_t)rows) * sizeof(int); 
+__host__ __device__ constexpr size_t dsrc_lds_bytes(const int rows, const int cols) {      // window, 20 ints of statistics and control, a first column per row
+  return (size_t)rows * cols * 3 * sizeof(double) + (20 + (size_t)rows) * sizeof(int); 
 }
 struct DsrcScale {
   const float* rec;    // (B, 3 n_src, h, w): dL/dI^ of every warped pixel, written by the main launch
@@ -629,6 +630,7 @@ struct DsrcArgs {
   int margin;               // window columns on either side of the band
   int nq, nq_inv16;         // 64-column pieces of a window row, and ceil(2^16 / nq)
   int wgs;                  // workgroups
+  int ref;                  // SfmLossDesc.projection = SFM_PROJECTION_REFERENCE_ORDER: the samples in the reference's evaluation order
   unsigned long long* counters;   // development (SFM_DSRC_COUNT): samples with taps outside the window; normally nullptr
 };
 hipError_t launch_dsrc_scatter(const DsrcArgs& a, hipStream_t st);

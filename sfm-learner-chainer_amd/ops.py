@@ -362,9 +362,12 @@ class FusedLoss:
                 d.mask_logits[s] = masks[s].data_ptr()
                 d_masks.append(torch.empty_like(masks[s]))
                 d.d_mask[s] = d_masks[-1].data_ptr()
-            if want_d_src:      # always planar
+            # (want_d_src: True, or one flag per scale -- SfmLossDesc.d_src[s] may be NULL for any scale)
+            if (want_d_src[s] if isinstance(want_d_src, (list, tuple)) else want_d_src):      # always planar
                 d_srcs.append(torch.zeros((B, 3 * n_src, h, w), dtype=torch.float32, device=dev))
                 d.d_src[s] = d_srcs[-1].data_ptr()
+            else:
+                d_srcs.append(None)
             if want_warped:     # always planar
                 warped.append(torch.empty((B, n_src, 3, h, w), dtype=torch.float32, device=dev))
                 d.warped[s] = warped[-1].data_ptr()
@@ -387,7 +390,7 @@ class FusedLoss:
         self.desc, self.device = d, dev
         self._desc_ref, self._ws_arg, self._loss5_arg = C.byref(d), C.c_void_p(self._ws_ptr), _p(self.loss5)
         self.d_disps, self.d_poses, self.d_masks, self.d_srcs = d_disps, d_poses, (d_masks if use_masks else None), \
-            (d_srcs if want_d_src else None)
+            (d_srcs if any(t is not None for t in d_srcs) else None)
         self.warped = warped if want_warped else None
         self._keep = (tgt_pyr, src_pyr, intrinsics, disps, poses, masks)
         return self
@@ -425,7 +428,8 @@ class FusedLoss:
     def _zero_d_src(self):
         if self.d_srcs is not None:
             for t in self.d_srcs:
-                t.zero_()
+                if t is not None:
+                    t.zero_()
 
     def _launch(self, fn, *mid):
         """One call through the C ABI on the device's current stream.  The argument objects that never change between

@@ -39,15 +39,16 @@ def test_descriptor_layout_matches_the_header():
 
 
 def test_projection_field_is_validated_without_a_gpu():
-    """SfmLossDesc.projection (ABI v5): FAST and REFERENCE_ORDER size the same workspace; any other value, and REFERENCE_ORDER
-    together with d_src, are SFM_ERR_CONFIG from every entry point."""
+    """SfmLossDesc.projection (ABI v5): FAST and REFERENCE_ORDER size the same workspace, with and without d_src (since the d_src of
+    round 6's two launches both projections produce it); any other value is SFM_ERR_CONFIG from every entry point."""
     d = _desc(ssim_rate=0.15, smooth_reg=0.1, smooth_mode=_lib.SMOOTH_SECOND_ORDER)
     n = _lib.lib.sfm_loss_workspace_bytes(C.byref(d))
     d.projection = _lib.SFM_PROJECTION_REFERENCE_ORDER
     assert _lib.lib.sfm_loss_workspace_bytes(C.byref(d)) == n > 0
     d.d_src[0] = d.d_src[1] = 0x1000
-    assert _lib.lib.sfm_loss_workspace_bytes(C.byref(d)) == 0
-    assert _lib.lib.sfm_loss_fwd(C.byref(d), None, None, 0, None) == _lib.ERR_CONFIG and "d_src" in _lib.last_error()
+    with_d_src = _lib.lib.sfm_loss_workspace_bytes(C.byref(d))
+    d.projection = _lib.SFM_PROJECTION_FAST
+    assert _lib.lib.sfm_loss_workspace_bytes(C.byref(d)) == with_d_src > n
     d = _desc(projection=2)
     assert _lib.lib.sfm_loss_fwd(C.byref(d), None, None, 0, None) == _lib.ERR_CONFIG and "projection" in _lib.last_error()
 
@@ -72,6 +73,20 @@ def test_workspace_query_needs_no_gpu():
     assert n > 0 and n % 256 == 0
     assert _lib.lib.sfm_warp_bwd_workspace_bytes(2, 16, 24) == 2 * ((16 * 24 + 255) // 256) * 12 * 4
     assert _lib.lib.sfm_warp_bwd_workspace_bytes(0, 16, 24) == 0
+
+
+def test_workspace_with_d_src_holds_the_record_of_the_image_gradient():
+    """With SfmLossDesc.d_src bound the main launch records dL/dI^ of every warped pixel in the workspace (B x 3 n_src x h x w floats
+    per scale that binds it) for the second launch, dsrc_scatter_kernel: the query grows by exactly that, per bound scale."""
+    d = _desc(ssim_rate=0.15, smooth_reg=0.1, smooth_mode=_lib.SMOOTH_SECOND_ORDER)
+    base = _lib.lib.sfm_loss_workspace_bytes(C.byref(d))
+    rec = lambda s: -(-d.B * 3 * d.n_src * d.H[s] * d.W[s] * 4 // 256) * 256      # rounded up to the 256-byte alignment of a workspace array
+    d.d_src[0] = 0x1000
+    assert _lib.lib.sfm_loss_workspace_bytes(C.byref(d)) == base + rec(0)
+    d.d_src[1] = 0x1000
+    assert _lib.lib.sfm_loss_workspace_bytes(C.byref(d)) == base + rec(0) + rec(1)
+    d.d_src[0] = None
+    assert _lib.lib.sfm_loss_workspace_bytes(C.byref(d)) == base + rec(1)
 
 
 @pytest.mark.parametrize("bad,code", [

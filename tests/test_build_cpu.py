@@ -79,8 +79,9 @@ def test_loss_kernels_fit_their_register_budget(tmp_path):
             budget = 168 if ssim_grad else 128
         assert v["VGPRs"] <= budget, (k, v["VGPRs"])
     # the second launch of a call with d_src: 12 wavefronts per workgroup, one workgroup per CU (its LDS window): no register limit in sight
+    # (one per projection: it re-projects the pixels by the chain of the main launch)
     scat = [v for k, v in kernels.items() if "dsrc_scatter_kernel" in k]
-    assert len(scat) == 1 and scat[0]["unit"] == "sfm_loss_dsrc.hip" and scat[0]["VGPRs"] <= 128, scat
+    assert len(scat) == 2 and all(v["unit"] == "sfm_loss_dsrc.hip" and v["VGPRs"] <= 128 for v in scat), scat
     # the benchmarked kernel itself: its allocation is what the occupancy of DESIGN.md 4.1 rests on
     head = [v for k, v in loss.items() if "loss_kernelILb1ELb1ELb1ELb0ELi2ELb1ELb0E" in k]
     assert len(head) == 1 and head[0]["VGPRs"] <= 160 and head[0]["SGPRs Spill"] <= 5, head

@@ -861,10 +861,17 @@ def test_two_sources_per_pass_gives_the_one_source_results(ops, synth, dev, cfg_
     assert out[0] > 0
 
 
-def test_reference_order_projection_is_refused_together_with_d_src(ops, synth, dev):
-    d = synth.make_inputs(B=1, H=24, W=40, n_src=2, n_scales=2, seed=3, with_masks=True)
-    with pytest.raises(ValueError, match="d_src"):
-        _bind(ops, dev, d, CONFIGS["ssim_smooth"], want_d_src=True, layout="hwc", projection="reference_order")
+@pytest.mark.parametrize("layout", ["planar", "hwc"])
+def test_reference_order_projection_with_d_src(ops, synth, dev, layout):
+    """SFM_PROJECTION_REFERENCE_ORDER together with d_src (refused until the d_src of two launches: dsrc_scatter_kernel re-projects in
+    either order): the reference-order kernels record dL/dI^ themselves, the second launch samples by the reference's chain -- loss,
+    every gradient and d_src against the oracle."""
+    cfg = CONFIGS["edge_aware"]
+    d = synth.make_inputs(B=2, H=64, W=208, n_src=2, n_scales=3, seed=43)
+    ref = _oracle(d, cfg, want_d_src=True)
+    fl = _bind(ops, dev, d, cfg, want_d_src=True, layout=layout, projection="reference_order")
+    _check_losses(fl.forward_backward(), ref)
+    _check_grads(fl, ref, 2, check_src=True, what="REFERENCE-ORDER PROJECTION with d_src, edge_aware B=2 64x208 %s" % layout, **knife_widths(d, ref))
     with pytest.raises(ValueError, match="projection"):
         ops.FusedLoss(projection="exact")
 
@@ -953,12 +960,13 @@ def test_large_motion_vs_oracle(ops, synth, dev, motion, cfg_name, B, H, W, n_sr
 @pytest.mark.parametrize("motion", [None, "medium", "large", "behind"])
 def test_d_src_through_the_lds_window(ops, synth, dev, motion, cfg_name):
     """The optional dL/d(src) output (north_star: the backward "scatters dL/d(depth, pose, src_img)") at the BASELINE frame size:
-    the kernels accumulate it in a wave-private LDS window of 12 (SSIM kernels) or 6 source rows x 76 columns of 16-byte texels
-    (r, g, b, tag) that is re-centred on the mean tap row of every output row and reaches memory once per source row that leaves it
-    (csrc/sfm_ssim_pass.h, dsrc_scatter); taps outside the window go to memory directly.  Default motion keeps most taps inside the
-    window; `medium` / `large` / `behind` (wide and mirrored footprints, most of the frame out of view) exercise the direct path and
-    windows that jump in both directions.  d_src element-wise against the oracle outside the scatter footprints of knife-edge
-    pixels, loss and the other gradients by the usual criteria (the launch runs another instantiation of the kernel)."""
+    the gradient kernels record dL/dI^ of every warped pixel and a second launch (csrc/sfm_loss_dsrc.hip, dsrc_scatter_kernel)
+    re-projects the pixels and sums their taps in an LDS window of doubles per (sample, source, band of columns) that follows the
+    mean tap row and column of the band; a row that leaves the window reaches memory once, taps outside it go to memory directly.
+    Default motion keeps most taps inside the window; `medium` / `large` / `behind` (wide and mirrored footprints, most of the frame
+    out of view) exercise the direct path and windows that move in both directions.  d_src element-wise against the oracle outside
+    the scatter footprints of knife-edge pixels, loss and the other gradients by the usual criteria (the main launch runs another
+    instantiation of the kernel)."""
     cfg = CONFIGS[cfg_name]
     kw = dict(B=4, H=128, W=416, n_src=2, n_scales=4, with_masks=True)      # (the inputs of test_large_motion_vs_oracle)
     d = synth.make_inputs(seed=21, **kw) if motion is None else make_motion_inputs(synth, motion, seed=21, **kw)
@@ -981,12 +989,32 @@ def test_d_src_through_the_lds_window(ops, synth, dev, motion, cfg_name):
         np.testing.assert_allclose(to_np(t), 2.0 * a, rtol=0, atol=2e-5 * max(float(np.abs(w).max()), 1e-30))
 
 
+@pytest.mark.parametrize("layout", ["planar", "hwc"])
+def test_d_src_of_some_scales_only(ops, synth, dev, layout):
+    """SfmLossDesc.d_src[s] may be NULL for any scale: the scales that bind it get what they get when every scale binds it (the second
+    launch has workgroups for them only; the record of dL/dI^ in the workspace has room for them only), the loss and the other
+    gradients do not change."""
+    cfg = CONFIGS["ssim_smooth"]
+    d = synth.make_inputs(B=3, H=64, W=200, n_src=3, n_scales=4, seed=41)
+    full = _bind(ops, dev, d, cfg, want_d_src=True, layout=layout)
+    part = _bind(ops, dev, d, cfg, want_d_src=[False, True, False, True], layout=layout)
+    lf, lp = to_np(full.forward_backward()).copy(), to_np(part.forward_backward()).copy()
+    np.testing.assert_array_equal(lp, lf)
+    assert part.d_srcs[0] is None and part.d_srcs[2] is None
+    for s in (1, 3):      # the same sums, added in another order (float atomics)
+        a, b = to_np(full.d_srcs[s]), to_np(part.d_srcs[s])
+        assert np.abs(a).max() > 0
+        np.testing.assert_allclose(b, a, rtol=0, atol=2e-6 * np.abs(a).max())
+    for a, b in zip(full.d_disps + full.d_poses, part.d_disps + part.d_poses):
+        np.testing.assert_array_equal(to_np(b), to_np(a))
+
+
 @pytest.mark.parametrize("cfg_name", ["edge_aware", "l1_smooth"])
 def test_d_src_under_heavy_minification(ops, synth, dev, cfg_name):
-    """Round-5 advisor finding: the window's read-add-write is guarded by a tag per texel against several lanes of ONE instruction
-    landing on one texel.  Here the source is sampled with a minification of 3 - 10 (the camera pulled back by 3 along z, depths
-    0.1 - 2: U = cx + (x - cx) D / (D + tz)): runs of 3 - 10 neighbouring lanes share a texel in every tap instruction, the loop
-    around the tag goes round as many times, and d_src must still be the oracle's sum."""
+    """Several lanes of ONE instruction landing on one texel of the d_src window (round-5 advisor finding; since round 6 the adds are
+    LDS atomics on doubles, ds_add_f64, and the hardware serialises them).  Here the source is sampled with a minification of 3 - 10
+    (the camera pulled back by 3 along z, depths 0.1 - 2: U = cx + (x - cx) D / (D + tz)): runs of 3 - 10 neighbouring lanes share a
+    texel in every tap instruction, and d_src must still be the oracle's sum."""
     cfg = CONFIGS[cfg_name]
     d = synth.make_inputs(B=2, H=64, W=208, n_src=2, n_scales=3, seed=31, rot_sigma=0.002, trans_sigma=0.005)
     for p in d["poses"]:
