@@ -54,6 +54,9 @@ const void* kernel_ptr_dsrc(bool loss, bool ssim, bool expl, int smode, bool hwc
 // instructions per row and channel) and why the wavefronts that flush are not the ones that load (a wavefront that waits for a load
 // waits for every atomic it issued before it: one in-order counter).
 // ------------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(4))) DsrcRec {      // dL/dI^ of one warped pixel, as the main launch stores it (geometry_backward)
+  float c[3];
+};
 __device__ __forceinline__ void dsrc_lds_add(double* p, const double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -135,9 +138,9 @@ __global__ void __launch_bounds__(64 * (NW + NF)) dsrc_scatter_kernel(const Dsrc
   const unsigned xc = (unsigned)min(x, w - 1);
 
   // the projection rows of (sample, scale, source): what loss_body hands its passes, for either projection
-  WaveGeom WG;
-  WaveGeomRef WGR;
-  build_wave_geom_any<REF>(A.pose, A.n_src, b, A.intrinsics + (size_t)(b * A.n_scales + s) * 9, lane, WG, WGR);
+  WaveGeom WG = {0.f, 0.f, 0.f, 0.f};
+  WaveGeomRef WGR = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (!flusher) build_wave_geom_any<REF>(A.pose, A.n_src, b, A.intrinsics + (size_t)(b * A.n_scales + s) * 9, lane, WG, WGR);
   const float xf = (float)x;
   const ScaleConst sc = make_scale_const(h, w);
   SsimCtx C;       // (only the fields the projection reads are ever set or used)
@@ -193,7 +196,8 @@ __global__ void __launch_bounds__(64 * (NW + NF)) dsrc_scatter_kernel(const Dsrc
     const int r = rsub;
     const bool valid = xvalid && r < h;
     const unsigned o = (unsigned)min(r, h - 1) * (unsigned)w + xc;
-    g0 = valid ? rec[o] : 0.f; g1 = valid ? rec[o + P] : 0.f; g2 = valid ? rec[o + 2 * P] : 0.f;
+    const DsrcRec gv = reinterpret_cast<const DsrcRec*>(rec)[o];
+    g0 = valid ? gv.c[0] : 0.f; g1 = valid ? gv.c[1] : 0.f; g2 = valid ? gv.c[2] : 0.f;
     dsp = dpl[o];
   }
 
@@ -228,7 +232,8 @@ __global__ void __launch_bounds__(64 * (NW + NF)) dsrc_scatter_kernel(const Dsrc
       const int rn = r + G;
       const bool nvalid = xvalid && rn < h;
       const unsigned o = (unsigned)min(rn, h - 1) * (unsigned)w + xc;
-      n0 = nvalid ? rec[o] : 0.f; n1 = nvalid ? rec[o + P] : 0.f; n2 = nvalid ? rec[o + 2 * P] : 0.f;
+      const DsrcRec gv = reinterpret_cast<const DsrcRec*>(rec)[o];
+      n0 = nvalid ? gv.c[0] : 0.f; n1 = nvalid ? gv.c[1] : 0.f; n2 = nvalid ? gv.c[2] : 0.f;
       ndsp = dpl[o];
     }
     if (flusher) {
@@ -300,42 +305,39 @@ __global__ void __launch_bounds__(64 * (NW + NF)) dsrc_scatter_kernel(const Dsrc
       const float fu1 = 1.f - p.fu, fv1 = 1.f - p.fv;
       const float wt[4] = {fu1 * fv1, p.fu * fv1, fu1 * p.fv, p.fu * p.fv};
       const float gI[3] = {g0, g1, g2};
+      // the taps inside the window: LDS adds on doubles, predicated tap by tap (in the usual case all four of every sample are inside)
+      const bool in4[4] = {act && r0 && (unsigned)cu0 < (unsigned)WC, act && r0 && (unsigned)(cu0 + 1) < (unsigned)WC,
+                           act && r1 && (unsigned)cu1 < (unsigned)WC, act && r1 && (unsigned)(cu1 + 1) < (unsigned)WC};
+      const int ad4[4] = {a0, a0 + 1, a1, a1 + 1};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (in4[k]) {
+          double* t = dsrc_win + ad4[k];
+          dsrc_lds_add(t, (double)(gI[0] * wt[k]));
+          dsrc_lds_add(t + PL, (double)(gI[1] * wt[k]));
+          dsrc_lds_add(t + 2 * PL, (double)(gI[2] * wt[k]));
+        }
+      }
+      // the taps outside it (above, below or beside): straight to memory, all of a sample's in one divergent block
       const bool miss = act && !(in0 && in1);
-      if (A.counters && lane == 0) atomicAdd(A.counters, (unsigned long long)__builtin_popcountll(m));      // diagnostics: in-view samples
-      if (__builtin_amdgcn_ballot_w64(miss) == 0) {        // the usual case: every sample of the row has its four taps in the window
-        if (act) {
-          const int ad4[4] = {a0, a0 + 1, a1, a1 + 1};
+      if (__builtin_amdgcn_ballot_w64(miss) != 0) {
+        if (miss) {
+          float* o = dst + (unsigned)(p.v0 * w + p.u0);
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            double* t = dsrc_win + ad4[k];
-            dsrc_lds_add(t, (double)(gI[0] * wt[k]));
-            dsrc_lds_add(t + PL, (double)(gI[1] * wt[k]));
-            dsrc_lds_add(t + 2 * PL, (double)(gI[2] * wt[k]));
+            if (!in4[k]) {
+              float* ok = o + (k >> 1) * w + (k & 1);
+#pragma unroll
+              for (int c = 0; c < 3; ++c) atomicAdd(ok + c * P, gI[c] * wt[k]);
+            }
           }
         }
-      } else {
-        const bool in4[4] = {act && r0 && (unsigned)cu0 < (unsigned)WC, act && r0 && (unsigned)(cu0 + 1) < (unsigned)WC,
-                             act && r1 && (unsigned)cu1 < (unsigned)WC, act && r1 && (unsigned)(cu1 + 1) < (unsigned)WC};
-        const int ad4[4] = {a0, a0 + 1, a1, a1 + 1};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float val[3] = {gI[0] * wt[k], gI[1] * wt[k], gI[2] * wt[k]};
-          if (in4[k]) {
-            double* t = dsrc_win + ad4[k];
-            dsrc_lds_add(t, (double)val[0]);
-            dsrc_lds_add(t + PL, (double)val[1]);
-            dsrc_lds_add(t + 2 * PL, (double)val[2]);
-          } else if (act) {         // outside the window (above, below or beside it): straight to memory
-            float* o = dst + (unsigned)((p.v0 + (k >> 1)) * w + p.u0 + (k & 1));
-#pragma unroll
-            for (int c = 0; c < 3; ++c) atomicAdd(o + c * P, val[c]);
-          }
-        }
-        if (A.counters) {      // diagnostics (sfm_dsrc_debug_counters): taps of this row that missed the window, by rows / by columns only
+        if (A.counters) {      // diagnostics (SFM_DSRC_COUNT): samples of this row with a tap outside the window, by rows / by columns only
           const unsigned long long mr = __builtin_amdgcn_ballot_w64(act && !(r0 && r1)), mc = __builtin_amdgcn_ballot_w64(act && r0 && r1 && !(in0 && in1));
           if (lane == 0) { atomicAdd(A.counters + 1, (unsigned long long)__builtin_popcountll(mr)); atomicAdd(A.counters + 2, (unsigned long long)__builtin_popcountll(mc)); }
         }
       }
+      if (A.counters && lane == 0) atomicAdd(A.counters, (unsigned long long)__builtin_popcountll(m));      // diagnostics: in-view samples
     }
     __syncthreads();
     g0 = n0; g1 = n1; g2 = n2; dsp = ndsp;

@@ -20,7 +20,7 @@ struct ScaleArgs {
   const float* mlog;
   float* d_disp;
   float* d_mask;
-  float* d_src;                // with d_src bound: the RECORD of dL/dI^ (B, 3 n_src, h, w) in the workspace that dsrc_scatter_kernel reads
+  float* d_src;                // with d_src bound: the RECORD of dL/dI^ (B, n_src, h, w, 3) in the workspace that dsrc_scatter_kernel reads
   float* warped;               // optional output (B,n_src,3,h,w): the warped sources, base_model.py:90-94
   int h, w, strips, chunks, tiles, item_begin, chunk_rows;
   float inv_cnt;               // 1 / (norm_B * 3 * h * w)                 base_model.py:111,115
@@ -613,7 +613,7 @@ __host__ __device__ constexpr size_t dsrc_lds_bytes(const int rows, const int co
   return (size_t)rows * cols * 3 * sizeof(double) + (20 + (size_t)rows) * sizeof(int); 
 }
 struct DsrcScale {
-  const float* rec;    // (B, 3 n_src, h, w): dL/dI^ of every warped pixel, written by the main launch
+  const float* rec;    // (B, n_src, h, w, 3): dL/dI^ of every warped pixel, written by the main launch
   const float* disp;   // (B, 1, h, w)
   float* d_src;        // (B, 3 n_src, h, w), accumulated into
   int h, w;

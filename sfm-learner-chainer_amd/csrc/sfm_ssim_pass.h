@@ -682,10 +682,11 @@ __device__ __forceinline__ void geometry_backward(const SsimCtx& C, const RowS& 
   // (DSRC: the instantiations a launch with SfmLossDesc.d_src bound runs: they record dL/dI^ of the pixel for dsrc_scatter_kernel,
   //  which applies the in-view test itself.  Instantiations of their own so that no other launch carries the branch.)
   if (DSRC && C.dsp != nullptr && C.outb) {
+    // (pixel-interleaved: one 12-byte store here, one 12-byte load there)
+    struct __attribute__((packed, aligned(4))) Rec { float c[3]; };
     const unsigned o = (unsigned)rc * (unsigned)w + (unsigned)(C.x0 + C.lane);
-    C.dsp[o] = gI[0];
-    C.dsp[o + (unsigned)C.P] = gI[1];
-    C.dsp[o + 2u * (unsigned)C.P] = gI[2];
+    Rec g; g.c[0] = gI[0]; g.c[1] = gI[1]; g.c[2] = gI[2];
+    reinterpret_cast<Rec*>(C.dsp)[o] = g;
   }
   (void)h;
 }
