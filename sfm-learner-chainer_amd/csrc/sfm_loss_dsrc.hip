@@ -194,10 +194,11 @@ __global__ void __launch_bounds__(64 * (NW + NF)) dsrc_scatter_kernel(const Dsrc
   float g0 = 0.f, g1 = 0.f, g2 = 0.f, dsp = 1.f;
   if (!flusher) {
     const int r = rsub;
-    const bool valid = xvalid && r < h;
+    // (clamped addresses, nothing selected on the loaded values: a select would wait for the load where it is issued; pixels outside
+    //  the band or the image are masked where they are used)
     const unsigned o = (unsigned)min(r, h - 1) * (unsigned)w + xc;
     const DsrcRec gv = reinterpret_cast<const DsrcRec*>(rec)[o];
-    g0 = valid ? gv.c[0] : 0.f; g1 = valid ? gv.c[1] : 0.f; g2 = valid ? gv.c[2] : 0.f;
+    g0 = gv.c[0]; g1 = gv.c[1]; g2 = gv.c[2];
     dsp = dpl[o];
   }
 
@@ -230,10 +231,9 @@ __global__ void __launch_bounds__(64 * (NW + NF)) dsrc_scatter_kernel(const Dsrc
     float n0 = 0.f, n1 = 0.f, n2 = 0.f, ndsp = 1.f;
     if (!flusher) {
       const int rn = r + G;
-      const bool nvalid = xvalid && rn < h;
       const unsigned o = (unsigned)min(rn, h - 1) * (unsigned)w + xc;
       const DsrcRec gv = reinterpret_cast<const DsrcRec*>(rec)[o];
-      n0 = nvalid ? gv.c[0] : 0.f; n1 = nvalid ? gv.c[1] : 0.f; n2 = nvalid ? gv.c[2] : 0.f;
+      n0 = gv.c[0]; n1 = gv.c[1]; n2 = gv.c[2];
       ndsp = dpl[o];
     }
     if (flusher) {
