@@ -343,6 +343,12 @@ class FusedLoss:
         d.image_layout = _lib.SFM_LAYOUT_HWC if hwc else _lib.SFM_LAYOUT_PLANAR
         d.projection = self.projection
         d_disps, d_masks, d_srcs, warped = [], [], [], []
+        # the d_src arrays of all bound scales are views of ONE allocation: the library accumulates into them (float atomics), so every
+        # backward starts by clearing them -- one fill kernel instead of one per scale
+        want_src = [bool(want_d_src[s] if isinstance(want_d_src, (list, tuple)) else want_d_src) for s in range(S)]
+        src_numel = [B * 3 * n_src * int(disps[s].shape[2]) * int(disps[s].shape[3]) if want_src[s] else 0 for s in range(S)]
+        self._d_src_all = torch.zeros((sum(src_numel),), dtype=torch.float32, device=dev) if any(want_src) else None
+        src_off = 0
         for s in range(S):
             h, w = disps[s].shape[2:]
             if hwc:
@@ -363,8 +369,9 @@ class FusedLoss:
                 d_masks.append(torch.empty_like(masks[s]))
                 d.d_mask[s] = d_masks[-1].data_ptr()
             # (want_d_src: True, or one flag per scale -- SfmLossDesc.d_src[s] may be NULL for any scale)
-            if (want_d_src[s] if isinstance(want_d_src, (list, tuple)) else want_d_src):      # always planar
-                d_srcs.append(torch.zeros((B, 3 * n_src, h, w), dtype=torch.float32, device=dev))
+            if want_src[s]:      # always planar
+                d_srcs.append(self._d_src_all[src_off:src_off + src_numel[s]].view(B, 3 * n_src, h, w))
+                src_off += src_numel[s]
                 d.d_src[s] = d_srcs[-1].data_ptr()
             else:
                 d_srcs.append(None)
@@ -427,9 +434,7 @@ class FusedLoss:
 
     def _zero_d_src(self):
         if self.d_srcs is not None:
-            for t in self.d_srcs:
-                if t is not None:
-                    t.zero_()
+            self._d_src_all.zero_()
 
     def _launch(self, fn, *mid):
         """One call through the C ABI on the device's current stream.  The argument objects that never change between
