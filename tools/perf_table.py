@@ -73,7 +73,7 @@ NAMES = [("cfg3", "cfg3, 2nd-order smoothness (the reference's live code)", "cfg
          ("cfg5_2src_smooth_disp", "cfg5 as parenthesised (2 src) on the smooth disparity field", None),
          ("cfg1", "cfg1 B=1, 1 scale, L1", None),
          ("ref_b4", "the reference's training regime: B=4, 4 scales, L1 only (`sfm_learner_v1.yml`)", "ref_b4_hwc_fused"),
-         ("cfg3_d_src", "cfg3 as written with the optional dL/d(src) bound", None),
+         ("cfg3_d_src", "cfg3 as written with the optional dL/d(src) bound (two launches; the kernel columns: the first one)", None),
          ("cfg3_d_src_smooth_disp", "... the same on the smooth disparity field", None)]
 for key, label, variant in NAMES:
     q = b.get(key)
