@@ -615,7 +615,7 @@ def sfm_loss(tgt_pyr, src_pyr, intrinsics, disps, poses, masks=None, *,
     d_poses = [np.zeros((B, 6), dtype=dtype) for _ in range(n_src)]
     d_masks = [np.zeros_like(np.asarray(masks[s], dtype=dtype)) for s in range(S)] if do_exp else None
     d_srcs = [np.zeros_like(np.asarray(src_pyr[s], dtype=dtype)) for s in range(S)] if want_d_src else None
-    warped_all, margin_all, cell_all, abs_all, clip_all, uv_all = [], [], [], [], [], []
+    warped_all, margin_all, cell_all, abs_all, clip_all, uv_all, zero_all = [], [], [], [], [], [], []
 
     for s in range(S):
         tgt = np.asarray(tgt_pyr[s], dtype=dtype)
@@ -640,7 +640,7 @@ def sfm_loss(tgt_pyr, src_pyr, intrinsics, disps, poses, masks=None, *,
         depth = dtype(1) / disp                                                # :60
         depthes = np.broadcast_to(depth.reshape(B, 1, P), (B, 3, P))           # :82-84
         K = np.asarray(intrinsics, dtype=dtype)[:, s]                          # :85
-        w_s, m_s, c_s, a_s, k_s, uv_s = [], [], [], [], [], []
+        w_s, m_s, c_s, a_s, k_s, uv_s, z_s = [], [], [], [], [], [], []
         for i in range(n_src):                                                 # :88
             img = src[:, 3 * i:3 * i + 3]
             proj, aux = projective_inverse_warp(img, depthes, poses[i], K, dtype, return_aux=True)   # :90-94
@@ -690,12 +690,14 @@ def sfm_loss(tgt_pyr, src_pyr, intrinsics, disps, poses, masks=None, *,
                 k_s.append(clip_m if (ssim_rate and not do_exp) else np.ones_like(aux["margin"]))
                 ad = np.abs(proj - tgt)
                 a_s.append(np.where(m[:, 0], dtype(1), np.where(ad > 0, ad, dtype(1)).min(axis=1)))
+                z_s.append(~m[:, 0] & (ad == 0).any(axis=1))      # a channel with I^ == I exactly: sign(0) = 0 here, +-1 one ulp away
                 uv_s.append(np.concatenate([aux["U"], aux["V"]], axis=1).reshape(B, 2, h, w))
         if keep_warped:
             warped_all.append(np.stack(w_s, axis=1))       # (B,n,3,h,w)
             margin_all.append(np.stack(m_s, axis=1))       # (B,n,h,w)
             cell_all.append(np.stack(c_s, axis=1))         # (B,n,h,w)
             abs_all.append(np.stack(a_s, axis=1))          # (B,n,h,w)  smallest non-zero |I^ - I| (kink of |.|)
+            zero_all.append(np.stack(z_s, axis=1))         # (B,n,h,w)  in view and I^ == I exactly in some channel (ON the kink)
             clip_all.append(np.stack(k_s, axis=1))         # (B,n,h,w)  distance of (1-SSIM)/2 to the clip kinks
             uv_all.append(np.stack(uv_s, axis=1))          # (B,n,2,h,w) sampling position (U, V) in source pixels
 
@@ -705,7 +707,7 @@ def sfm_loss(tgt_pyr, src_pyr, intrinsics, disps, poses, masks=None, *,
     if backward:
         res.update(d_disps=d_disps, d_poses=d_poses, d_masks=d_masks, d_srcs=d_srcs)
     if keep_warped:
-        res.update(warped=warped_all, margin=margin_all, cell_margin=cell_all, abs_margin=abs_all, clip_margin=clip_all, uv=uv_all)
+        res.update(warped=warped_all, margin=margin_all, cell_margin=cell_all, abs_margin=abs_all, abs_zero=zero_all, clip_margin=clip_all, uv=uv_all)
     return res
 
 

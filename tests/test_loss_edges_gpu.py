@@ -147,12 +147,15 @@ def test_random_shapes_and_modes(ops, synth, dev, B, H, W, n_src, n_scales, cfg_
     oracle's), and only their reach -- never more than the oracle-side bound -- is added.  A d_pose array that misses its criteria
     is accepted only when the oracle, re-run with named knife-edge pixels pushed across the discontinuity they sit on, matches the
     kernel by the flat criteria (pose_explained_by_discontinuities).  All of it is reported."""
-    from test_loss_gpu import count_in_view_mismatches, knife_cap, knife_mask
+    from test_loss_gpu import count_in_view_mismatches, knife_cap, knife_mask, knife_widths
     from util import parity_note
     cfg = CONFIGS[cfg_name]
+    # (SFM_SWEEP_D_SRC=1: the same sweep with the optional dL/d(src) bound -- a soak of the two-launch d_src over shapes, batch sizes,
+    #  source counts, loss modes, layouts and, with SFM_SWEEP_PROJECTION, both projections)
+    want_src = os.environ.get("SFM_SWEEP_D_SRC") == "1"
     for attempt in range(16):
         d = synth.make_inputs(B=B, H=H, W=W, n_src=n_src, n_scales=n_scales, seed=(seed + attempt) % 10000, with_masks=True)
-        ref = _oracle(d, cfg)
+        ref = _oracle(d, cfg, want_d_src=want_src)
         flips = sum(int((ref["margin"][s_] < 8e-6).sum()) for s_ in range(n_scales))
         flip_reach = sum(float((ref["margin"][s_] < 8e-6).sum()) * 3.0 / (B * ref["margin"][s_].shape[-2] * ref["margin"][s_].shape[-1])
                          for s_ in range(n_scales))
@@ -169,7 +172,7 @@ def test_random_shapes_and_modes(ops, synth, dev, B, H, W, n_src, n_scales, cfg_
     layout = "hwc" if seed % 2 else "planar"                                   # both image layouts take part in the sweep
     # (SFM_SWEEP_PROJECTION=reference_order runs the same sweep with SfmLossDesc.projection = SFM_PROJECTION_REFERENCE_ORDER: a soak of
     #  that mode over shapes, batch sizes, source counts, loss modes and layouts)
-    fl = _bind(ops, dev, d, cfg, layout=layout, projection=os.environ.get("SFM_SWEEP_PROJECTION", "fast"))
+    fl = _bind(ops, dev, d, cfg, layout=layout, projection=os.environ.get("SFM_SWEEP_PROJECTION", "fast"), want_d_src=want_src)
     plain = dict(d, masks=None)
     count_in_view_mismatches(ops, dev, plain, ref, layout, "sweep %s %dx%d" % (cfg_name, H, W))
     counted = sum(c * 3.0 / (B * ref["margin"][s_].shape[-2] * ref["margin"][s_].shape[-1])
@@ -180,10 +183,14 @@ def test_random_shapes_and_modes(ops, synth, dev, B, H, W, n_src, n_scales, cfg_
     _check_losses(fl.forward(), ref, slack=slack)
     _check_losses(fl.forward_backward(), ref, slack=slack)
     ref64 = lambda: O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], d["masks"], backward=True,
-                               dtype=np.float64, **cfg)
+                               want_d_src=want_src, dtype=np.float64, **cfg)
     from test_loss_gpu import pose_explained_by_discontinuities
-    _check_grads(fl, ref, n_src, check_mask=bool(cfg.get("exp_reg")), what="sweep %s %dx%d" % (cfg_name, H, W), ref64=ref64,
-                 explain=lambda i, got: pose_explained_by_discontinuities(d, cfg, ref, i, got))
+    _check_grads(fl, ref, n_src, check_src=want_src, check_mask=bool(cfg.get("exp_reg")), what="sweep %s %dx%d" % (cfg_name, H, W), ref64=ref64,
+                 explain=lambda i, got: pose_explained_by_discontinuities(d, cfg, ref, i, got),
+                 # (d_src is compared element-wise without a second opinion: like the d_src tests, the soak takes the knife classes at
+                 #  the width the fp32 uncertainty of each sample's position gives them -- tools/diag_sweep_dsrc.py: where the flat widths
+                 #  leave an element off, the kernel agrees with the fp64 oracle to the last digit and the fp32 oracle does not)
+                 **(knife_widths(d, ref) if want_src else {}))
 
 
 @pytest.mark.parametrize("B,H,W,n_src,n_scales,cfg_name", [(2, 14, 30, 2, 1, "ssim_smooth"), (3, 16, 26, 3, 1, "edge_aware"), (1, 12, 40, 2, 1, "l1_smooth")])
