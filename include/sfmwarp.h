@@ -179,7 +179,8 @@ typedef struct SfmLossDesc {
   int32_t projection;            /* SFM_PROJECTION_* (ABI v5); 0 = SFM_PROJECTION_FAST        */
 } SfmLossDesc;
 
-/* scratch needed by the three calls below for this descriptor (0 on a bad descriptor) */
+/* scratch needed by the three calls below for this descriptor (0 on a bad descriptor).  It depends on the shapes, on n_src and on
+ * WHICH d_src[] are bound: query with the descriptor the calls will get. */
 size_t sfm_loss_workspace_bytes(const SfmLossDesc *desc);
 
 /* loss5 (device, 5 floats): total, pixel, smooth, exp, ssim -- the chainer.report keys

@@ -582,6 +582,8 @@ static int make_plan(const SfmLossDesc* d, bool grad, bool need_loss, bool need_
     if (p.hwc && (long long)h * w * 12 >= (1ll << 24))
       return fail(SFM_ERR_SHAPE, "sfm_loss: scale %d is %dx%d, SFM_LAYOUT_HWC takes images of fewer than 2^24 / 12 pixels", s, h, w);
     if (!d->tgt[s] || !d->src[s] || !d->disp[s]) return fail(SFM_ERR_NULL, "sfm_loss: tgt/src/disp[%d] is NULL", s);
+    // (the second launch of a call with d_src addresses the record of one (sample, source) with 32-bit byte offsets)
+    if (d->d_src[s] && (long long)h * w * 12 >= (1ll << 32)) return fail(SFM_ERR_SHAPE, "sfm_loss: scale %d is %dx%d, d_src takes images of fewer than 2^32 / 12 pixels", s, h, w);
     if (p.expl && !d->mask_logits[s]) return fail(SFM_ERR_NULL, "sfm_loss: exp_reg > 0 but mask_logits[%d] is NULL", s);
     ScaleArgs& S = A.sc[s];
     S.tgt = d->tgt[s];

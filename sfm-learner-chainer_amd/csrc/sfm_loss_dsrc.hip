@@ -49,14 +49,17 @@ const void* kernel_ptr_dsrc(bool loss, bool ssim, bool expl, int smode, bool hwc
 // column (cbs[slot], set while the slot is slack and clear, from the mean horizontal shift of the step before): the window follows
 // the samples sideways as well, row by row, without a column ever having to move.
 //
-// What bounds this launch is the float atomics of the flush: every row of every window goes to memory as dense 256-byte atomic
-// instructions, ~50 ns each per CU (MI355X_MICROARCH.md, global float atomics), which is why a window is 128 columns (two
-// instructions per row and channel) and why the wavefronts that flush are not the ones that load (a wavefront that waits for a load
-// waits for every atomic it issued before it: one in-order counter).
+// What bounds this launch (profiles/r06_d_src.txt): the instruction stream of the sampling wavefronts -- two of them per SIMD, ~300 vector
+// and ~140 scalar instructions per pixel row each; the flushing wavefronts wait at the barrier for four fifths of a step.  They are
+// wavefronts of their own because loads and atomics share one in-order counter (a wavefront that waits for a load waits for every atomic
+// it issued before it), and the flush itself -- 71 MB of dense float atomics per cfg3 step -- needs ~55 us of the chip's atomic rate.
 // ------------------------------------------------------------------------------------------
 struct __attribute__((packed, aligned(4))) DsrcRec {      // dL/dI^ of one warped pixel, as the main launch stores it (geometry_backward)
   float c[3];
 };
+__device__ __forceinline__ float* at_off(float* base, const unsigned byte_off) {      // (a 32-bit offset from a wave-uniform base)
+  return reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off);
+}
 __device__ __forceinline__ void dsrc_lds_add(double* p, const double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -197,9 +200,9 @@ __global__ void __launch_bounds__(64 * (NW + NF)) dsrc_scatter_kernel(const Dsrc
     // (clamped addresses, nothing selected on the loaded values: a select would wait for the load where it is issued; pixels outside
     //  the band or the image are masked where they are used)
     const unsigned o = (unsigned)min(r, h - 1) * (unsigned)w + xc;
-    const DsrcRec gv = reinterpret_cast<const DsrcRec*>(rec)[o];
+    const DsrcRec gv = ld_off<DsrcRec>(rec, 12u * o);      // (32-bit byte offsets from wave-uniform bases: no 64-bit vector arithmetic)
     g0 = gv.c[0]; g1 = gv.c[1]; g2 = gv.c[2];
-    dsp = dpl[o];
+    dsp = ldf(dpl, o);
   }
 
   // placement: the first step's own samples (a pass without adds)
@@ -232,9 +235,9 @@ __global__ void __launch_bounds__(64 * (NW + NF)) dsrc_scatter_kernel(const Dsrc
     if (!flusher) {
       const int rn = r + G;
       const unsigned o = (unsigned)min(rn, h - 1) * (unsigned)w + xc;
-      const DsrcRec gv = reinterpret_cast<const DsrcRec*>(rec)[o];
+      const DsrcRec gv = ld_off<DsrcRec>(rec, 12u * o);
       n0 = gv.c[0]; n1 = gv.c[1]; n2 = gv.c[2];
-      ndsp = dpl[o];
+      ndsp = ldf(dpl, o);
     }
     if (flusher) {
       // the rows the move INTO this step's window (d_cur, decided a step ago) pushed out of its active part: to memory, now
@@ -292,13 +295,17 @@ __global__ void __launch_bounds__(64 * (NW + NF)) dsrc_scatter_kernel(const Dsrc
       int s1 = sb + (r1 ? rel + 1 : 0);
       s1 -= s1 >= DR ? DR : 0;
       const int cu0 = p.u0 - cbs[s0], cu1 = p.u0 - cbs[s1];
-      float v2[2] = {act ? clampd(p.v0 - r) : 0.f, act ? clampd(p.u0 - x) : 0.f};
-      wave_sums_lockstep(v2);                  // (under the latency of the two reads)
-      if (lane == 63) {
-        int* st = hdr + 4 * (g % 3);
-        atomicAdd(&st[0], (int)v2[0]);
-        atomicAdd(&st[1], (int)v2[1]);
-        atomicAdd(&st[2], (int)__builtin_popcountll(m));
+      // the statistics that place the window: from the wavefronts of every other image row of the step (all segments: the horizontal
+      // shift varies along a row; half the samples of a step are plenty for a mean)
+      if ((rsub & 1) == 0) {
+        float v2[2] = {act ? (float)(p.v0 - r) : 0.f, act ? (float)(p.u0 - x) : 0.f};      // (in view: within the image, exact in fp32)
+        wave_sums_lockstep(v2);                  // (under the latency of the two reads)
+        if (lane == 63) {
+          int* st = hdr + 4 * (g % 3);
+          atomicAdd(&st[0], (int)v2[0]);
+          atomicAdd(&st[1], (int)v2[1]);
+          atomicAdd(&st[2], (int)__builtin_popcountll(m));
+        }
       }
       const bool in0 = r0 && (unsigned)cu0 < (unsigned)(WC - 1), in1 = r1 && (unsigned)cu1 < (unsigned)(WC - 1);   // both columns of the row inside
       const int a0 = s0 * WC + cu0, a1 = s1 * WC + cu1;
@@ -322,13 +329,13 @@ __global__ void __launch_bounds__(64 * (NW + NF)) dsrc_scatter_kernel(const Dsrc
       const bool miss = act && !(in0 && in1);
       if (__builtin_amdgcn_ballot_w64(miss) != 0) {
         if (miss) {
-          float* o = dst + (unsigned)(p.v0 * w + p.u0);
+          const unsigned o4 = 4u * (unsigned)(p.v0 * w + p.u0), P4 = 4u * P;      // byte offsets into the three planes
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             if (!in4[k]) {
-              float* ok = o + (k >> 1) * w + (k & 1);
+              const unsigned ok = o4 + 4u * (unsigned)((k >> 1) * w + (k & 1));
 #pragma unroll
-              for (int c = 0; c < 3; ++c) atomicAdd(ok + c * P, gI[c] * wt[k]);
+              for (int c = 0; c < 3; ++c) atomicAdd(at_off(dst, ok + c * P4), gI[c] * wt[k]);
             }
           }
         }
