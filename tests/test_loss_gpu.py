@@ -1063,6 +1063,31 @@ def test_large_motion_full_batch_vs_oracle(ops, synth, dev, motion):
     _check_grads(fl, ref, 2, what=what, ref64=ref64, **knife_widths(d, ref))
 
 
+@pytest.mark.parametrize("smooth_field", [False, True])
+def test_d_src_full_batch_vs_oracle(ops, synth, dev, smooth_field):
+    """d_src at BASELINE cfg3's FULL batch (B=32, as written, pixel-interleaved): the launches bench.py's `cfg3_d_src` and
+    `cfg3_d_src_smooth_disp` keys time -- 512 workgroups of the second launch in two rounds over the chip, windows that move every
+    step, the samples outside them on the direct path -- against the oracle, d_src element-wise."""
+    cfg = CONFIGS["edge_aware"]
+    kw = dict(disp_div=32, disp_noise=0.0) if smooth_field else {}
+    d = synth.make_inputs(B=32, H=128, W=416, n_src=2, n_scales=4, seed=1, **kw)
+    ref = _oracle(d, cfg, want_d_src=True)
+    ref64 = lambda: O.sfm_loss(d["tgt_pyr"], d["src_pyr"], d["intrinsics"], d["disps"], d["poses"], None, backward=True, want_d_src=True,
+                               keep_warped=True, dtype=np.float64, **cfg)
+    what = "D_SRC FULL BATCH edge_aware B=32 128x416 hwc%s" % (" smooth disparity field" if smooth_field else "")
+    fl = _bind(ops, dev, d, cfg, want_d_src=True, layout="hwc")
+    _check_losses(fl.forward_backward(), ref)
+    _check_grads(fl, ref, 2, check_src=True, what=what, ref64=ref64, **knife_widths(d, ref))
+    # ... and a second call accumulates the same sums again (float atomics: to rounding)
+    first = [to_np(t).copy() for t in fl.d_srcs]
+    keep = fl._zero_d_src
+    fl._zero_d_src = lambda: None
+    fl.backward(1.0)
+    fl._zero_d_src = keep
+    for a, t in zip(first, fl.d_srcs):
+        np.testing.assert_allclose(to_np(t), 2.0 * a, rtol=0, atol=2e-5 * max(float(np.abs(a).max()), 1e-30))
+
+
 @pytest.mark.parametrize("cfg_name,B,H,W,n_src", [
     ("ssim_smooth", 32, 128, 416, 2),     # BASELINE cfg3 / cfg4's per-GPU share, live smoothness form
     ("edge_aware", 32, 128, 416, 2),      # BASELINE cfg3 as written (edge-aware smoothness)
